@@ -1,0 +1,83 @@
+"""ctypes binding of csrc/libgct2.so (the C ABI declared in include/gct2.h).
+
+There is NO fallback: if the shared library is missing or a call returns non-zero, this module
+raises.  Nothing here imports `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+F32, BF16, F16 = 0, 1, 2
+DTYPE_NAMES = {F32: "f32", BF16: "bf16", F16: "f16"}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgct2.so")
+
+
+class Gct2Error(RuntimeError):
+    """non-zero status from libgct2 (mirrors TensorFlow raising on bad shapes)."""
+
+
+class LossScaleState(C.Structure):
+    _fields_ = [("scale", C.c_float), ("inv_scale", C.c_float), ("good_steps", C.c_int32), ("found_inf", C.c_int32)]
+
+
+_vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+
+# name -> argtypes, exactly the prototypes of include/gct2.h
+SIGNATURES = {
+    "gct2_abi_version": [],
+    "gct2_device_check": [],
+    "gct2_debug_force_direct": [_i],
+    "gct2_conv4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_conv4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_conv4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gct2_convT4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_convT4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_convT4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gct2_dense_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gct2_dense_bwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gct2_rng_uniform_int": [_u64, _u64, _u64, _vp, _sz, _i, _i, _vp],
+    "gct2_rng_normal": [_u64, _u64, _u64, _vp, _sz, _vp],
+    "gct2_noise_image": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gct2_mse_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
+    "gct2_adam_keras_multi": [_vp, _vp, _vp, _vp, _vp, _i, _sz, _f, _f, _f, _f, _vp, _vp, _i, _vp],
+    "gct2_cast_from_f32": [_i, _vp, _vp, _sz, _vp],
+    "gct2_loss_scale_init": [_vp, _f, _vp],
+    "gct2_loss_scale_begin": [_vp, _vp],
+    "gct2_scale_check_finite": [_vp, _sz, _vp, _vp],
+    "gct2_loss_scale_update": [_vp, _i, _vp],
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libgct2.so and attach prototypes; raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Gct2Error(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C gan-class-transfer2_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = None if name == "gct2_debug_force_direct" else _i
+    lib.gct2_last_error.argtypes = []
+    lib.gct2_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().gct2_last_error().decode("utf-8", "replace")
+        raise Gct2Error(f"{what or 'gct2'} failed (status {rc}): {msg}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,206 @@
+// extern "C" boundary (include/gct2.h): argument validation, path selection (MFMA vs direct), launches.
+#include "gct2_common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+// implemented in the kernel translation units
+bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p);
+int tapgemm_mfma(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
+int tapgemm_direct(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
+bool wgrad_mfma_supported(int dtype, const WgradParams& p);
+int wgrad_mfma(int dtype, WgradParams p, hipStream_t s);
+int wgrad_direct(int dtype, const WgradParams& p, hipStream_t s);
+int pw_rng_uniform_int(uint64_t, uint64_t, uint64_t, int32_t*, size_t, int, int, hipStream_t);
+int pw_rng_normal(uint64_t, uint64_t, uint64_t, float*, size_t, hipStream_t);
+int pw_noise(int, const float*, const int32_t*, const float*, void*, int, int, int, int, int, hipStream_t);
+int pw_dense_fwd(int, const void*, int, const float*, const float*, float*, int, int, int, hipStream_t);
+int pw_dense_bwd(int, const void*, int, const float*, const float*, void*, int, float*, float*, int, int, int, int, hipStream_t);
+int pw_mse(const float*, const float*, float*, float*, float*, size_t, const float*, hipStream_t);
+int pw_colsum(int, const void*, int, float*, size_t, int, hipStream_t);
+int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, const float*, const int32_t*, int, hipStream_t);
+int pw_cast(int, const float*, void*, size_t, hipStream_t);
+int pw_ls_init(gct2_loss_scale_state*, float, hipStream_t);
+int pw_ls_begin(gct2_loss_scale_state*, hipStream_t);
+int pw_ls_check(const float*, size_t, gct2_loss_scale_state*, hipStream_t);
+int pw_ls_update(gct2_loss_scale_state*, int, hipStream_t);
+
+static thread_local char g_err[512] = "";
+static int g_force_direct = 0;   // test hook: route every conv through the direct kernels
+
+int gct2_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int gct2_check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return gct2_fail(GCT2_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return GCT2_OK;
+}
+
+namespace {
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool dtype_ok(int d) { return d == GCT2_F32 || d == GCT2_BF16 || d == GCT2_F16; }
+inline size_t esize(int d) { return d == GCT2_F32 ? 4 : 2; }
+
+int check_conv_args(const char* fn, int dtype, const void* a, const void* b, const void* c, int B, int H, int W, int Cin, int Cout) {
+  if (!dtype_ok(dtype)) return gct2_fail(GCT2_EINVAL, "%s: unknown dtype %d", fn, dtype);
+  if (!a || !b || !c) return gct2_fail(GCT2_EINVAL, "%s: null pointer", fn);
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return gct2_fail(GCT2_EINVAL, "%s: non-positive dimension", fn);
+  if ((size_t)B * H * W * 4 >= ((size_t)1 << 31)) return gct2_fail(GCT2_EINVAL, "%s: B*H*W too large for 32-bit pixel indices", fn);
+  return GCT2_OK;
+}
+int run_tapgemm(int dtype, int form, int epi, const TapGemmParams& p, void* stream) {
+  if (!g_force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(dtype, form, epi, p, S(stream));
+  return tapgemm_direct(dtype, form, epi, p, S(stream));
+}
+int run_wgrad(int dtype, const WgradParams& p, void* stream) {
+  if (!g_force_direct && wgrad_mfma_supported(dtype, p)) return wgrad_mfma(dtype, p, S(stream));
+  return wgrad_direct(dtype, p, S(stream));
+}
+}  // namespace
+
+extern "C" {
+
+int gct2_abi_version(void) { return 1; }
+const char* gct2_last_error(void) { return g_err; }
+void gct2_debug_force_direct(int on) { g_force_direct = on; }
+
+int gct2_device_check(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return gct2_fail(GCT2_ENODEV, "no HIP device");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return gct2_fail(GCT2_ENODEV, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return gct2_fail(GCT2_ENODEV, "device is %s, this library is built for gfx950", prop.gcnArchName);
+  return GCT2_OK;
+}
+
+int gct2_conv4s2_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
+                     int Cin, int Cout, int relu, void* stream) {
+  if (int e = check_conv_args("conv4s2_fwd", dtype, x, w, y, B, H, W, Cin, Cout)) return e;
+  if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: H=%d W=%d must be even (skip concat, train.py:114-119)", H, W);
+  if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: ld smaller than channel count");
+  TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H / 2, W / 2, Cin, Cout, relu, 0};
+  return run_tapgemm(dtype, FORM_CONV, EPI_BIAS_ACT, p, stream);
+}
+
+int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
+                       int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+  if (int e = check_conv_args("conv4s2_dgrad", dtype, dz, w, dx, B, H, W, Cin, Cout)) return e;
+  if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: H=%d W=%d must be even", H, W);
+  if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: ld smaller than channel count");
+  TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H / 2, W / 2, Cout, Cin, 0, accumulate};
+  return run_tapgemm(dtype, FORM_CONVT, EPI_MASK, p, stream);
+}
+
+int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
+                       int Cin, int Cout, void* stream) {
+  if (int e = check_conv_args("conv4s2_wgrad", dtype, x, dz, dw, B, H, W, Cin, Cout)) return e;
+  if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: H=%d W=%d must be even", H, W);
+  if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: ld smaller than channel count");
+  WgradParams p{x, ldx, dz, lddz, dw, B, H / 2, W / 2, Cin, Cout, 1};
+  if (int e = run_wgrad(dtype, p, stream)) return e;
+  if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, S(stream));
+  return GCT2_OK;
+}
+
+int gct2_convT4s2_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
+                      int Cin, int Cout, int relu, void* stream) {
+  if (int e = check_conv_args("convT4s2_fwd", dtype, x, w, y, B, 2 * H, 2 * W, Cin, Cout)) return e;
+  if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_fwd: ld smaller than channel count");
+  TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H, W, Cin, Cout, relu, 0};
+  return run_tapgemm(dtype, FORM_CONVT, EPI_BIAS_ACT, p, stream);
+}
+
+int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
+                        int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+  if (int e = check_conv_args("convT4s2_dgrad", dtype, dz, w, dx, B, 2 * H, 2 * W, Cin, Cout)) return e;
+  if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "convT4s2_dgrad: ld smaller than channel count");
+  TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H, W, Cout, Cin, 0, accumulate};
+  return run_tapgemm(dtype, FORM_CONV, EPI_MASK, p, stream);
+}
+
+int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
+                        int Cin, int Cout, void* stream) {
+  if (int e = check_conv_args("convT4s2_wgrad", dtype, x, dz, dw, B, 2 * H, 2 * W, Cin, Cout)) return e;
+  if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: ld smaller than channel count");
+  WgradParams p{dz, lddz, x, ldx, dw, B, H, W, Cout, Cin, 1};
+  if (int e = run_wgrad(dtype, p, stream)) return e;
+  if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, S(stream));
+  return GCT2_OK;
+}
+
+int gct2_dense_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* y, int M, int Cin, int Cout, void* stream) {
+  if (!dtype_ok(dtype) || !x || !w || !y) return gct2_fail(GCT2_EINVAL, "dense_fwd: bad dtype or null pointer");
+  if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout > 4 || ldx < Cin) return gct2_fail(GCT2_EINVAL, "dense_fwd: bad shape (Cout must be 1..4)");
+  return pw_dense_fwd(dtype, x, ldx, w, b, y, M, Cin, Cout, S(stream));
+}
+
+int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float* dy, void* dx, int lddx, float* dw, float* db, int M,
+                   int Cin, int Cout, int Cmask, void* stream) {
+  if (!dtype_ok(dtype) || !x || !w || !dy || !dx || !dw) return gct2_fail(GCT2_EINVAL, "dense_bwd: bad dtype or null pointer");
+  if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout > 4 || ldx < Cin || Cmask < 0 || Cmask > Cin || lddx < Cmask)
+    return gct2_fail(GCT2_EINVAL, "dense_bwd: bad shape");
+  if ((Cin + 1) * Cout > 256) return gct2_fail(GCT2_EINVAL, "dense_bwd: (Cin+1)*Cout = %d exceeds 256", (Cin + 1) * Cout);
+  if ((size_t)Cin * 16 + 128 * 16 + (size_t)128 * Cin * esize(dtype) > 160 * 1024)
+    return gct2_fail(GCT2_EINVAL, "dense_bwd: Cin=%d too large for the LDS tile", Cin);
+  return pw_dense_bwd(dtype, x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, S(stream));
+}
+
+int gct2_rng_uniform_int(uint64_t seed, uint64_t stream_id, uint64_t offset, int32_t* out, size_t n, int lo, int hi, void* stream) {
+  if (!out || hi < lo) return gct2_fail(GCT2_EINVAL, "rng_uniform_int: null output or empty range");
+  return pw_rng_uniform_int(seed, stream_id, offset, out, n, lo, hi, S(stream));
+}
+int gct2_rng_normal(uint64_t seed, uint64_t stream_id, uint64_t offset, float* out, size_t n, void* stream) {
+  if (!out) return gct2_fail(GCT2_EINVAL, "rng_normal: null output");
+  return pw_rng_normal(seed, stream_id, offset, out, n, S(stream));
+}
+
+int gct2_noise_image(int dtype, const float* x, const int32_t* t_int, const float* eps, void* out, int ldout, int B, int HW, int C,
+                     int steps, void* stream) {
+  if (!dtype_ok(dtype) || !x || !t_int || !eps || !out) return gct2_fail(GCT2_EINVAL, "noise_image: bad dtype or null pointer");
+  if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || steps <= 0) return gct2_fail(GCT2_EINVAL, "noise_image: bad shape");
+  return pw_noise(dtype, x, t_int, eps, out, ldout, B, HW, C, steps, S(stream));
+}
+
+int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n,
+                     const float* loss_scale_ptr, void* stream) {
+  if (!pred || !target || !dpred || !loss || !partials || n == 0) return gct2_fail(GCT2_EINVAL, "mse_fwd_bwd: null pointer or n == 0");
+  return pw_mse(pred, target, dpred, loss, partials, n, loss_scale_ptr, S(stream));
+}
+
+int gct2_adam_keras_multi(float* p, float* m, float* v, float* g, void* shadow, int shadow_dtype, size_t n, float alpha, float beta1,
+                          float beta2, float eps, const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad, void* stream) {
+  if (!p || !m || !v || !g) return gct2_fail(GCT2_EINVAL, "adam_keras_multi: null pointer");
+  if (shadow && !dtype_ok(shadow_dtype)) return gct2_fail(GCT2_EINVAL, "adam_keras_multi: bad shadow dtype");
+  if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) % 16 || (shadow && (uintptr_t)shadow % 8))
+    return gct2_fail(GCT2_EINVAL, "adam_keras_multi: arenas must be 16-byte aligned");
+  return pw_adam(p, m, v, g, shadow, shadow_dtype, n, alpha, beta1, beta2, eps, inv_scale_ptr, found_inf, zero_grad, S(stream));
+}
+
+int gct2_cast_from_f32(int dtype, const float* src, void* dst, size_t n, void* stream) {
+  if (!dtype_ok(dtype) || !src || !dst) return gct2_fail(GCT2_EINVAL, "cast_from_f32: bad dtype or null pointer");
+  return pw_cast(dtype, src, dst, n, S(stream));
+}
+
+int gct2_loss_scale_init(gct2_loss_scale_state* st, float initial_scale, void* stream) {
+  if (!st || !(initial_scale > 0.f)) return gct2_fail(GCT2_EINVAL, "loss_scale_init: null state or non-positive scale");
+  return pw_ls_init(st, initial_scale, S(stream));
+}
+int gct2_loss_scale_begin(gct2_loss_scale_state* st, void* stream) {
+  if (!st) return gct2_fail(GCT2_EINVAL, "loss_scale_begin: null state");
+  return pw_ls_begin(st, S(stream));
+}
+int gct2_scale_check_finite(const float* g, size_t n, gct2_loss_scale_state* st, void* stream) {
+  if (!g || !st) return gct2_fail(GCT2_EINVAL, "scale_check_finite: null pointer");
+  return pw_ls_check(g, n, st, S(stream));
+}
+int gct2_loss_scale_update(gct2_loss_scale_state* st, int growth_interval, void* stream) {
+  if (!st || growth_interval <= 0) return gct2_fail(GCT2_EINVAL, "loss_scale_update: null state or bad interval");
+  return pw_ls_update(st, growth_interval, S(stream));
+}
+
+}  // extern "C"

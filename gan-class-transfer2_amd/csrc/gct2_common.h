@@ -1,0 +1,117 @@
+// Shared device-side helpers for the gfx950 kernels (wave = 64, MFMA 16x16x32, LDS tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gct2.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// host-side error plumbing (capi.hip)
+int gct2_fail(int code, const char* fmt, ...);
+int gct2_check_launch(const char* what);
+
+template <typename T> struct is16 { static constexpr bool value = sizeof(T) == 2; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// D(16x16,f32) += A(16x32) * B(32x16); operands as raw 128-bit fragments (8 x 16-bit).
+// lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15], D[row 4*(l>>4)+r][col l&15]
+// (verified on hardware by tests/hw_probe/probe_mfma_tr.hip).
+template <typename T> __device__ __forceinline__ f32x4_t mfma16(u32x4_t a, u32x4_t b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t mfma16<__bf16>(u32x4_t a, u32x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mfma16<_Float16>(u32x4_t a, u32x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// ---- LDS tile images -----------------------------------------------------------------------------
+// "N image": [rows][64 x 16-bit] = 128-byte rows, 16-byte chunk c of row r stored at chunk
+//  c ^ ((r>>1)&7): ds_read_b128 of (row = base+(lane&15), chunk = 4*kk+(lane>>4)) is conflict-free.
+__device__ __forceinline__ int nimg_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+// "T image": [64 k-rows][128 x 16-bit] = 256-byte rows (reduction index is the ROW); the 32-byte chunk
+//  q of row k is stored at q ^ f(k), f(k) = (k&3) | ((k>>3)&1)<<2, so a ds_read_tr16_b64 (4 rows x 16
+//  columns per 16-lane group) touches 64 distinct banks per 32-lane half.
+__device__ __forceinline__ int timg_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ int timg_off(int k, int chunk16) {
+  return k * 256 + ((((chunk16 >> 1) ^ timg_swz(k))) << 5) + ((chunk16 & 1) << 4);
+}
+
+__device__ __forceinline__ u32x4_t lds_read128(const char* lds, int off) {
+  return *reinterpret_cast<const u32x4_t*>(lds + off);
+}
+__device__ __forceinline__ void lds_write128(char* lds, int off, u32x4_t v) {
+  *reinterpret_cast<u32x4_t*>(lds + off) = v;
+}
+// fragment (8 consecutive reduction elements for this lane's row/col) out of an N image
+__device__ __forceinline__ u32x4_t nimg_frag(const char* img, int rowbase, int kk, int lane) {
+  return lds_read128(img, nimg_off(rowbase + (lane & 15), 4 * kk + (lane >> 4)));
+}
+// same fragment out of a T image (column block `colbase`, multiple of 16) via two transposed reads
+__device__ __forceinline__ u32x4_t timg_frag(const char* img, int colbase, int kk, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int k0 = kk * 32 + 8 * g + q;
+  const int c32 = colbase >> 4;
+  const int o0 = k0 * 256 + ((c32 ^ timg_swz(k0)) << 5) + p * 8;
+  const int o1 = (k0 + 4) * 256 + ((c32 ^ timg_swz(k0 + 4)) << 5) + p * 8;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + o0));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + o1));
+  u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+  u32x4_t r = {l2[0], l2[1], h2[0], h2[1]};
+  return r;
+}
+
+__device__ __forceinline__ u32x4_t gload128(const void* p) {
+  return *reinterpret_cast<const u32x4_t*>(p);
+}
+
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  T x = from_f32<T>(a), y = from_f32<T>(b);
+  return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+template <typename T> __device__ __forceinline__ float unpack_lo(uint32_t u) {
+  return to_f32<T>(__builtin_bit_cast(T, (uint16_t)(u & 0xffffu)));
+}
+template <typename T> __device__ __forceinline__ float unpack_hi(uint32_t u) {
+  return to_f32<T>(__builtin_bit_cast(T, (uint16_t)(u >> 16)));
+}
+
+// ---- geometry of the two 4x4/stride-2 "tap GEMMs" ------------------------------------------------
+// FORM_CONV : out on the SMALL grid (Hs x Ws), source on the BIG grid (2Hs x 2Ws), 16 taps,
+//             weights [tap][k][n]   (Conv2D forward, Conv2DTranspose input-gradient)
+// FORM_CONVT: out on the BIG grid, one launch-z per output parity phase, source on the SMALL grid,
+//             4 taps per phase, weights [tap][n][k]   (Conv2DTranspose forward, Conv2D input-gradient)
+enum { FORM_CONV = 0, FORM_CONVT = 1 };
+enum { EPI_BIAS_ACT = 0, EPI_MASK = 1 };
+
+struct TapGemmParams {
+  const void* x; int ldx;        // source activations / gradients
+  const void* w;                 // weights, Keras layout
+  const float* bias;             // EPI_BIAS_ACT
+  const void* act; int ldact;    // EPI_MASK: mask source on the output grid (may be null)
+  void* y; int ldy;              // output view
+  int B, Hs, Ws;                 // SMALL grid
+  int K, N;                      // reduction channels per tap, output channels
+  int relu, accumulate;
+};
+
+// wgrad: dw[tap][cb][cs] += sum_r big[pix_big(r,tap)][cb] * small[r][cs], r over the SMALL grid.
+struct WgradParams {
+  const void* big; int ldbig;     // tensor on the BIG grid (2Hs x 2Ws), Cb channels
+  const void* small; int ldsmall; // tensor on the SMALL grid, Cs channels
+  float* dw;                      // fp32 [16][Cb][Cs]
+  int B, Hs, Ws, Cb, Cs;
+  int rsplit;                     // number of r-range splits (gridDim.z)
+};

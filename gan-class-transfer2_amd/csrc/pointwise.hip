@@ -1,0 +1,390 @@
+// HBM-bound kernels of the train step: RNG + noising (train.py:224-234), Dense(3) head (train.py:198-202),
+// fp32 MSE and its gradient (train.py:262-272), bias gradients, Keras Adam (train.py:75) and the
+// mixed-precision loss-scale state machine (train.py:82-83).  All are streaming kernels: 16-byte accesses
+// where the layout allows, grids capped at a few workgroups per CU with grid-stride loops.
+#include "gct2_common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;   // 256 CUs x 8
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter = (idx, stream), key = seed -------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+  const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+  c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+__device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t stream_id, uint64_t idx, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = c[i];
+}
+
+__global__ void rng_uniform_int_kernel(uint64_t seed, uint64_t stream_id, uint64_t offset, int32_t* out, size_t n,
+                                       int lo, uint32_t range) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t e = offset + i;
+  uint32_t r[4];
+  philox4x32_10(seed, stream_id, e >> 2, r);
+  out[i] = lo + (int32_t)__umulhi(r[e & 3], range);
+}
+
+// element e uses counter e>>2; lanes (0,1) of the counter feed elements 4c,4c+1, lanes (2,3) feed 4c+2,4c+3
+__global__ void rng_normal_kernel(uint64_t seed, uint64_t stream_id, uint64_t offset, float* out, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t e = offset + i;
+    uint32_t r[4];
+    philox4x32_10(seed, stream_id, e >> 2, r);
+    const int pair = (int)((e >> 1) & 1);
+    const float u1 = ((float)(r[2 * pair] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(r[2 * pair + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    const float ang = 6.283185307179586f * u2;
+    out[i] = (e & 1) ? rad * sinf(ang) : rad * cosf(ang);
+  }
+}
+
+template <typename T>
+__global__ void noise_kernel(const float* __restrict__ x, const int32_t* __restrict__ t_int, const float* __restrict__ eps,
+                             T* __restrict__ out, int ldout, size_t npix, int HW, int C, float inv_steps1) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t total = npix * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    const int b = (int)(pix / HW);
+    const float t = (float)t_int[b] * inv_steps1;              // t /= (steps + 1)      train.py:87
+    const float a = (1.f - t) * (1.f - t) * 0.25f;             // alpha_dash            train.py:93
+    const float v = x[i] * sqrtf(a) + eps[i] * sqrtf(1.f - a); // train.py:231-234
+    out[pix * ldout + c] = from_f32<T>(v);
+  }
+}
+
+// ---- Dense(3) head -------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dense_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
+                                 float* __restrict__ y, int M, int Cin, int Cout) {
+  extern __shared__ float wsm[];                  // [Cin][4]
+  for (int i = threadIdx.x; i < Cin * 4; i += blockDim.x) {
+    const int o = i & 3, k = i >> 2;
+    wsm[i] = (o < Cout) ? w[k * Cout + o] : 0.f;
+  }
+  __syncthreads();
+  const int stride = gridDim.x * blockDim.x;
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
+    const T* xr = x + (size_t)m * ldx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = 0; k < Cin; k++) {
+      const float v = to_f32(xr[k]);
+      a0 = fmaf(v, wsm[4 * k + 0], a0); a1 = fmaf(v, wsm[4 * k + 1], a1);
+      a2 = fmaf(v, wsm[4 * k + 2], a2); a3 = fmaf(v, wsm[4 * k + 3], a3);
+    }
+    const float acc[4] = {a0, a1, a2, a3};
+    for (int o = 0; o < Cout; o++) y[(size_t)m * Cout + o] = acc[o] + (b ? b[o] : 0.f);
+  }
+}
+
+// one workgroup walks tiles of PIX pixels: dx per pixel, and per-(i,o) partial sums of dw/db over the tile
+template <typename T, int PIX>
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ dy, T* __restrict__ dx, int lddx,
+                                                        float* __restrict__ dw, float* __restrict__ db, int M, int Cin,
+                                                        int Cout, int Cmask) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* wsm = reinterpret_cast<float*>(smem_raw);          // [Cin][4]
+  float* dys = wsm + Cin * 4;                               // [PIX][4]
+  T* xs = reinterpret_cast<T*>(dys + PIX * 4);              // [PIX][Cin]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Cin * 4; i += 256) {
+    const int o = i & 3, k = i >> 2;
+    wsm[i] = (o < Cout) ? w[k * Cout + o] : 0.f;
+  }
+  const int nout = (Cin + 1) * Cout;                        // dw entries + db entries owned by threads
+  const int my_i = tid / Cout, my_o = tid - my_i * Cout;    // valid when tid < nout
+  float wacc = 0.f;
+  const int ntiles = (M + PIX - 1) / PIX;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int mbase = tile * PIX;
+    __syncthreads();
+    for (int i = tid; i < PIX * Cin; i += 256) {
+      const int pm = i / Cin, k = i - pm * Cin;
+      xs[i] = (mbase + pm < M) ? x[(size_t)(mbase + pm) * ldx + k] : from_f32<T>(0.f);
+    }
+    for (int i = tid; i < PIX * 4; i += 256) {
+      const int pm = i >> 2, o = i & 3;
+      dys[i] = (o < Cout && mbase + pm < M) ? dy[(size_t)(mbase + pm) * Cout + o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < PIX * Cmask; i += 256) {
+      const int pm = i / Cmask, k = i - pm * Cmask;
+      if (mbase + pm >= M) continue;
+      float g = dys[4 * pm] * wsm[4 * k] + dys[4 * pm + 1] * wsm[4 * k + 1] + dys[4 * pm + 2] * wsm[4 * k + 2] +
+                dys[4 * pm + 3] * wsm[4 * k + 3];
+      if (!(to_f32(xs[pm * Cin + k]) > 0.f)) g = 0.f;
+      dx[(size_t)(mbase + pm) * lddx + k] = from_f32<T>(g);
+    }
+    if (tid < nout) {
+      if (my_i < Cin) {
+        for (int pm = 0; pm < PIX; pm++) wacc = fmaf(to_f32(xs[pm * Cin + my_i]), dys[4 * pm + my_o], wacc);
+      } else {
+        for (int pm = 0; pm < PIX; pm++) wacc += dys[4 * pm + my_o];
+      }
+    }
+  }
+  if (tid < nout) {
+    if (my_i < Cin) atomicAdd(dw + my_i * Cout + my_o, wacc);
+    else if (db) atomicAdd(db + my_o, wacc);
+  }
+}
+
+// ---- MSE -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                  float* __restrict__ dpred, float* __restrict__ partials, size_t n,
+                                                  const float* __restrict__ loss_scale_ptr) {
+  const float scale = (loss_scale_ptr ? *loss_scale_ptr : 1.f) * 2.0f / (float)n;
+  float acc = 0.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = pred[i] - target[i];
+    acc = fmaf(d, d, acc);
+    dpred[i] = d * scale;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(256) void mse_finish_kernel(const float* __restrict__ partials, int nparts, float* loss, float inv_n) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)partials[i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = (float)((ws[0] + ws[1] + ws[2] + ws[3]) * (double)inv_n);
+}
+
+// ---- bias gradient: db[c] += sum_m dz[m][c] --------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dz, int ld, float* __restrict__ db, size_t M, int C,
+                                                     int rows_per_block) {
+  // thread = (channel within a 64-wide tile, one of 4 row lanes)
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const size_t r0 = (size_t)blockIdx.y * rows_per_block;
+  const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float acc = 0.f;
+  if (c < C)
+    for (size_t r = r0 + rl; r < r1; r += 4) acc += to_f32(dz[r * ld + c]);
+  __shared__ float ws[256];
+  ws[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(db + c, ws[threadIdx.x] + ws[threadIdx.x + 64] + ws[threadIdx.x + 128] + ws[threadIdx.x + 192]);
+}
+// ---- Keras Adam over a flat arena ------------------------------------------------------------------------
+template <typename S, bool HAS_SHADOW>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ g, S* __restrict__ shadow, size_t n, float alpha,
+                                                   float b1, float b2, float eps, const float* __restrict__ inv_scale_ptr,
+                                                   const int32_t* __restrict__ found_inf, int zero_grad) {
+  const bool skip = found_inf && *found_inf != 0;
+  const float inv_scale = inv_scale_ptr ? *inv_scale_ptr : 1.f;
+  const size_t n4 = n >> 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float ob1 = 1.f - b1, ob2 = 1.f - b2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4_t gv = reinterpret_cast<f32x4_t*>(g)[i];
+    if (zero_grad) reinterpret_cast<f32x4_t*>(g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (skip) continue;
+    f32x4_t pv = reinterpret_cast<f32x4_t*>(p)[i], mv = reinterpret_cast<f32x4_t*>(m)[i], vv = reinterpret_cast<f32x4_t*>(v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float gg = gv[k] * inv_scale;
+      mv[k] = b1 * mv[k] + ob1 * gg;
+      vv[k] = b2 * vv[k] + ob2 * gg * gg;
+      pv[k] = pv[k] - alpha * mv[k] / (sqrtf(vv[k]) + eps);
+    }
+    reinterpret_cast<f32x4_t*>(p)[i] = pv; reinterpret_cast<f32x4_t*>(m)[i] = mv; reinterpret_cast<f32x4_t*>(v)[i] = vv;
+    if (HAS_SHADOW) {
+      if constexpr (sizeof(S) == 2) {
+        u32x2_t o = {pack2<S>(pv[0], pv[1]), pack2<S>(pv[2], pv[3])};
+        reinterpret_cast<u32x2_t*>(shadow)[i] = o;
+      } else {
+        reinterpret_cast<f32x4_t*>(shadow)[i] = pv;
+      }
+    }
+  }
+  // tail (n % 4 elements)
+  const size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float gg = g[i] * inv_scale;
+    if (zero_grad) g[i] = 0.f;
+    if (!skip) {
+      const float mm = b1 * m[i] + ob1 * gg, vv = b2 * v[i] + ob2 * gg * gg;
+      const float pp = p[i] - alpha * mm / (sqrtf(vv) + eps);
+      m[i] = mm; v[i] = vv; p[i] = pp;
+      if (HAS_SHADOW) shadow[i] = from_f32<S>(pp);
+    }
+  }
+}
+
+template <typename S>
+__global__ void cast_kernel(const float* __restrict__ src, S* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = from_f32<S>(src[i]);
+}
+
+// ---- loss scale ------------------------------------------------------------------------------------------
+__global__ void ls_init_kernel(gct2_loss_scale_state* s, float scale) {
+  s->scale = scale; s->inv_scale = 1.f / scale; s->good_steps = 0; s->found_inf = 0;
+}
+__global__ void ls_begin_kernel(gct2_loss_scale_state* s) { s->found_inf = 0; }
+__global__ void ls_check_kernel(const float* __restrict__ g, size_t n, gct2_loss_scale_state* s) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = g[i];
+    bad |= !(fabsf(x) <= 3.402823466e38f);      // false for inf and nan
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&s->found_inf, 1);
+}
+__global__ void ls_update_kernel(gct2_loss_scale_state* s, int growth_interval) {
+  if (s->found_inf) {
+    s->scale = fmaxf(s->scale * 0.5f, 1.f); s->good_steps = 0;
+  } else {
+    s->good_steps += 1;
+    if (s->good_steps >= growth_interval) { s->scale *= 2.f; s->good_steps = 0; }
+  }
+  s->inv_scale = 1.f / s->scale;
+}
+
+inline int blocks_for(size_t n, int per_block) {
+  size_t b = (n + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > (size_t)kMaxBlocks ? kMaxBlocks : b));
+}
+
+}  // namespace
+
+// ---- host launchers (called from capi.hip) ------------------------------------------------------------------
+int pw_rng_uniform_int(uint64_t seed, uint64_t stream_id, uint64_t offset, int32_t* out, size_t n, int lo, int hi, hipStream_t s) {
+  if (n == 0) return GCT2_OK;
+  hipLaunchKernelGGL(rng_uniform_int_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed, stream_id, offset, out, n, lo,
+                     (uint32_t)(hi - lo + 1));
+  return gct2_check_launch("rng_uniform_int");
+}
+int pw_rng_normal(uint64_t seed, uint64_t stream_id, uint64_t offset, float* out, size_t n, hipStream_t s) {
+  if (n == 0) return GCT2_OK;
+  hipLaunchKernelGGL(rng_normal_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, seed, stream_id, offset, out, n);
+  return gct2_check_launch("rng_normal");
+}
+template <typename T>
+static int noise_t(const float* x, const int32_t* t, const float* eps, void* out, int ldout, int B, int HW, int C, int steps, hipStream_t s) {
+  const size_t npix = (size_t)B * HW;
+  hipLaunchKernelGGL(noise_kernel<T>, dim3(blocks_for(npix * C, 256)), dim3(256), 0, s, x, t, eps, reinterpret_cast<T*>(out), ldout, npix,
+                     HW, C, 1.0f / (float)(steps + 1));
+  return gct2_check_launch("noise_image");
+}
+int pw_noise(int dtype, const float* x, const int32_t* t, const float* eps, void* out, int ldout, int B, int HW, int C, int steps, hipStream_t s) {
+  if (dtype == GCT2_F32) return noise_t<float>(x, t, eps, out, ldout, B, HW, C, steps, s);
+  if (dtype == GCT2_BF16) return noise_t<__bf16>(x, t, eps, out, ldout, B, HW, C, steps, s);
+  return noise_t<_Float16>(x, t, eps, out, ldout, B, HW, C, steps, s);
+}
+template <typename T>
+static int dense_fwd_t(const void* x, int ldx, const float* w, const float* b, float* y, int M, int Cin, int Cout, hipStream_t s) {
+  hipLaunchKernelGGL(dense_fwd_kernel<T>, dim3(blocks_for(M, 256)), dim3(256), Cin * 4 * sizeof(float), s, reinterpret_cast<const T*>(x), ldx,
+                     w, b, y, M, Cin, Cout);
+  return gct2_check_launch("dense_fwd");
+}
+int pw_dense_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* y, int M, int Cin, int Cout, hipStream_t s) {
+  if (dtype == GCT2_F32) return dense_fwd_t<float>(x, ldx, w, b, y, M, Cin, Cout, s);
+  if (dtype == GCT2_BF16) return dense_fwd_t<__bf16>(x, ldx, w, b, y, M, Cin, Cout, s);
+  return dense_fwd_t<_Float16>(x, ldx, w, b, y, M, Cin, Cout, s);
+}
+template <typename T>
+static int dense_bwd_t(const void* x, int ldx, const float* w, const float* dy, void* dx, int lddx, float* dw, float* db, int M, int Cin,
+                       int Cout, int Cmask, hipStream_t s) {
+  constexpr int PIX = 128;
+  const size_t lds = (size_t)Cin * 16 + PIX * 16 + (size_t)PIX * Cin * sizeof(T);
+  const int ntiles = (M + PIX - 1) / PIX;
+  const int grid = ntiles < 1024 ? ntiles : 1024;
+  auto kern = dense_bwd_kernel<T, PIX>;
+  if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, reinterpret_cast<const T*>(x), ldx, w, dy, reinterpret_cast<T*>(dx), lddx, dw, db,
+                     M, Cin, Cout, Cmask);
+  return gct2_check_launch("dense_bwd");
+}
+int pw_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float* dy, void* dx, int lddx, float* dw, float* db, int M,
+                 int Cin, int Cout, int Cmask, hipStream_t s) {
+  if (dtype == GCT2_F32) return dense_bwd_t<float>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, s);
+  if (dtype == GCT2_BF16) return dense_bwd_t<__bf16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, s);
+  return dense_bwd_t<_Float16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, s);
+}
+int pw_mse(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n, const float* ls, hipStream_t s) {
+  const int nb = blocks_for(n, 1024) > 1024 ? 1024 : blocks_for(n, 1024);
+  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, s, pred, target, dpred, partials, n, ls);
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, s, partials, nb, loss, 1.0f / (float)n);
+  return gct2_check_launch("mse_fwd_bwd");
+}
+template <typename T>
+static int colsum_t(const void* dz, int ld, float* db, size_t M, int C, hipStream_t s) {
+  const int ctiles = (C + 63) / 64;
+  int rblocks = (int)((M + 511) / 512);
+  const int cap = (1024 + ctiles - 1) / ctiles;
+  if (rblocks > cap) rblocks = cap;
+  if (rblocks < 1) rblocks = 1;
+  const int rows_per_block = (int)((M + rblocks - 1) / rblocks);
+  hipLaunchKernelGGL(colsum_kernel<T>, dim3(ctiles, rblocks), dim3(256), 0, s, reinterpret_cast<const T*>(dz), ld, db, M, C, rows_per_block);
+  return gct2_check_launch("colsum");
+}
+int pw_colsum(int dtype, const void* dz, int ld, float* db, size_t M, int C, hipStream_t s) {
+  if (dtype == GCT2_F32) return colsum_t<float>(dz, ld, db, M, C, s);
+  if (dtype == GCT2_BF16) return colsum_t<__bf16>(dz, ld, db, M, C, s);
+  return colsum_t<_Float16>(dz, ld, db, M, C, s);
+}
+int pw_adam(float* p, float* m, float* v, float* g, void* shadow, int sdt, size_t n, float alpha, float b1, float b2, float eps,
+            const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad, hipStream_t s) {
+  if (n == 0) return GCT2_OK;
+  const int nb = blocks_for(n / 4 + 4, 256);
+#define GCT2_ADAM(S, HS) hipLaunchKernelGGL((adam_kernel<S, HS>), dim3(nb), dim3(256), 0, s, p, m, v, g, reinterpret_cast<S*>(shadow), n, alpha, b1, b2, eps, inv_scale_ptr, found_inf, zero_grad)
+  if (!shadow) GCT2_ADAM(float, false);
+  else if (sdt == GCT2_BF16) GCT2_ADAM(__bf16, true);
+  else if (sdt == GCT2_F16) GCT2_ADAM(_Float16, true);
+  else GCT2_ADAM(float, true);
+#undef GCT2_ADAM
+  return gct2_check_launch("adam_keras_multi");
+}
+int pw_cast(int dtype, const float* src, void* dst, size_t n, hipStream_t s) {
+  if (n == 0) return GCT2_OK;
+  const int nb = blocks_for(n, 256);
+  if (dtype == GCT2_BF16) hipLaunchKernelGGL(cast_kernel<__bf16>, dim3(nb), dim3(256), 0, s, src, reinterpret_cast<__bf16*>(dst), n);
+  else if (dtype == GCT2_F16) hipLaunchKernelGGL(cast_kernel<_Float16>, dim3(nb), dim3(256), 0, s, src, reinterpret_cast<_Float16*>(dst), n);
+  else hipLaunchKernelGGL(cast_kernel<float>, dim3(nb), dim3(256), 0, s, src, reinterpret_cast<float*>(dst), n);
+  return gct2_check_launch("cast_from_f32");
+}
+int pw_ls_init(gct2_loss_scale_state* st, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(ls_init_kernel, dim3(1), dim3(1), 0, s, st, scale);
+  return gct2_check_launch("loss_scale_init");
+}
+int pw_ls_begin(gct2_loss_scale_state* st, hipStream_t s) {
+  hipLaunchKernelGGL(ls_begin_kernel, dim3(1), dim3(1), 0, s, st);
+  return gct2_check_launch("loss_scale_begin");
+}
+int pw_ls_check(const float* g, size_t n, gct2_loss_scale_state* st, hipStream_t s) {
+  if (n == 0) return GCT2_OK;
+  hipLaunchKernelGGL(ls_check_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, s, g, n, st);
+  return gct2_check_launch("scale_check_finite");
+}
+int pw_ls_update(gct2_loss_scale_state* st, int growth_interval, hipStream_t s) {
+  hipLaunchKernelGGL(ls_update_kernel, dim3(1), dim3(1), 0, s, st, growth_interval);
+  return gct2_check_launch("loss_scale_update");
+}

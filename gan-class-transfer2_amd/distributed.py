@@ -1,0 +1,102 @@
+"""Data-parallel replicas: one process per GPU, gradients summed with RCCL all-reduce over xGMI.
+
+The reference is single-GPU (train.py:40) - this is the build-side addition of SURVEY.md §8(e).  The path shards by
+batch only: every rank holds a full replica and `bs/rank` images; the ONE exchange step is the all-reduce of the
+gradient arena, issued bucket by bucket in backward-completion order on a side stream while the rest of the
+backward pass is still running; the 1/world_size of the mean is folded into Adam's gradient read
+(gct2_adam_keras_multi's inv_scale), so replicas stay bit-identical.
+
+The reducer only needs a flat gradient tensor and the contiguous [lo, hi) range of every layer, so it runs
+unchanged on CPU tensors with the gloo backend (tests/test_distributed_cpu.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class BucketedAllReducer:
+    """sums `flat[lo:hi]` across ranks, one collective per bucket of consecutive layers.
+
+    layer_order / layer_ranges: layers in the order their gradients complete during backward, each a
+    contiguous range of `flat` (ParamArena orders the arena that way).  xGMI is point-to-point, so few large
+    collectives beat many small ones: layers are merged until a bucket holds >= bucket_elems elements."""
+
+    def __init__(self, flat: torch.Tensor, layer_order: Sequence[str], layer_ranges: Dict[str, Tuple[int, int]],
+                 bucket_elems: int = 4 << 20, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets: List[Tuple[int, int]] = []
+        self.flush_after: Dict[str, int] = {}          # layer name -> bucket index closed by that layer
+        lo = None
+        for k, name in enumerate(layer_order):
+            l, h = layer_ranges[name]
+            lo = l if lo is None else lo
+            if h - lo >= bucket_elems or k == len(layer_order) - 1:
+                self.flush_after[name] = len(self.buckets)
+                self.buckets.append((lo, h))
+                lo = None
+        self.on_cuda = flat.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if self.on_cuda else None
+        self.works: List[Optional[object]] = [None] * len(self.buckets)
+        self.launched = 0
+
+    def begin(self) -> None:
+        self.works = [None] * len(self.buckets)
+        self.launched = 0
+
+    def grad_ready(self, layer: str) -> None:
+        """call when every kernel writing `layer`'s gradients has been enqueued on the current stream."""
+        if self.world == 1 or layer not in self.flush_after:
+            return
+        idx = self.flush_after[layer]
+        lo, hi = self.buckets[idx]
+        view = self.flat[lo:hi]
+        if self.on_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self.works[idx] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.works[idx] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.launched += 1
+
+    def wait_bucket(self, idx: int) -> Tuple[int, int]:
+        """block the CURRENT stream (not the host, on a GPU) until bucket idx holds the global sum."""
+        w = self.works[idx]
+        if w is not None:
+            w.wait()
+            if self.on_cuda:
+                torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
+        return self.buckets[idx]
+
+
+class DataParallelStep:
+    """drives UNetEngine.train_step on every rank with overlapped gradient all-reduce."""
+
+    def __init__(self, engine, bucket_elems: int = 4 << 20, group=None):
+        self.engine = engine
+        A = engine.arena
+        self.reducer = BucketedAllReducer(A.g, engine.topo.layer_order(), A.layer_ranges, bucket_elems, group)
+        engine.grad_ready_hook = self.reducer.grad_ready
+        self.world = self.reducer.world
+        if self.world > 1 and engine.ls_state is not None:
+            raise NotImplementedError("dynamic loss scaling across ranks needs a found_inf all-reduce (not built yet)")
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        if self.world > 1:
+            dist.broadcast(self.engine.arena.p, src)
+            self.engine.arena.refresh_shadow(self.engine._stream())
+
+    def train_step(self, x, t_int=None, eps=None):
+        eng, red = self.engine, self.reducer
+        red.begin()
+        loss = eng.train_step(x, t_int, eps, apply=False)      # backward fires grad_ready per layer
+        for idx in range(len(red.buckets)):
+            lo, hi = red.wait_bucket(idx)
+            eng.apply_adam(lo, hi, grad_div=float(self.world))  # mean over ranks folded into the gradient read
+        eng.finish_step()
+        return loss

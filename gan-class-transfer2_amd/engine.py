@@ -1,0 +1,405 @@
+"""Execution plan of one `Trainer` train step (train.py:223-272 + Keras fit/Adam, train.py:511-517)
+over the C ABI of include/gct2.h.
+
+HBM layout (all NHWC, `ld` = pixel stride in elements):
+  R_i   [B, H/2^i, W/2^i, ld_i]   the output of Residual_i = concat([U_i(..), x_i], -1) (train.py:113-119):
+        channels [0, Fu_i) are written by UpShuffle_i, channels [Fu_i, Fu_i+C_i) by the producer of x_i
+        (DownShuffle_{i-1}, or the noising kernel for i = 0)  ->  the concat is never materialised.
+  dR_i  same shape: gradient w.r.t. the PRE-activation of every channel of R_i (ReLU masks are applied by
+        the kernel that writes the gradient), so consumers (wgrad, dgrad) read it unmasked.
+  parameters: one fp32 arena (p, m, v, g) + a compute-dtype shadow arena, tensors ordered by backward
+        completion (dense, U_0..U_{n-1}, D_{n-1}..D_0) so gradient buckets are contiguous ranges.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BF16, F16, F32, call
+
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+@dataclass
+class Topology:
+    """channel rule of Denoiser.__init__ (train.py:179-190)."""
+    pixel_size: int = 128
+    max_size: int = 512
+    octaves: int = 6
+
+    def fd(self, i: int) -> int:
+        return min(self.pixel_size * 2 ** i, self.max_size)
+
+    def fu(self, i: int) -> int:
+        return min(self.pixel_size * 2 ** i // 2, self.max_size)
+
+    def cx(self, i: int) -> int:
+        return 3 if i == 0 else self.fd(i - 1)
+
+    def up_in(self, i: int) -> int:
+        return self.fd(i) if i == self.octaves - 1 else self.fu(i + 1) + self.fd(i)
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        s: Dict[str, Tuple[int, ...]] = {}
+        for i in range(self.octaves):
+            s[f"D{i}.w"] = (4, 4, self.cx(i), self.fd(i))
+            s[f"D{i}.b"] = (self.fd(i),)
+            s[f"U{i}.w"] = (4, 4, self.fu(i), self.up_in(i))
+            s[f"U{i}.b"] = (self.fu(i),)
+        s["dense.w"] = (self.fu(0) + 3, 3)
+        s["dense.b"] = (3,)
+        return s
+
+    def backward_order(self) -> List[str]:
+        names = ["dense.w", "dense.b"]
+        for i in range(self.octaves):
+            names += [f"U{i}.w", f"U{i}.b"]
+        for i in reversed(range(self.octaves)):
+            names += [f"D{i}.w", f"D{i}.b"]
+        return names
+
+    def layer_order(self) -> List[str]:
+        """layers in backward completion order; one gradient bucket per layer."""
+        return ["dense"] + [f"U{i}" for i in range(self.octaves)] + [f"D{i}" for i in reversed(range(self.octaves))]
+
+
+class ParamArena:
+    ALIGN = 64  # elements; keeps every tensor 16-byte aligned in the 16-bit shadow too
+
+    def __init__(self, topo: Topology, dtype: int, device: torch.device):
+        self.topo, self.dtype, self.device = topo, dtype, device
+        self.shapes = topo.param_shapes()
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        self.layer_ranges: Dict[str, Tuple[int, int]] = {}
+        for layer in topo.layer_order():
+            lo = off
+            for suffix in (".w", ".b"):
+                name = layer + suffix
+                self.offsets[name] = off
+                off = _round_up(off + int(np.prod(self.shapes[name])), self.ALIGN)
+            self.layer_ranges[layer] = (lo, off)
+        self.total = off
+        z = lambda dt: torch.zeros(self.total, dtype=dt, device=device)
+        self.p, self.m, self.v, self.g = z(torch.float32), z(torch.float32), z(torch.float32), z(torch.float32)
+        self.shadow = z(TORCH_DTYPE[dtype]) if dtype != F32 else None
+
+    def numel(self, name: str) -> int:
+        return int(np.prod(self.shapes[name]))
+
+    def _view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
+        o = self.offsets[name]
+        return arena[o:o + self.numel(name)].view(self.shapes[name])
+
+    def param(self, name): return self._view(self.p, name)
+    def grad(self, name): return self._view(self.g, name)
+    def slot_m(self, name): return self._view(self.m, name)
+    def slot_v(self, name): return self._view(self.v, name)
+
+    def wptr(self, name: str) -> int:
+        """device pointer of the compute-dtype operand copy of a weight."""
+        o = self.offsets[name]
+        if self.shadow is None:
+            return self.p.data_ptr() + 4 * o
+        return self.shadow.data_ptr() + 2 * o
+
+    def pptr(self, name: str) -> int:
+        return self.p.data_ptr() + 4 * self.offsets[name]
+
+    def gptr(self, name: str) -> int:
+        return self.g.data_ptr() + 4 * self.offsets[name]
+
+    def refresh_shadow(self, stream: int) -> None:
+        if self.shadow is not None:
+            call("gct2_cast_from_f32", self.dtype, self.p.data_ptr(), self.shadow.data_ptr(), self.total, stream)
+
+    def glorot_init(self, seed: int = 1234) -> None:
+        """Keras glorot_uniform kernels, zero biases (train.py:134,149,162)."""
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        for name in sorted(self.shapes):
+            shp = self.shapes[name]
+            if name.endswith(".b"):
+                self.param(name).zero_()
+                continue
+            if len(shp) == 2:
+                fan_in, fan_out = shp
+            else:
+                rf = shp[0] * shp[1]
+                fan_in, fan_out = rf * shp[2], rf * shp[3]
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            w = (torch.rand(shp, generator=gen, dtype=torch.float32) * 2 - 1) * lim
+            self.param(name).copy_(w.to(self.device))
+
+
+class _Buffers:
+    pass
+
+
+class UNetEngine:
+    """the planned (zero-copy concat) forward / backward / optimizer step of the Denoiser U-Net."""
+
+    def __init__(self, topo: Topology, dtype: int = BF16, device: Optional[torch.device] = None, steps: int = 200,
+                 base_lr: float = 2e-5, warm_up: int = 2000, beta_1: float = 0.9, beta_2: float = 0.999,
+                 epsilon: float = 1e-7, loss_scaling: bool = False, seed: int = 1234, rng_seed: int = 0):
+        self.lib = _lib.load()
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise _lib.Gct2Error("UNetEngine needs a HIP device (torch device 'cuda'); there is no CPU path")
+        call("gct2_device_check")
+        self.topo, self.dtype, self.steps = topo, dtype, steps
+        self.base_lr, self.warm_up = base_lr, warm_up
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+        self.loss_scaling = loss_scaling
+        self.arena = ParamArena(topo, dtype, self.device)
+        self.arena.glorot_init(seed)
+        self.arena.refresh_shadow(self._stream())
+        self.iterations = 0            # optimizer.iterations [TF]
+        self.rng_seed, self.rng_offset_t, self.rng_offset_eps = rng_seed, 0, 0
+        self._bufs: Dict[Tuple[int, int, int], _Buffers] = {}
+        self.ls_state = None
+        if loss_scaling:
+            self.ls_state = torch.zeros(4, dtype=torch.int32, device=self.device)  # 16-byte gct2_loss_scale_state
+            call("gct2_loss_scale_init", self.ls_state.data_ptr(), float(2 ** 15), self._stream())
+        # called with the layer name as soon as that layer's gradient kernels are enqueued (DP all-reduce)
+        self.grad_ready_hook: Optional[Callable[[str], None]] = None
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def check_input_shape(self, H: int, W: int) -> None:
+        n = self.topo.octaves
+        if H % (2 ** n) or W % (2 ** n):
+            raise ValueError(
+                f"spatial size {H}x{W} is not divisible by 2**octaves = {2 ** n}: the channel concat of "
+                "train.py:114-119 would see mismatched shapes (TensorFlow raises InvalidArgumentError here)")
+
+    def buffers(self, B: int, H: int, W: int) -> _Buffers:
+        key = (B, H, W)
+        if key in self._bufs:
+            return self._bufs[key]
+        self.check_input_shape(H, W)
+        t, n, dt = self.topo, self.topo.octaves, TORCH_DTYPE[self.dtype]
+        b = _Buffers()
+        b.B, b.H, b.W = B, H, W
+        b.hw = [(H >> i, W >> i) for i in range(n + 1)]
+        b.ld = [_round_up(t.fu(i) + t.cx(i), 8) for i in range(n)]
+        z = lambda *shape, dtype=dt: torch.zeros(*shape, dtype=dtype, device=self.device)
+        b.R = [z(B, b.hw[i][0], b.hw[i][1], b.ld[i]) for i in range(n)]
+        b.dR = [z(B, b.hw[i][0], b.hw[i][1], b.ld[i]) for i in range(n)]
+        b.Dlast = z(B, b.hw[n][0], b.hw[n][1], t.fd(n - 1))
+        b.dDlast = z(B, b.hw[n][0], b.hw[n][1], t.fd(n - 1))
+        b.pred = z(B, H, W, 3, dtype=torch.float32)
+        b.dpred = z(B, H, W, 3, dtype=torch.float32)
+        b.eps = z(B, H, W, 3, dtype=torch.float32)
+        b.t_int = z(B, dtype=torch.int32)
+        b.loss = z(1, dtype=torch.float32)
+        b.partials = z(1024, dtype=torch.float32)
+        self._bufs[key] = b
+        return b
+
+    def _esize(self) -> int:
+        return 4 if self.dtype == F32 else 2
+
+    def _slice_ptr(self, buf: torch.Tensor, ch: int) -> int:
+        return buf.data_ptr() + ch * self._esize()
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def set_params(self, params: Dict[str, "np.ndarray | torch.Tensor"]) -> None:
+        for name, val in params.items():
+            tv = torch.as_tensor(np.asarray(val, dtype=np.float32) if not torch.is_tensor(val) else val)
+            self.arena.param(name).copy_(tv.to(self.device, torch.float32))
+        self.arena.refresh_shadow(self._stream())
+
+    def get_params(self) -> Dict[str, np.ndarray]:
+        return {k: self.arena.param(k).detach().cpu().numpy().copy() for k in self.arena.shapes}
+
+    def get_grads(self) -> Dict[str, np.ndarray]:
+        return {k: self.arena.grad(k).detach().cpu().numpy().copy() for k in self.arena.shapes}
+
+    # ---- Trainer.call pieces --------------------------------------------------------------------
+    def sample_noise(self, b: _Buffers) -> None:
+        """t_int ~ U{1..steps}, eps ~ N(0,1)  (train.py:224-227) from the library's Philox streams."""
+        s = self._stream()
+        call("gct2_rng_uniform_int", self.rng_seed, 1, self.rng_offset_t, b.t_int.data_ptr(), b.B, 1, self.steps, s)
+        call("gct2_rng_normal", self.rng_seed, 2, self.rng_offset_eps, b.eps.data_ptr(), b.eps.numel(), s)
+        self.rng_offset_t += b.B
+        self.rng_offset_eps += b.eps.numel()
+
+    def noise_into_r0(self, b: _Buffers, x: torch.Tensor) -> None:
+        t = self.topo
+        call("gct2_noise_image", self.dtype, x.data_ptr(), b.t_int.data_ptr(), b.eps.data_ptr(),
+             self._slice_ptr(b.R[0], t.fu(0)), b.ld[0], b.B, b.H * b.W, 3, self.steps, self._stream())
+
+    def load_input_into_r0(self, b: _Buffers, noised: torch.Tensor) -> None:
+        """Denoiser.call on an externally prepared image (sampler / inference path)."""
+        t = self.topo
+        b.R[0][..., t.fu(0):t.fu(0) + 3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
+
+    def forward(self, b: _Buffers) -> torch.Tensor:
+        """Denoiser.call (train.py:206-215): R_0's image slice must already hold the network input."""
+        t, n, s, dt, A = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena
+        for i in range(n):                                      # DownShuffle_i  (train.py:184)
+            H, W = b.hw[i]
+            if i < n - 1:
+                y, ldy = self._slice_ptr(b.R[i + 1], t.fu(i + 1)), b.ld[i + 1]
+            else:
+                y, ldy = b.Dlast.data_ptr(), t.fd(i)
+            call("gct2_conv4s2_fwd", dt, self._slice_ptr(b.R[i], t.fu(i)), b.ld[i], A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"),
+                 y, ldy, b.B, H, W, t.cx(i), t.fd(i), 1, s)
+        for i in reversed(range(n)):                            # UpShuffle_i    (train.py:188)
+            Hi, Wi = b.hw[i + 1]
+            if i < n - 1:
+                x, ldx = b.R[i + 1].data_ptr(), b.ld[i + 1]
+            else:
+                x, ldx = b.Dlast.data_ptr(), t.fd(i)
+            call("gct2_convT4s2_fwd", dt, x, ldx, A.wptr(f"U{i}.w"), A.pptr(f"U{i}.b"), b.R[i].data_ptr(), b.ld[i],
+                 b.B, Hi, Wi, t.up_in(i), t.fu(i), 1, s)
+        M = b.B * b.H * b.W                                     # Dense(3)       (train.py:198-202)
+        call("gct2_dense_fwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"), b.pred.data_ptr(),
+             M, t.fu(0) + 3, 3, s)
+        return b.pred
+
+    def loss_and_dpred(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
+        """fp32 MSE against the clean image (predict_x, train.py:243-244,262-272) and its gradient."""
+        ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
+        call("gct2_mse_fwd_bwd", b.pred.data_ptr(), target.data_ptr(), b.dpred.data_ptr(), b.loss.data_ptr(),
+             b.partials.data_ptr(), b.pred.numel(), ls_ptr, self._stream())
+        return b.loss
+
+    def _ready(self, layer: str) -> None:
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(layer)
+
+    def backward(self, b: _Buffers) -> None:
+        """reverse pass (what tape.gradient does inside Keras fit, train.py:516); fills the g arena."""
+        t, n, s, dt, A = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena
+        M = b.B * b.H * b.W
+        call("gct2_dense_bwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), b.dpred.data_ptr(), b.dR[0].data_ptr(),
+             b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), s)
+        self._ready("dense")
+        for i in range(n):                                      # UpShuffle_i backward, outermost first
+            Hi, Wi = b.hw[i + 1]
+            if i < n - 1:
+                x, ldx, dx, lddx = b.R[i + 1].data_ptr(), b.ld[i + 1], b.dR[i + 1].data_ptr(), b.ld[i + 1]
+            else:
+                x, ldx, dx, lddx = b.Dlast.data_ptr(), t.fd(i), b.dDlast.data_ptr(), t.fd(i)
+            dz, lddz = b.dR[i].data_ptr(), b.ld[i]
+            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), A.gptr(f"U{i}.b"), b.B, Hi, Wi,
+                 t.up_in(i), t.fu(i), s)
+            self._ready(f"U{i}")
+            call("gct2_convT4s2_dgrad", dt, dz, lddz, A.wptr(f"U{i}.w"), x, ldx, dx, lddx, b.B, Hi, Wi, t.up_in(i),
+                 t.fu(i), 0, s)
+        for i in reversed(range(n)):                            # DownShuffle_i backward, innermost first
+            H, W = b.hw[i]
+            if i < n - 1:
+                dz, lddz = self._slice_ptr(b.dR[i + 1], t.fu(i + 1)), b.ld[i + 1]
+            else:
+                dz, lddz = b.dDlast.data_ptr(), t.fd(i)
+            x, ldx = self._slice_ptr(b.R[i], t.fu(i)), b.ld[i]
+            call("gct2_conv4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"D{i}.w"), A.gptr(f"D{i}.b"), b.B, H, W, t.cx(i),
+                 t.fd(i), s)
+            self._ready(f"D{i}")
+            if i > 0:                                           # the image itself needs no gradient
+                call("gct2_conv4s2_dgrad", dt, dz, lddz, A.wptr(f"D{i}.w"), x, ldx, self._slice_ptr(b.dR[i], t.fu(i)),
+                     b.ld[i], b.B, H, W, t.cx(i), t.fd(i), 1, s)
+
+    # ---- optimizer (train.py:50-65,75) -----------------------------------------------------------
+    def learning_rate(self, k: Optional[int] = None) -> float:
+        """WarmUp.__call__ (train.py:57-65), float32 arithmetic like the reference."""
+        k = self.iterations if k is None else k
+        if k < self.warm_up:
+            return float(np.float32(self.base_lr) * np.float32(k + 1) / np.float32(self.warm_up + 1))
+        return float(np.float32(self.base_lr))
+
+    def adam_alpha(self, k: Optional[int] = None) -> float:
+        k = self.iterations if k is None else k
+        tt = k + 1
+        return self.learning_rate(k) * math.sqrt(1.0 - self.beta_2 ** tt) / (1.0 - self.beta_1 ** tt)
+
+    def apply_adam(self, lo: int = 0, hi: Optional[int] = None, grad_div: float = 1.0) -> None:
+        """Keras Adam on arena range [lo, hi); does not advance `iterations` (see finish_step).
+        grad_div > 1 folds the data-parallel mean (sum over ranks / world size) into the gradient read."""
+        A, s = self.arena, self._stream()
+        hi = A.total if hi is None else hi
+        if self.ls_state is not None:
+            if grad_div != 1.0:
+                raise _lib.Gct2Error("loss scaling with data parallelism: average the gradients before unscaling")
+            inv_ptr, inf_ptr = self.ls_state.data_ptr() + 4, self.ls_state.data_ptr() + 12
+        else:
+            inv_ptr, inf_ptr = None, None
+        if grad_div != 1.0:
+            inv_ptr = self._const_scalar(1.0 / grad_div).data_ptr()
+        shadow = None if A.shadow is None else A.shadow.data_ptr() + 2 * lo
+        call("gct2_adam_keras_multi", A.p.data_ptr() + 4 * lo, A.m.data_ptr() + 4 * lo, A.v.data_ptr() + 4 * lo,
+             A.g.data_ptr() + 4 * lo, shadow, self.dtype, hi - lo, self.adam_alpha(), self.beta_1, self.beta_2,
+             self.epsilon, inv_ptr, inf_ptr, 1, s)
+
+    def _const_scalar(self, v: float) -> torch.Tensor:
+        if not hasattr(self, "_consts"):
+            self._consts = {}
+        if v not in self._consts:
+            self._consts[v] = torch.tensor([v], dtype=torch.float32, device=self.device)
+        return self._consts[v]
+
+    def finish_step(self) -> None:
+        if self.ls_state is not None:
+            call("gct2_loss_scale_update", self.ls_state.data_ptr(), 2000, self._stream())
+        self.iterations += 1
+
+    def begin_step(self) -> None:
+        if self.ls_state is not None:
+            call("gct2_loss_scale_begin", self.ls_state.data_ptr(), self._stream())
+
+    def check_finite(self) -> None:
+        if self.ls_state is not None:
+            call("gct2_scale_check_finite", self.arena.g.data_ptr(), self.arena.total, self.ls_state.data_ptr(), self._stream())
+
+    # ---- the whole step ---------------------------------------------------------------------------
+    def train_step(self, x: torch.Tensor, t_int: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None,
+                   apply: bool = True) -> torch.Tensor:
+        """x: fp32 [B,H,W,3] on the device.  Returns the fp32 loss as a 1-element device tensor
+        (no host synchronisation).  t_int / eps may be injected for parity runs (SURVEY.md §8c RNG)."""
+        if x.dim() != 4 or x.shape[-1] != 3:
+            raise ValueError(f"expected an NHWC batch [B,H,W,3], got {tuple(x.shape)}")
+        if x.dtype != torch.float32 or not x.is_contiguous() or x.device != self.device:
+            x = x.to(self.device, torch.float32).contiguous()
+        B, H, W, _ = x.shape
+        b = self.buffers(B, H, W)
+        self.begin_step()
+        if t_int is None or eps is None:
+            self.sample_noise(b)
+        if t_int is not None:
+            b.t_int.copy_(t_int.to(self.device, torch.int32))
+        if eps is not None:
+            b.eps.copy_(eps.to(self.device, torch.float32))
+        self.noise_into_r0(b, x)
+        self.forward(b)
+        loss = self.loss_and_dpred(b, x)
+        self.backward(b)
+        if apply:
+            self.check_finite()
+            self.apply_adam()
+            self.finish_step()
+        return loss
+
+    def predict(self, noised: torch.Tensor) -> torch.Tensor:
+        B, H, W, _ = noised.shape
+        b = self.buffers(B, H, W)
+        self.load_input_into_r0(b, noised)
+        return self.forward(b)
+
+    def loss_scale(self) -> Tuple[float, int]:
+        if self.ls_state is None:
+            return 1.0, 0
+        raw = self.ls_state.cpu()
+        return float(raw[:1].view(torch.float32)[0]), int(raw[2])

@@ -1,0 +1,449 @@
+"""Host-side mirror of the reference's Python model/train-loop surface (train.py:17-283, 498-523).
+
+Same names, constructor arguments and defaults as /root/reference/train.py so a user of that script finds
+`WarmUp`, `alpha_dash`, `Residual`, `Block`, `UpShuffle`, `DownShuffle`, `identity`, `Denoiser`, `Trainer`,
+`compile`/`fit` and the module-level hyper-parameters here; tensors are NHWC torch tensors on the HIP device
+and all arithmetic runs in libgct2.so (include/gct2.h).  There is no TensorFlow and no CPU fallback.
+
+Module-level globals below ARE the config API, like the reference's (train.py:17-36); `configure(...)` sets
+several at once.  `compute_dtype` is the one MI355X-specific knob.
+"""
+from __future__ import annotations
+
+import sys
+from typing import Callable, Dict, Iterable, List, Optional, Sequence as Seq
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F16, F32, call
+from .engine import TORCH_DTYPE, Topology, UNetEngine
+
+# ---- train.py:17-36 ---------------------------------------------------------------------------------
+size = 256
+pixel_size = 128 * 1
+max_size = 512 * 1
+block_depth = 0
+octaves = 6  # bottleneck = 4x4
+
+batch_size = 1
+steps = 200
+
+residual = False
+concat = True
+
+predict_x = True  # as opposed to epsilon
+predict_scaled_epsilon = False
+prediction_weighting = False
+ordinary_differential_equation = False
+
+mixed_precision = False
+
+warm_up = 2_000
+
+# MI355X knob: None -> float32, or float16 when mixed_precision (train.py:38); "bfloat16" selects the
+# bf16-operand / fp32-accumulate MFMA path that BASELINE.json's metric is quoted on.
+compute_dtype: Optional[str] = None
+
+_DTYPES = {"float32": F32, "bfloat16": BF16, "float16": F16}
+
+
+def configure(**kw) -> None:
+    """set module-level hyper-parameters (the reference edits them in source, train.py:5-36)."""
+    mod = sys.modules[__name__]
+    for k, v in kw.items():
+        if not hasattr(mod, k):
+            raise AttributeError(f"unknown hyper-parameter {k!r}")
+        setattr(mod, k, v)
+
+
+def preferred_dtype_code() -> int:
+    """train.py:38: preferred_type = float16 if mixed_precision else float32 (+ the bf16 knob)."""
+    if compute_dtype is not None:
+        return _DTYPES[compute_dtype]
+    return F16 if mixed_precision else F32
+
+
+def _unsupported(what: str, line: str):
+    raise NotImplementedError(
+        f"{what} is off in the reference's defaults ({line}) and outside this build's hot-path scope "
+        "(SURVEY.md §8a/§8f); only the default branch is implemented")
+
+
+# ---- optimizer pieces (train.py:47-83) -----------------------------------------------------------------
+class WarmUp:
+    """train.py:50-65: lr(step) = base*(step+1)/(warmup_steps+1) while step < warmup_steps, else base."""
+
+    def __init__(self, base, warmup_steps):
+        self.base = base
+        self.warmup_steps = warmup_steps
+
+    def __call__(self, step):
+        import numpy as np
+        if step < self.warmup_steps:
+            return float(np.float32(self.base) * np.float32(step + 1) / np.float32(self.warmup_steps + 1))
+        return float(np.float32(self.base))
+
+
+class Adam:
+    """tf.keras.optimizers.Adam hyper-parameters (train.py:75); the update itself is
+    gct2_adam_keras_multi (epsilon added to sqrt(v))."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
+        self.iterations = 0
+        self.loss_scaling = False
+
+    def lr(self, step: int) -> float:
+        return self.learning_rate(step) if callable(self.learning_rate) else float(self.learning_rate)
+
+
+class LossScaleOptimizer:
+    """tf.keras.mixed_precision.LossScaleOptimizer (train.py:82-83): dynamic loss scaling."""
+
+    def __init__(self, inner_optimizer: Adam):
+        self.inner = inner_optimizer
+        self.inner.loss_scaling = True
+
+    def __getattr__(self, k):
+        return getattr(self.inner, k)
+
+
+def default_optimizer():
+    """train.py:75,82-83"""
+    opt = Adam(WarmUp(2e-5, warm_up))
+    return LossScaleOptimizer(opt) if mixed_precision else opt
+
+
+def alpha_dash(t):
+    """train.py:85-93"""
+    t = t / (steps + 1)
+    return (1 - t) ** 2 * 0.25
+
+
+test_step = 25  # train.py:95
+
+
+def identity(y_true, y_pred):
+    """train.py:171-173: reduce_mean(y_pred), y_true ignored."""
+    return torch.mean(y_pred)
+
+
+# ---- eager layers (train.py:97-169) ---------------------------------------------------------------------
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _as_compute(x: torch.Tensor, code: int) -> torch.Tensor:
+    if not x.is_cuda:
+        raise _lib.Gct2Error("layers run on the HIP device only (there is no CPU path)")
+    return x.to(TORCH_DTYPE[code]).contiguous()
+
+
+class Layer:
+    def build(self, input_shape):
+        pass
+
+    def call(self, input):
+        raise NotImplementedError
+
+    def __call__(self, input):
+        if not getattr(self, "_built", False):
+            self.build(tuple(input[0].shape) if isinstance(input, (tuple, list)) else tuple(input.shape))
+            self._built = True
+        return self.call(input)
+
+
+class Sequential(Layer):
+    """the subset of tf.keras.Sequential the reference uses (train.py:130,183,191)."""
+
+    def __init__(self, layers: Seq[Layer]):
+        self.layers = list(layers)
+
+    def call(self, input):
+        for layer in self.layers:
+            input = layer(input)
+        return input
+
+
+class Residual(Layer):
+    """train.py:97-121 (concat mode)."""
+
+    def __init__(self, module, highway=lambda x: x):
+        self.module = module
+        self.highway = highway
+        if residual:
+            _unsupported("residual=True", "train.py:26")
+
+    def call(self, input):
+        if concat:
+            return torch.cat([self.module(input).to(input.dtype), self.highway(input)], -1)
+        return self.module(input)
+
+
+class Block(Layer):
+    """train.py:123-143: block_depth x [Conv2D 3x3/s1 + ReLU]; identity at block_depth = 0."""
+
+    def __init__(self, filters):
+        self.filters = filters
+        if block_depth != 0:
+            _unsupported("block_depth > 0", "train.py:20")
+
+    def call(self, input):
+        return input
+
+
+class _ConvLayer(Layer):
+    """shared storage for DownShuffle / UpShuffle: kernel/bias are fp32 master views (possibly into a
+    Denoiser's parameter arena) plus a compute-dtype operand copy."""
+
+    def __init__(self, filters):
+        self.filters = filters
+        self.kernel: Optional[torch.Tensor] = None      # fp32, Keras layout
+        self.bias: Optional[torch.Tensor] = None
+        self._operand = None                             # callable -> device pointer of compute-dtype kernel
+        self.dtype_code = preferred_dtype_code()
+
+    def _kernel_shape(self, cin):
+        raise NotImplementedError
+
+    def build(self, input_shape):
+        if self.kernel is not None:
+            return
+        import math
+        cin = input_shape[-1]
+        shp = self._kernel_shape(cin)
+        lim = math.sqrt(6.0 / (16 * shp[2] + 16 * shp[3]))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.kernel = ((torch.rand(shp) * 2 - 1) * lim).to(dev)
+        self.bias = torch.zeros(self.filters, device=dev)
+
+    def _operand_tensor(self) -> torch.Tensor:
+        return self.kernel if self.dtype_code == F32 else self.kernel.to(TORCH_DTYPE[self.dtype_code])
+
+
+class UpShuffle(_ConvLayer):
+    """train.py:145-156: Conv2DTranspose(filters, 4, 2, 'same', relu)."""
+
+    def _kernel_shape(self, cin):
+        return (4, 4, self.filters, cin)
+
+    def call(self, input):
+        x = _as_compute(input, self.dtype_code)
+        B, H, W, C = x.shape
+        y = torch.empty(B, 2 * H, 2 * W, self.filters, dtype=x.dtype, device=x.device)
+        w = self._operand_tensor()
+        call("gct2_convT4s2_fwd", self.dtype_code, x.data_ptr(), C, w.data_ptr(), self.bias.data_ptr(), y.data_ptr(),
+             self.filters, B, H, W, C, self.filters, 1, _stream(x))
+        return y
+
+
+class DownShuffle(_ConvLayer):
+    """train.py:158-169: Conv2D(filters, 4, 2, 'same', relu)."""
+
+    def _kernel_shape(self, cin):
+        return (4, 4, cin, self.filters)
+
+    def call(self, input):
+        x = _as_compute(input, self.dtype_code)
+        B, H, W, C = x.shape
+        if H % 2 or W % 2:
+            raise ValueError(f"DownShuffle needs even spatial dims, got {H}x{W}")
+        y = torch.empty(B, H // 2, W // 2, self.filters, dtype=x.dtype, device=x.device)
+        w = self._operand_tensor()
+        call("gct2_conv4s2_fwd", self.dtype_code, x.data_ptr(), C, w.data_ptr(), self.bias.data_ptr(), y.data_ptr(),
+             self.filters, B, H, W, C, self.filters, 1, _stream(x))
+        return y
+
+
+class Dense(Layer):
+    """tf.keras.layers.Dense(units) on a rank-4 input (train.py:198-202); fp32 output."""
+
+    def __init__(self, units):
+        self.units = units
+        self.kernel = None
+        self.bias = None
+        self.dtype_code = preferred_dtype_code()
+
+    def build(self, input_shape):
+        if self.kernel is not None:
+            return
+        import math
+        cin = input_shape[-1]
+        lim = math.sqrt(6.0 / (cin + self.units))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.kernel = ((torch.rand(cin, self.units) * 2 - 1) * lim).to(dev)
+        self.bias = torch.zeros(self.units, device=dev)
+
+    def call(self, input):
+        x = _as_compute(input, self.dtype_code)
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty(*x.shape[:-1], self.units, dtype=torch.float32, device=x.device)
+        call("gct2_dense_fwd", self.dtype_code, x.data_ptr(), C, self.kernel.data_ptr(), self.bias.data_ptr(), y.data_ptr(),
+             M, C, self.units, _stream(x))
+        return y
+
+
+# ---- the model (train.py:175-283) -------------------------------------------------------------------------
+class Denoiser(Layer):
+    """train.py:175-215.  `self.middle` has the reference's nested structure (and is eagerly callable, one
+    kernel launch + one concat copy per layer); `call` runs the planned zero-copy engine instead.
+    Both read the SAME parameters: the layers' kernel/bias are views into the engine's arena."""
+
+    def __init__(self, seed: int = 1234, device: Optional[torch.device] = None):
+        self.topology = Topology(pixel_size, max_size, octaves)
+        self.dtype_code = preferred_dtype_code()
+        self._device = device
+        self._seed = seed
+        self.downs: List[DownShuffle] = [None] * octaves
+        self.ups: List[UpShuffle] = [None] * octaves
+        self.middle = Block(min(pixel_size * 2 ** octaves, max_size))
+        for i in reversed(range(octaves)):
+            filters = min(pixel_size * 2 ** i, max_size)
+            self.downs[i] = DownShuffle(filters)
+            self.ups[i] = UpShuffle(min(pixel_size * 2 ** i // 2, max_size))
+            self.middle = Residual(
+                Sequential([
+                    self.downs[i],
+                    Block(filters),
+                    self.middle,
+                    Block(filters),
+                    self.ups[i],
+                ])
+            )
+        self.head = Dense(3)
+        self.middle = Sequential([
+            Block(pixel_size),
+            self.middle,
+            Block(pixel_size),
+            self.head,
+        ])
+        self.engine: Optional[UNetEngine] = None
+
+    def ensure_engine(self, **engine_kw) -> UNetEngine:
+        if self.engine is None:
+            kw = dict(steps=steps, warm_up=warm_up, seed=self._seed)
+            kw.update(engine_kw)
+            self.engine = UNetEngine(self.topology, self.dtype_code, self._device, **kw)
+            A = self.engine.arena
+            for i in range(octaves):
+                for layer, tag in ((self.downs[i], f"D{i}"), (self.ups[i], f"U{i}")):
+                    layer.kernel, layer.bias = A.param(tag + ".w"), A.param(tag + ".b")
+                    layer.dtype_code = self.dtype_code
+                    layer._built = True
+            self.head.kernel, self.head.bias = A.param("dense.w"), A.param("dense.b")
+            self.head.dtype_code = self.dtype_code
+            self.head._built = True
+        return self.engine
+
+    @property
+    def trainable_variables(self) -> Dict[str, torch.Tensor]:
+        A = self.ensure_engine().arena
+        return {k: A.param(k) for k in A.shapes}
+
+    def call(self, input):
+        x, t = input            # t is ignored by the reference as well (train.py:208-210)
+        eng = self.ensure_engine()
+        return eng.predict(x).clone()
+
+    def call_eager(self, input):
+        """the reference's literal layer-by-layer evaluation of self.middle (train.py:210)."""
+        x, t = input
+        self.ensure_engine()
+        return self.middle(x)
+
+
+class LambdaCallback:
+    """tf.keras.callbacks.LambdaCallback(on_epoch_begin=...) (train.py:519-521)."""
+
+    def __init__(self, on_epoch_begin: Optional[Callable] = None, on_epoch_end: Optional[Callable] = None):
+        self.on_epoch_begin = on_epoch_begin
+        self.on_epoch_end = on_epoch_end
+
+
+class Trainer(Layer):
+    """train.py:217-283 + the Keras compile/fit driver (train.py:511-523)."""
+
+    def __init__(self, denoiser: Denoiser):
+        self.denoiser = denoiser
+        self.optimizer = None
+        self.loss_fn = None
+        if ordinary_differential_equation:
+            _unsupported("ordinary_differential_equation=True", "train.py:32")
+        if not predict_x:
+            _unsupported("predict_x=False (epsilon prediction)", "train.py:29")
+
+    def _engine(self) -> UNetEngine:
+        opt = self.optimizer
+        kw = {}
+        if opt is not None and self.denoiser.engine is None:
+            inner = getattr(opt, "inner", opt)
+            kw = dict(beta_1=inner.beta_1, beta_2=inner.beta_2, epsilon=inner.epsilon,
+                      loss_scaling=bool(inner.loss_scaling))
+            lr = inner.learning_rate
+            if isinstance(lr, WarmUp):
+                kw.update(base_lr=lr.base, warm_up=lr.warmup_steps)
+            elif not callable(lr):
+                kw.update(base_lr=float(lr), warm_up=0)
+            else:
+                raise NotImplementedError("only WarmUp or constant learning rates are supported")
+        eng = self.denoiser.ensure_engine(**kw)
+        return eng
+
+    def call(self, x):
+        """returns the scalar fp32 loss for a freshly noised batch (train.py:223-272); no gradients."""
+        eng = self._engine()
+        x = x.to(eng.device, torch.float32).contiguous()
+        b = eng.buffers(*x.shape[:3])
+        eng.sample_noise(b)
+        eng.noise_into_r0(b, x)
+        eng.forward(b)
+        return eng.loss_and_dpred(b, x).clone()[0]
+
+    def compile(self, optimizer, loss):
+        """train.py:511-514"""
+        if self.denoiser.engine is not None and optimizer is not None:
+            eng, inner = self.denoiser.engine, getattr(optimizer, "inner", optimizer)
+            eng.beta_1, eng.beta_2, eng.epsilon = inner.beta_1, inner.beta_2, inner.epsilon
+            lr = inner.learning_rate
+            if isinstance(lr, WarmUp):
+                eng.base_lr, eng.warm_up = lr.base, lr.warmup_steps
+            elif not callable(lr):
+                eng.base_lr, eng.warm_up = float(lr), 0
+            if bool(inner.loss_scaling) != (eng.ls_state is not None):
+                raise _lib.Gct2Error("loss scaling must be chosen before the first call builds the engine")
+        self.optimizer, self.loss_fn = optimizer, loss
+
+    def train_step(self, data):
+        """one Keras train_step on a (x, y) batch with y == x (train.py:293): returns {'loss': tensor}."""
+        x = data[0] if isinstance(data, (tuple, list)) else data
+        loss = self._engine().train_step(x)
+        inner = getattr(self.optimizer, "inner", self.optimizer)
+        if inner is not None:
+            inner.iterations = self._engine().iterations
+        return {"loss": loss}
+
+    def fit(self, dataset: Iterable, steps_per_epoch: int = 1000, epochs: int = 1, callbacks: Seq = (), verbose: int = 1):
+        """train.py:516-523.  `dataset` yields (image, image) batches, NHWC in [-1, 1)."""
+        if self.optimizer is None:
+            raise RuntimeError("call compile(optimizer, loss) before fit (train.py:511)")
+        it = iter(dataset)
+        history = {"loss": []}
+        for epoch in range(epochs):
+            logs: Dict[str, float] = {}
+            for cb in callbacks:
+                if getattr(cb, "on_epoch_begin", None):
+                    cb.on_epoch_begin(epoch, logs)
+            running = None
+            for _ in range(steps_per_epoch):
+                out = self.train_step(next(it))
+                running = out["loss"] if running is None else running + out["loss"]
+            logs["loss"] = float(running[0]) / steps_per_epoch     # one host sync per epoch
+            history["loss"].append(logs["loss"])
+            if verbose:
+                print(f"Epoch {epoch + 1}/{epochs} - loss: {logs['loss']:.6f}", flush=True)
+            for cb in callbacks:
+                if getattr(cb, "on_epoch_end", None):
+                    cb.on_epoch_end(epoch, logs)
+        return history

@@ -1,0 +1,147 @@
+/*
+ * gct2.h - C ABI of the MI355X (gfx950) train-step kernels for relgukxilef/GAN-Class-Transfer2.
+ *
+ * The reference (/root/reference/train.py) has no native code and no FFI: every device op is a
+ * TensorFlow/Keras call.  Each entry point below replaces one such call site (cited per function,
+ * file:line into /root/reference/train.py) and is what a ctypes / cffi binding of the reference's
+ * Python host code would bind.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise.
+ *  - activations are NHWC "views": pointer to channel 0 of pixel 0 + `ld` = distance between
+ *    consecutive pixels in ELEMENTS (>= channels; lets a tensor live inside a channel slice of a
+ *    wider concat buffer, which is how train.py:114-119's tf.concat becomes zero-copy).
+ *  - `dtype` selects the storage/operand type of activations, activation gradients and the
+ *    weight operand: GCT2_F32 (reference default, train.py:34,38), GCT2_BF16, GCT2_F16
+ *    (train.py:43-45 mixed_float16).  Accumulation, biases, weight gradients, Adam state: fp32.
+ *  - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *    No allocation, no host synchronisation, no ownership transfer; re-entrant across streams.
+ *  - return value: GCT2_OK or an error code; nothing is launched when arguments are rejected.
+ */
+#ifndef GCT2_H
+#define GCT2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GCT2_F32 = 0, GCT2_BF16 = 1, GCT2_F16 = 2 };
+enum {
+  GCT2_OK = 0,
+  GCT2_EINVAL = 1,   /* bad shape / stride / alignment / dtype */
+  GCT2_ELAUNCH = 2,  /* HIP launch error (hipGetLastError != success) */
+  GCT2_ENODEV = 3    /* no gfx950 device visible */
+};
+
+/* library / device identification ------------------------------------------------------------ */
+int gct2_abi_version(void);                 /* bumps when a signature below changes */
+const char* gct2_last_error(void);          /* host string describing the last non-OK return */
+int gct2_device_check(void);                /* GCT2_OK iff the current device is gfx950 */
+/* test hook: non-zero routes every convolution through the direct (non-MFMA) kernels */
+void gct2_debug_force_direct(int on);
+
+/* ---- DownShuffle = Conv2D(f, 4, 2, 'same', relu)   train.py:158-169 ------------------------- */
+/* y[b,oh,ow,o] = act(bias[o] + sum_{kh,kw,i} x[b,2oh+kh-1,2ow+kw-1,i] * w[kh,kw,i,o])
+ * x: [B,H,W,Cin] view, H and W even;  w: Keras kernel (4,4,Cin,Cout) of `dtype`;
+ * bias: fp32[Cout] or NULL;  y: [B,H/2,W/2,Cout] view;  relu != 0 applies max(.,0). */
+int gct2_conv4s2_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias,
+                     void* y, int ldy, int B, int H, int W, int Cin, int Cout, int relu,
+                     void* stream);
+
+/* input gradient of the above (autodiff of train.py:161-166 inside Keras fit, train.py:516):
+ * dx[b,ih,iw,i] (+)= mask * sum_{kh,kw,o} dz[b,oh,ow,o] * w[kh,kw,i,o],  ih = 2oh+kh-1.
+ * dz: [B,H/2,W/2,Cout] PRE-activation gradient;  dx: [B,H,W,Cin] view.
+ * act (may be NULL): [B,H,W,Cin] view of the tensor whose ReLU produced x; mask = act > 0, so dx is
+ * again a pre-activation gradient.  accumulate != 0: dx += result (skip branch of the concat,
+ * train.py:114-119), else dx = result. */
+int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act,
+                       int ldact, void* dx, int lddx, int B, int H, int W, int Cin, int Cout,
+                       int accumulate, void* stream);
+
+/* weight + bias gradient: dw[kh,kw,i,o] += sum_{b,oh,ow} x[b,2oh+kh-1,2ow+kw-1,i]*dz[b,oh,ow,o],
+ * db[o] += sum dz[..,o].  dw: fp32 (4,4,Cin,Cout), db: fp32[Cout] or NULL.  ACCUMULATES: the caller
+ * provides zeroed (or running) buffers. */
+int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
+                       float* db, int B, int H, int W, int Cin, int Cout, void* stream);
+
+/* ---- UpShuffle = Conv2DTranspose(f, 4, 2, 'same', relu)   train.py:145-156 ------------------ */
+/* y[b,2ih+kh-1,2iw+kw-1,o] += x[b,ih,iw,i] * w[kh,kw,o,i]; then bias, relu.
+ * x: [B,H,W,Cin] view;  w: Keras kernel (4,4,Cout,Cin);  y: [B,2H,2W,Cout] view. */
+int gct2_convT4s2_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias,
+                      void* y, int ldy, int B, int H, int W, int Cin, int Cout, int relu,
+                      void* stream);
+
+/* dx[b,ih,iw,i] (+)= mask * sum_{kh,kw,o} dz[b,2ih+kh-1,2iw+kw-1,o] * w[kh,kw,o,i]
+ * dz: [B,2H,2W,Cout];  dx/act: [B,H,W,Cin] views;  mask/accumulate as for conv4s2_dgrad. */
+int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act,
+                        int ldact, void* dx, int lddx, int B, int H, int W, int Cin, int Cout,
+                        int accumulate, void* stream);
+
+/* dw[kh,kw,o,i] += sum_{b,ih,iw} x[b,ih,iw,i] * dz[b,2ih+kh-1,2iw+kw-1,o]; db[o] += sum dz. */
+int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
+                        float* db, int B, int H, int W, int Cin, int Cout, void* stream);
+
+/* ---- Dense(3) head on a rank-4 input   train.py:198-202 ------------------------------------- */
+/* y[m,o] = b[o] + sum_i x[m,i] * w[i,o];  x: [M,Cin] view of `dtype`; w fp32 (Cin,Cout), Cout <= 4;
+ * y: fp32 [M,Cout] contiguous (the loss is taken in fp32, train.py:262-263). */
+int gct2_dense_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* y,
+                   int M, int Cin, int Cout, void* stream);
+
+/* dx[m,i] = mask * sum_o dy[m,o] w[i,o] for i < Cmask (channels >= Cmask get no gradient written);
+ * dw[i,o] += sum_m x[m,i] dy[m,o];  db[o] += sum_m dy[m,o].   dy fp32 [M,Cout].
+ * mask = x[m,i] > 0 (x is the ReLU output feeding the head; train.py:188,198). */
+int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float* dy, void* dx,
+                   int lddx, float* dw, float* db, int M, int Cin, int Cout, int Cmask,
+                   void* stream);
+
+/* ---- Trainer.call pieces   train.py:223-272 -------------------------------------------------- */
+/* t_int[b] ~ U{1..steps} (train.py:224-226) and eps ~ N(0,1) (train.py:227) from a counter-based
+ * Philox4x32-10 stream keyed by (seed, stream_id); `offset` = elements already drawn. */
+int gct2_rng_uniform_int(uint64_t seed, uint64_t stream_id, uint64_t offset, int32_t* out, size_t n,
+                         int lo, int hi_inclusive, void* stream);
+int gct2_rng_normal(uint64_t seed, uint64_t stream_id, uint64_t offset, float* out, size_t n,
+                    void* stream);
+
+/* noised = x*sqrt(a_b) + eps*sqrt(1-a_b), a_b = 0.25*(1 - t_b/(steps+1))^2  (train.py:85-93,229-234)
+ * x, eps: fp32 [B, HW, C] contiguous; t_int: int32[B]; out: view [B*HW, C] of `dtype` with ldout. */
+int gct2_noise_image(int dtype, const float* x, const int32_t* t_int, const float* eps, void* out,
+                     int ldout, int B, int HW, int C, int steps, void* stream);
+
+/* loss = mean((target - pred)^2) in fp32 (train.py:272); dpred = loss_scale * 2 (pred-target)/n.
+ * `loss` (1 float) is overwritten; `partials` is caller scratch of >= 1024 floats.
+ * loss_scale_ptr: device pointer to the current loss scale (fp16 mode) or NULL for 1. */
+int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss,
+                     float* partials, size_t n, const float* loss_scale_ptr, void* stream);
+
+/* ---- optimizer   train.py:50-65, 75 (Keras Adam + WarmUp) ------------------------------------ */
+/* Keras ResourceApplyAdam over a flat fp32 arena of n parameters:
+ *   g' = g * (*inv_scale_ptr or 1);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+ *   p -= alpha * m / (sqrt(v) + eps),  alpha = lr_k * sqrt(1-b2^t)/(1-b1^t) computed by the host
+ *   (lr_k from the WarmUp schedule).  Skipped entirely when *found_inf != 0 (LossScaleOptimizer,
+ *   train.py:82-83).  shadow (may be NULL): low-precision copy of p in `shadow_dtype` written in the
+ *   same pass.  zero_grad != 0: g is zeroed after use (the wgrad kernels accumulate). */
+int gct2_adam_keras_multi(float* p, float* m, float* v, float* g, void* shadow, int shadow_dtype,
+                          size_t n, float alpha, float beta1, float beta2, float eps,
+                          const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad,
+                          void* stream);
+
+/* fp32 -> dtype cast of a flat array (initial weight shadows). */
+int gct2_cast_from_f32(int dtype, const float* src, void* dst, size_t n, void* stream);
+
+/* ---- mixed precision (train.py:34,43-45,82-83) ------------------------------------------------ */
+/* state = {float scale; float inv_scale; int32 good_steps; int32 found_inf} on the device.
+ * scale_check_finite: found_inf |= any(!isfinite(g)).  (found_inf must be zeroed by loss_scale_begin) */
+typedef struct { float scale; float inv_scale; int32_t good_steps; int32_t found_inf; } gct2_loss_scale_state;
+int gct2_loss_scale_init(gct2_loss_scale_state* state, float initial_scale, void* stream);
+int gct2_loss_scale_begin(gct2_loss_scale_state* state, void* stream);          /* found_inf = 0 */
+int gct2_scale_check_finite(const float* g, size_t n, gct2_loss_scale_state* state, void* stream);
+/* dynamic update [TF]: finite -> good_steps++, x2 every growth_interval; non-finite -> /2, reset. */
+int gct2_loss_scale_update(gct2_loss_scale_state* state, int growth_interval, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCT2_H */

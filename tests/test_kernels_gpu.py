@@ -1,0 +1,331 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle (oracle/denoiser_oracle.py), same seeded inputs.
+
+Tolerances (stated per SURVEY.md §4):
+  * GCT2_F32  : rel-L2 <= 2e-6  (fp32 fma accumulation vs the fp64 oracle)
+  * GCT2_BF16 / GCT2_F16 : inputs are pre-rounded to the 16-bit type, so only accumulation order (fp32) and the
+    final output rounding differ from the oracle: rel-L2 <= 4e-3 (bf16, 2^-9 output rounding) / 6e-4 (f16).
+PARITY UNPINNED w.r.t. TensorFlow: the reference holds no fixtures (see oracle/denoiser_oracle.py header).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16, F16 = 0, 1, 2
+TDT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+TOL_OUT = {F32: 2e-6, BF16: 4e-3, F16: 6e-4}      # outputs stored in the compute dtype
+TOL_F32OUT = {F32: 2e-6, BF16: 2e-5, F16: 2e-5}   # fp32 outputs (weight gradients) of pre-rounded operands
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def rnd(a, dt):
+    """value-round a float64 array to the compute dtype."""
+    if dt == F32:
+        return a.astype(np.float32).astype(np.float64)
+    return torch.tensor(a, dtype=torch.float64).to(TDT[dt]).to(torch.float64).numpy()
+
+
+def dev(a, dt, device):
+    return torch.tensor(np.asarray(a), dtype=torch.float64).to(TDT[dt]).to(device).contiguous()
+
+
+def lib():
+    import gan_class_transfer2_amd as g
+    return g._lib
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# (B, H, W, Cin, Cout): MFMA-eligible shapes (multiples of 8) incl. ragged tiles, and direct-path shapes
+CONV_SHAPES = [
+    (2, 8, 8, 64, 128),      # one full tile
+    (1, 4, 12, 72, 136),     # K and N ragged w.r.t. 64/128, M ragged
+    (3, 2, 2, 256, 64),      # tiny spatial grid (bottleneck regime), deep K
+    (2, 16, 16, 3, 8),       # image layer: Cin = 3 -> direct kernels
+    (1, 6, 10, 5, 7),        # nothing aligned -> direct kernels
+]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv4s2_fwd(gpu, dt, shape):
+    B, H, W, Cin, Cout = shape
+    rng = np.random.default_rng(1)
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+    b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+    ref = np.maximum(O.conv4s2_fwd(x, w, b), 0)
+    # input and output both live inside wider (concat-style) buffers: exercises ld != C and pointer offsets
+    ldx, ldy, offx, offy = Cin + 8, Cout + 16, 8, 8
+    xb = torch.zeros(B, H, W, ldx, dtype=TDT[dt], device=gpu)
+    xb[..., offx:offx + Cin] = dev(x, dt, gpu)
+    yb = torch.full((B, H // 2, W // 2, ldy), 7.0, dtype=TDT[dt], device=gpu)
+    wd, bd = dev(w, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
+    es = xb.element_size()
+    lib().call("gct2_conv4s2_fwd", dt, xb.data_ptr() + offx * es, ldx, wd.data_ptr(), bd.data_ptr(),
+               yb.data_ptr() + offy * es, ldy, B, H, W, Cin, Cout, 1, stream())
+    torch.cuda.synchronize()
+    out = yb[..., offy:offy + Cout].double().cpu().numpy()
+    assert rel_l2(out, ref) <= TOL_OUT[dt]
+    # nothing outside the output slice was touched
+    assert float((yb[..., :offy].float() - 7).abs().max()) == 0 and float((yb[..., offy + Cout:].float() - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_convT4s2_fwd(gpu, dt, shape):
+    B, H, W, Cin, Cout = shape
+    rng = np.random.default_rng(2)
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    w = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+    b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+    ref = np.maximum(O.convT4s2_fwd(x, w, b), 0)
+    xd, wd, bd = dev(x, dt, gpu), dev(w, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
+    ldy = Cout + 8
+    yb = torch.zeros(B, 2 * H, 2 * W, ldy, dtype=TDT[dt], device=gpu)
+    lib().call("gct2_convT4s2_fwd", dt, xd.data_ptr(), Cin, wd.data_ptr(), bd.data_ptr(), yb.data_ptr(), ldy,
+               B, H, W, Cin, Cout, 1, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(yb[..., :Cout].double().cpu().numpy(), ref) <= TOL_OUT[dt]
+    assert float(yb[..., Cout:].float().abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_conv4s2_dgrad(gpu, dt, shape, accumulate):
+    B, H, W, Cin, Cout = shape
+    rng = np.random.default_rng(3)
+    x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)      # ReLU output that fed the conv
+    w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+    prev = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    dx_ref, _, _ = O.conv4s2_bwd(x, w, dz)
+    ref = dx_ref * (x > 0) + (prev if accumulate else 0)
+    dzd, wd, actd = dev(dz, dt, gpu), dev(w, dt, gpu), dev(x, dt, gpu)
+    dxd = dev(prev, dt, gpu)
+    lib().call("gct2_conv4s2_dgrad", dt, dzd.data_ptr(), Cout, wd.data_ptr(), actd.data_ptr(), Cin, dxd.data_ptr(), Cin,
+               B, H, W, Cin, Cout, accumulate, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(dxd.double().cpu().numpy(), ref) <= TOL_OUT[dt]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_convT4s2_dgrad(gpu, dt, shape):
+    B, H, W, Cin, Cout = shape
+    rng = np.random.default_rng(4)
+    x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+    w = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+    dz = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+    dx_ref, _, _ = O.convT4s2_bwd(x, w, dz)
+    ref = dx_ref * (x > 0)
+    dzd, wd, actd = dev(dz, dt, gpu), dev(w, dt, gpu), dev(x, dt, gpu)
+    dxd = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
+    lib().call("gct2_convT4s2_dgrad", dt, dzd.data_ptr(), Cout, wd.data_ptr(), actd.data_ptr(), Cin, dxd.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 0, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(dxd.double().cpu().numpy(), ref) <= TOL_OUT[dt]
+    # no mask: plain input gradient
+    lib().call("gct2_convT4s2_dgrad", dt, dzd.data_ptr(), Cout, wd.data_ptr(), None, 0, dxd.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 0, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(dxd.double().cpu().numpy(), dx_ref) <= TOL_OUT[dt]
+
+
+WGRAD_SHAPES = CONV_SHAPES + [(4, 32, 32, 64, 128)]   # long reduction: exercises the r-split + atomics
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_conv4s2_wgrad(gpu, dt, shape):
+    B, H, W, Cin, Cout = shape
+    rng = np.random.default_rng(5)
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+    _, dw_ref, db_ref = O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)
+    xd, dzd = dev(x, dt, gpu), dev(dz, dt, gpu)
+    dw = torch.zeros(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)
+    db = torch.zeros(Cout, dtype=torch.float32, device=gpu)
+    lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(),
+               B, H, W, Cin, Cout, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().numpy(), dw_ref) <= TOL_F32OUT[dt]
+    assert rel_l2(db.cpu().numpy(), db_ref) <= TOL_F32OUT[dt]
+    # the entry point ACCUMULATES: a second call doubles the result
+    lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(),
+               B, H, W, Cin, Cout, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().numpy(), 2 * dw_ref) <= TOL_F32OUT[dt]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_convT4s2_wgrad(gpu, dt, shape):
+    B, H, W, Cin, Cout = shape
+    H, W = H // 2, W // 2
+    rng = np.random.default_rng(6)
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    dz = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+    _, dw_ref, db_ref = O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dz)
+    xd, dzd = dev(x, dt, gpu), dev(dz, dt, gpu)
+    dw = torch.zeros(4, 4, Cout, Cin, dtype=torch.float32, device=gpu)
+    db = torch.zeros(Cout, dtype=torch.float32, device=gpu)
+    lib().call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(),
+               B, H, W, Cin, Cout, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(dw.cpu().numpy(), dw_ref) <= TOL_F32OUT[dt]
+    assert rel_l2(db.cpu().numpy(), db_ref) <= TOL_F32OUT[dt]
+
+
+def test_mfma_and_direct_paths_agree(gpu):
+    """the same bf16 problem through the MFMA path and the direct path (forced): independent kernels."""
+    B, H, W, Cin, Cout = 2, 8, 8, 128, 128
+    rng = np.random.default_rng(7)
+    x, w = dev(rng.standard_normal((B, H, W, Cin)), BF16, gpu), dev(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, BF16, gpu)
+    outs = []
+    for force in (0, 1):
+        lib().load().gct2_debug_force_direct(force)
+        y = torch.zeros(B, H // 2, W // 2, Cout, dtype=torch.bfloat16, device=gpu)
+        lib().call("gct2_conv4s2_fwd", BF16, x.data_ptr(), Cin, w.data_ptr(), None, y.data_ptr(), Cout, B, H, W, Cin, Cout, 0, stream())
+        torch.cuda.synchronize()
+        outs.append(y.double().cpu().numpy())
+    lib().load().gct2_debug_force_direct(0)
+    assert rel_l2(outs[0], outs[1]) <= 4e-3
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+def test_dense_fwd_bwd(gpu, dt):
+    M, Cin, Cout, ld, Cmask = 1000, 67, 3, 72, 64
+    rng = np.random.default_rng(8)
+    x = rnd(np.maximum(rng.standard_normal((M, Cin)), 0), dt)
+    w = rng.standard_normal((Cin, Cout)).astype(np.float32).astype(np.float64)
+    b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+    dy = rng.standard_normal((M, Cout)).astype(np.float32).astype(np.float64)
+    xb = torch.zeros(M, ld, dtype=TDT[dt], device=gpu)
+    xb[:, :Cin] = dev(x, dt, gpu)
+    wd, bd = torch.tensor(w, dtype=torch.float32, device=gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
+    y = torch.zeros(M, Cout, dtype=torch.float32, device=gpu)
+    lib().call("gct2_dense_fwd", dt, xb.data_ptr(), ld, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, Cin, Cout, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(y.cpu().numpy(), x @ w + b) <= 2e-6
+    dyd = torch.tensor(dy, dtype=torch.float32, device=gpu)
+    dxb = torch.full((M, ld), 5.0, dtype=TDT[dt], device=gpu)
+    dw = torch.zeros(Cin, Cout, dtype=torch.float32, device=gpu)
+    db = torch.zeros(Cout, dtype=torch.float32, device=gpu)
+    lib().call("gct2_dense_bwd", dt, xb.data_ptr(), ld, wd.data_ptr(), dyd.data_ptr(), dxb.data_ptr(), ld, dw.data_ptr(),
+               db.data_ptr(), M, Cin, Cout, Cmask, stream())
+    torch.cuda.synchronize()
+    dx_ref = (dy @ w.T) * (x > 0)
+    assert rel_l2(dxb[:, :Cmask].double().cpu().numpy(), dx_ref[:, :Cmask]) <= TOL_OUT[dt]
+    assert float((dxb[:, Cmask:].float() - 5).abs().max()) == 0       # image channels get no gradient
+    assert rel_l2(dw.cpu().numpy(), x.T @ dy) <= 2e-5
+    assert rel_l2(db.cpu().numpy(), dy.sum(0)) <= 2e-5
+
+
+def test_noise_mse(gpu):
+    B, HW, C, steps = 5, 64, 3, 200
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (B, HW, C)).astype(np.float32)
+    eps = rng.standard_normal((B, HW, C)).astype(np.float32)
+    t = rng.integers(1, steps + 1, B).astype(np.int32)
+    ref = O.noise_image(x.astype(np.float64).reshape(B, HW, 1, C), t, eps.astype(np.float64).reshape(B, HW, 1, C), steps).reshape(B * HW, C)
+    xd, ed, td = torch.tensor(x, device=gpu), torch.tensor(eps, device=gpu), torch.tensor(t, device=gpu)
+    out = torch.zeros(B * HW, 8, dtype=torch.float32, device=gpu)
+    lib().call("gct2_noise_image", F32, xd.data_ptr(), td.data_ptr(), ed.data_ptr(), out.data_ptr() + 4 * 2, 8, B, HW, C, steps, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(out[:, 2:5].cpu().numpy(), ref) <= 1e-6
+    # MSE + gradient
+    n = 100003
+    pred, tgt = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    pd_, tg = torch.tensor(pred, device=gpu), torch.tensor(tgt, device=gpu)
+    dp = torch.zeros(n, device=gpu); loss = torch.zeros(1, device=gpu); part = torch.zeros(1024, device=gpu)
+    lib().call("gct2_mse_fwd_bwd", pd_.data_ptr(), tg.data_ptr(), dp.data_ptr(), loss.data_ptr(), part.data_ptr(), n, None, stream())
+    torch.cuda.synchronize()
+    d = pred.astype(np.float64) - tgt
+    assert abs(float(loss[0]) - np.mean(d * d)) <= 1e-6 * np.mean(d * d)
+    assert rel_l2(dp.cpu().numpy(), 2 * d / n) <= 1e-6
+
+
+def test_rng_streams(gpu):
+    """distributional checks (TF's Philox stream cannot be reproduced, SURVEY.md §8c 'RNG')."""
+    n = 1 << 20
+    t = torch.zeros(n, dtype=torch.int32, device=gpu)
+    e = torch.zeros(n, dtype=torch.float32, device=gpu)
+    lib().call("gct2_rng_uniform_int", 123, 1, 0, t.data_ptr(), n, 1, 200, stream())
+    lib().call("gct2_rng_normal", 123, 2, 0, e.data_ptr(), n, stream())
+    torch.cuda.synchronize()
+    tn, en = t.cpu().numpy(), e.cpu().numpy().astype(np.float64)
+    assert tn.min() == 1 and tn.max() == 200
+    counts = np.bincount(tn, minlength=201)[1:]
+    assert abs(counts - n / 200).max() < 6 * np.sqrt(n / 200)
+    assert abs(en.mean()) < 5e-3 and abs(en.std() - 1) < 5e-3
+    assert abs(np.mean(en ** 3)) < 2e-2 and abs(np.mean(en ** 4) - 3) < 5e-2
+    # counter-based: drawing [0,n) in two calls with offsets equals one call
+    e2 = torch.zeros(n, dtype=torch.float32, device=gpu)
+    h = n // 2 + 3
+    lib().call("gct2_rng_normal", 123, 2, 0, e2.data_ptr(), h, stream())
+    lib().call("gct2_rng_normal", 123, 2, h, e2.data_ptr() + 4 * h, n - h, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(e, e2)
+
+
+@pytest.mark.parametrize("sdt", [F32, BF16, F16])
+def test_adam_keras(gpu, sdt):
+    cfg = O.OracleConfig()
+    n = 4099   # not a multiple of 4: exercises the tail
+    rng = np.random.default_rng(10)
+    p = rng.standard_normal(n).astype(np.float32); g = (rng.standard_normal(n) * 1e-4).astype(np.float32)
+    m = (rng.standard_normal(n) * 1e-4).astype(np.float32); v = (rng.random(n) * 1e-8).astype(np.float32)
+    k = 7
+    pr, mr, vr = O.keras_adam_step(p, g, m, v, k, cfg)
+    import math
+    alpha = O.warmup_lr(k, cfg.base_lr, cfg.warm_up) * math.sqrt(1 - cfg.beta_2 ** (k + 1)) / (1 - cfg.beta_1 ** (k + 1))
+    t = lambda a: torch.tensor(a, device=gpu)
+    pd_, md, vd, gd = t(p), t(m), t(v), t(g)
+    sh = torch.zeros(n, dtype=TDT[sdt], device=gpu)
+    lib().call("gct2_adam_keras_multi", pd_.data_ptr(), md.data_ptr(), vd.data_ptr(), gd.data_ptr(), sh.data_ptr(), sdt, n,
+               alpha, cfg.beta_1, cfg.beta_2, cfg.epsilon, None, None, 1, stream())
+    torch.cuda.synchronize()
+    assert rel_l2(pd_.cpu().numpy(), pr) <= 1e-6 and rel_l2(md.cpu().numpy(), mr) <= 1e-6 and rel_l2(vd.cpu().numpy(), vr) <= 1e-6
+    assert float(gd.abs().max()) == 0                       # zero_grad
+    assert torch.equal(sh, pd_.to(TDT[sdt]))                # shadow = rounded copy of the new p
+    # Keras epsilon placement: differs measurably from sqrt(v_hat)+eps
+    upd = (p - pd_.cpu().numpy())
+    torch_style = alpha * 0 + O.warmup_lr(k, cfg.base_lr, cfg.warm_up) * (mr / (1 - cfg.beta_1 ** (k + 1))) / (np.sqrt(vr / (1 - cfg.beta_2 ** (k + 1))) + cfg.epsilon)
+    assert rel_l2(upd, torch_style) > 1e-3
+
+
+def test_loss_scale_state_machine(gpu):
+    st = torch.zeros(4, dtype=torch.int32, device=gpu)
+    L = lib()
+    L.call("gct2_loss_scale_init", st.data_ptr(), 2.0 ** 15, stream())
+    ref = O.LossScaleState(growth_interval=3)
+    g_ok = torch.ones(1000, device=gpu)
+    g_bad = g_ok.clone(); g_bad[777] = float("inf")
+    g_nan = g_ok.clone(); g_nan[3] = float("nan")
+    p = torch.zeros(1000, device=gpu); m = torch.zeros(1000, device=gpu); v = torch.zeros(1000, device=gpu)
+    for step, g in enumerate([g_ok, g_ok, g_bad, g_ok, g_ok, g_ok, g_nan, g_ok]):
+        gg = g.clone()
+        L.call("gct2_loss_scale_begin", st.data_ptr(), stream())
+        L.call("gct2_scale_check_finite", gg.data_ptr(), gg.numel(), st.data_ptr(), stream())
+        p_before = p.clone()
+        L.call("gct2_adam_keras_multi", p.data_ptr(), m.data_ptr(), v.data_ptr(), gg.data_ptr(), None, 0, 1000, 1e-3, 0.9, 0.999,
+               1e-7, st.data_ptr() + 4, st.data_ptr() + 12, 1, stream())
+        L.call("gct2_loss_scale_update", st.data_ptr(), 3, stream())
+        torch.cuda.synchronize()
+        finite = bool(torch.isfinite(g).all())
+        applied = ref.update(finite)
+        raw = st.cpu()
+        assert float(raw[:1].view(torch.float32)[0]) == ref.scale and int(raw[2]) == ref.good_steps
+        assert bool((p != p_before).any()) == applied          # update skipped on inf/nan
+        assert bool(torch.isfinite(p).all())

@@ -1,0 +1,194 @@
+"""Full train-step parity of the HIP path (through the C ABI) against the CPU oracle and the golden fixture.
+
+Stated tolerances:
+  fp32 mode   : loss 1e-5 rel; prediction / every gradient / post-Adam weights rel-L2 <= 2e-5 vs the fp64 oracle.
+  bf16 mode   : vs the oracle with the SAME operand rounding model (weights, stored activations and stored activation
+                gradients rounded to bf16): loss 2e-3 rel, prediction rel-L2 <= 1e-2, gradients rel-L2 <= 3e-2;
+                vs the plain fp32 CPU oracle (BASELINE config 2): loss within 1e-3 rel (north_star's bound).
+PARITY UNPINNED w.r.t. TensorFlow (no fixtures in the reference; oracle header).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_step.npz")
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def make_engine(cfg, dtype, gpu, **kw):
+    import gan_class_transfer2_amd as g
+    topo = g.Topology(cfg.pixel_size, cfg.max_size, cfg.octaves)
+    return g.UNetEngine(topo, dtype, gpu, steps=cfg.steps, base_lr=cfg.base_lr, warm_up=cfg.warm_up, **kw)
+
+
+def test_golden_tiny_step_fp32(gpu):
+    z = np.load(GOLDEN)
+    cfg = O.OracleConfig(size=16, pixel_size=8, max_size=16, octaves=2, batch_size=2)
+    eng = make_engine(cfg, 0, gpu)
+    names = list(eng.arena.shapes)
+    eng.set_params({k: z["param/" + k] for k in names})
+    x = torch.tensor(z["x"], dtype=torch.float32, device=gpu)
+    loss = eng.train_step(x, torch.tensor(z["t_int"]), torch.tensor(z["eps"], dtype=torch.float32), apply=False)
+    torch.cuda.synchronize()
+    b = eng.buffers(2, 16, 16)
+    assert abs(float(loss[0]) - float(z["loss"])) <= 1e-5 * float(z["loss"])
+    assert rel_l2(b.pred.cpu().numpy(), z["pred"]) <= 2e-5
+    fu0 = eng.topo.fu(0)
+    assert rel_l2(b.R[0][..., fu0:fu0 + 3].cpu().numpy(), z["noised"]) <= 1e-6
+    grads = eng.get_grads()
+    for k in names:
+        assert rel_l2(grads[k], z["grad/" + k]) <= 2e-5, k
+    # two optimizer steps from the same start (fresh batches per step, like fit)
+    eng.arena.g.zero_()
+    eng.set_params({k: z["param/" + k] for k in names})
+    losses = []
+    for step in range(2):
+        xs, ts, es = O.synthetic_batch(cfg, seed=step)
+        losses.append(eng.train_step(torch.tensor(xs, dtype=torch.float32, device=gpu), torch.tensor(ts),
+                                     torch.tensor(es, dtype=torch.float32)).clone())
+    torch.cuda.synchronize()
+    assert eng.iterations == 2
+    assert np.allclose([float(l[0]) for l in losses], z["losses2"], rtol=1e-5)
+    for k in names:
+        assert rel_l2(eng.arena.param(k).cpu().numpy(), z["param2/" + k]) <= 1e-6, k
+        # the UPDATE itself (p2 - p0), not just p2 which is dominated by p0
+        upd, upd_ref = eng.arena.param(k).cpu().numpy().astype(np.float64) - z["param/" + k], z["param2/" + k] - z["param/" + k]
+        assert rel_l2(upd, upd_ref) <= 2e-3, k
+        assert rel_l2(eng.arena.slot_m(k).cpu().numpy(), z["m2/" + k]) <= 5e-5, k
+        assert rel_l2(eng.arena.slot_v(k).cpu().numpy(), z["v2/" + k]) <= 5e-5, k
+
+
+@pytest.mark.parametrize("dtype,rounding", [(1, "bf16"), (2, "f16")])
+def test_medium_step_lowp_vs_rounded_oracle(gpu, dtype, rounding):
+    """MFMA-eligible channel counts (64..128) on a small grid: exercises tapgemm + wgrad MFMA inside the plan."""
+    cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
+    params = O.init_params(cfg, seed=5)
+    x, t_int, eps = O.synthetic_batch(cfg, seed=3)
+    loss_ref, pred_ref, grads_ref, _ = O.trainer_step(params, x, t_int, eps, cfg, operand_round=rounding)
+    eng = make_engine(cfg, dtype, gpu)
+    eng.set_params(params)
+    loss = eng.train_step(torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int),
+                          torch.tensor(eps, dtype=torch.float32), apply=False)
+    torch.cuda.synchronize()
+    b = eng.buffers(4, 32, 32)
+    tol = {"bf16": (2e-3, 1e-2, 3e-2), "f16": (3e-4, 2e-3, 5e-3)}[rounding]
+    assert abs(float(loss[0]) - loss_ref) <= tol[0] * loss_ref
+    assert rel_l2(b.pred.cpu().numpy(), pred_ref) <= tol[1]
+    grads = eng.get_grads()
+    for k in grads:
+        assert rel_l2(grads[k], grads_ref[k]) <= tol[2], k
+
+
+def test_config2_bf16_vs_fp32_cpu_oracle(gpu):
+    """BASELINE.json config 2: 3x64x64, bs 32, octaves 6, bf16 step vs the fp32 CPU oracle: loss within 1e-3 rel."""
+    from oracle import torch_cross as T
+    cfg = O.OracleConfig(size=64, batch_size=32, octaves=6)
+    params = O.init_params(cfg, seed=1234, dtype=np.float32)
+    x, t_int, eps = O.synthetic_batch(cfg, seed=0, dtype=np.float32)
+    loss_ref, pred_ref, grads_ref = T.trainer_step(params, x, t_int, eps, cfg, dtype=torch.float32)
+    eng = make_engine(cfg, 1, gpu)
+    eng.set_params(params)
+    loss = eng.train_step(torch.tensor(x, device=gpu), torch.tensor(t_int), torch.tensor(eps), apply=False)
+    torch.cuda.synchronize()
+    assert abs(float(loss[0]) - loss_ref) <= 1e-3 * loss_ref
+    b = eng.buffers(32, 64, 64)
+    assert rel_l2(b.pred.cpu().numpy(), pred_ref) <= 1e-2
+    # gradients: bf16 storage of activations / activation gradients through 12 layers whose gradient norms decay
+    # ~10x per level (|g| 4e-1 at the head, 4e-7 at the bottleneck) leaves 0.5 % (U0) .. 16 % (D5) relative error
+    # per tensor against UNROUNDED fp32 (measured; the fp32 HIP mode itself differs from torch-CPU fp32 by 1e-3
+    # there).  Bound the whole gradient vector tightly and every tensor loosely; the tight per-tensor check is
+    # test_medium_step_lowp_vs_rounded_oracle (same rounding model on both sides).
+    grads = eng.get_grads()
+    names = sorted(grads)
+    flat = np.concatenate([grads[k].ravel() for k in names]); flat_ref = np.concatenate([grads_ref[k].ravel() for k in names])
+    assert rel_l2(flat, flat_ref) <= 1e-2
+    worst = max(rel_l2(grads[k], grads_ref[k]) for k in grads)
+    assert worst <= 0.25, worst
+
+
+def test_denoiser_eager_layers_match_planned_engine(gpu):
+    """the reference's literal nested evaluation (self.middle(x), train.py:210) == the zero-copy plan."""
+    import gan_class_transfer2_amd as g
+    g.configure(size=32, pixel_size=16, max_size=32, octaves=3, compute_dtype="float32")
+    try:
+        den = g.Denoiser(seed=3)
+        x = torch.randn(2, 32, 32, 3, device=gpu)
+        t = torch.ones(2, 1, 1, 1, dtype=torch.int32, device=gpu)
+        planned = den((x, t))
+        eager = den.call_eager((x, t))
+        torch.cuda.synchronize()
+        assert planned.shape == (2, 32, 32, 3) and eager.shape == planned.shape
+        assert rel_l2(planned.cpu().numpy(), eager.cpu().numpy()) <= 1e-6
+        with pytest.raises(ValueError):
+            den((torch.randn(1, 20, 20, 3, device=gpu), t))      # 20 % 2**3 != 0  (train.py:114-119 would fail too)
+    finally:
+        g.configure(size=256, pixel_size=128, max_size=512, octaves=6, compute_dtype=None)
+
+
+def test_trainer_compile_fit_api(gpu):
+    """train.py:511-523 driver surface: compile(optimizer, identity) + fit(dataset, steps_per_epoch, epochs, callbacks)."""
+    import gan_class_transfer2_amd as g
+    from gan_class_transfer2_amd import model as M
+    g.configure(size=16, pixel_size=8, max_size=16, octaves=2, compute_dtype="float32")
+    try:
+        den = g.Denoiser()
+        tr = g.Trainer(den)
+        opt = g.Adam(g.WarmUp(2e-5, M.warm_up))
+
+        def dataset():
+            gen = torch.Generator().manual_seed(0)
+            while True:
+                img = (torch.randint(0, 256, (4, 16, 16, 3), generator=gen).float() / 128 - 1).to(gpu)
+                yield img, img
+
+        ex = next(dataset())[0]
+        l0 = g.identity(ex, tr(ex))                                  # train.py:505-509 warm-up call
+        assert l0.ndim == 0 and float(l0) > 0
+        tr.compile(opt, g.identity)
+        seen = []
+        hist = tr.fit(dataset(), steps_per_epoch=3, epochs=2, verbose=0,
+                      callbacks=[g.LambdaCallback(on_epoch_begin=lambda e, logs: seen.append(e))])
+        assert seen == [0, 1] and len(hist["loss"]) == 2 and den.engine.iterations == 6 and opt.iterations == 6
+        assert abs(opt.lr(5) - 2e-5 * 6 / 2001) < 1e-12
+    finally:
+        g.configure(size=256, pixel_size=128, max_size=512, octaves=6, compute_dtype=None)
+
+
+def test_fp16_loss_scaling_step(gpu):
+    """mixed_precision=True path (train.py:34,43-45,82-83): fp16 operands, dynamic loss scale, finite grads applied."""
+    cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
+    params = O.init_params(cfg, seed=5)
+    x, t_int, eps = O.synthetic_batch(cfg, seed=3)
+    _, _, grads_ref, _ = O.trainer_step(params, x, t_int, eps, cfg, operand_round="f16")
+    eng = make_engine(cfg, 2, gpu, loss_scaling=True)
+    eng.set_params(params)
+    p0 = eng.get_params()
+    eng.train_step(torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32), apply=False)
+    torch.cuda.synchronize()
+    grads = eng.get_grads()
+    scale, _ = eng.loss_scale()
+    assert scale == 2.0 ** 15
+    for k in grads:                                             # gradients are the scaled ones
+        assert rel_l2(grads[k] / scale, grads_ref[k]) <= 1e-2, k
+    eng.check_finite(); eng.apply_adam(); eng.finish_step()
+    torch.cuda.synchronize()
+    p1 = eng.get_params()
+    assert eng.loss_scale() == (2.0 ** 15, 1)
+    assert any(np.abs(p1[k] - p0[k]).max() > 0 for k in p0)
+    # poison one gradient: the step must be skipped and the scale halved
+    eng.train_step(torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32), apply=False)
+    eng.arena.g[5] = float("inf")
+    eng.check_finite(); eng.apply_adam(); eng.finish_step()
+    torch.cuda.synchronize()
+    p2 = eng.get_params()
+    assert all(np.array_equal(p2[k], p1[k]) for k in p1)
+    assert eng.loss_scale() == (2.0 ** 14, 0)
