@@ -1,0 +1,129 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/gct2.h declares (no compute calls), argument
+validation returns errors without a GPU, and the host-side logic (topology, arena layout, schedules, config API)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "gct2.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gct2_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    import gan_class_transfer2_amd as g
+    lib = ctypes.CDLL(g._lib.LIB_PATH)
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gct2.h but not exported"
+    # and the ctypes table binds exactly the declared entry points (minus last_error, bound separately)
+    assert sorted(set(g._lib.SIGNATURES) | {"gct2_last_error"}) == names
+    assert g._lib.load().gct2_abi_version() == 1
+
+
+def test_argument_validation_needs_no_gpu():
+    import gan_class_transfer2_amd as g
+    L = g._lib.load()
+    # odd height: the reference's concat would fail (train.py:114-119); nothing is launched
+    rc = L.gct2_conv4s2_fwd(0, 16, 8, 16, None, 16, 8, 1, 5, 4, 8, 8, 1, None)
+    assert rc == 1 and b"even" in L.gct2_last_error()
+    assert L.gct2_conv4s2_fwd(7, 16, 8, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1      # bad dtype
+    assert L.gct2_conv4s2_fwd(0, None, 8, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1    # null pointer
+    assert L.gct2_convT4s2_fwd(0, 16, 4, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1     # ld < channels
+    assert L.gct2_dense_fwd(0, 16, 67, 16, None, 16, 10, 67, 5, None) == 1                 # Cout > 4
+    with pytest.raises(g.Gct2Error):
+        g._lib.call("gct2_adam_keras_multi", 4, 16, 16, 16, None, 0, 8, 1e-3, 0.9, 0.999, 1e-7, None, None, 0, None)  # misaligned
+
+
+def test_product_path_fails_loudly_without_device_or_library(monkeypatch):
+    import gan_class_transfer2_amd as g
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            g.UNetEngine(g.Topology(8, 16, 2), g.F32, torch.device("cpu"))
+    monkeypatch.setattr(g._lib, "_lib", None)
+    monkeypatch.setattr(g._lib, "LIB_PATH", "/nonexistent/libgct2.so")
+    with pytest.raises(g.Gct2Error):
+        g._lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gan-class-transfer2_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_topology_matches_reference_channel_rule():
+    import gan_class_transfer2_amd as g
+    t = g.Topology(128, 512, 6)
+    s = t.param_shapes()
+    assert s["D0.w"] == (4, 4, 3, 128) and s["D5.w"] == (4, 4, 512, 512)
+    assert s["U0.w"] == (4, 4, 64, 256) and s["U4.w"] == (4, 4, 512, 1024) and s["U5.w"] == (4, 4, 512, 512)
+    assert s["dense.w"] == (67, 3)
+    assert sum(int(np.prod(v)) for v in s.values()) == 41_691_660
+    assert t.layer_order() == ["dense", "U0", "U1", "U2", "U3", "U4", "U5", "D5", "D4", "D3", "D2", "D1", "D0"]
+
+
+def test_arena_layout_is_aligned_and_bucketable():
+    from gan_class_transfer2_amd.engine import ParamArena
+    import gan_class_transfer2_amd as g
+    A = ParamArena(g.Topology(128, 512, 6), g.BF16, torch.device("cpu"))
+    prev_hi = 0
+    for layer in A.topo.layer_order():
+        lo, hi = A.layer_ranges[layer]
+        assert lo == prev_hi and lo % 64 == 0          # contiguous, in backward order, 16-byte aligned in bf16
+        prev_hi = hi
+    assert prev_hi == A.total and A.total >= 41_691_660
+    A.glorot_init(1)
+    w = A.param("U3.w")
+    lim = np.sqrt(6.0 / (16 * 512 + 16 * 1024))
+    assert float(w.abs().max()) <= lim and float(w.abs().max()) > 0.99 * lim and float(A.param("U3.b").abs().max()) == 0
+    A.grad("D1.w").fill_(1.0)
+    lo, hi = A.layer_ranges["D1"]
+    assert float(A.g[lo:hi].sum()) == 4 * 4 * 128 * 256 and float(A.g.sum()) == 4 * 4 * 128 * 256
+
+
+def test_reference_config_surface_and_schedules():
+    from gan_class_transfer2_amd import model as M
+    # defaults of train.py:17-36
+    assert (M.size, M.pixel_size, M.max_size, M.block_depth, M.octaves, M.batch_size, M.steps) == (256, 128, 512, 0, 6, 1, 200)
+    assert (M.residual, M.concat, M.predict_x, M.mixed_precision, M.warm_up) == (False, True, True, False, 2000)
+    w = M.WarmUp(2e-5, 2000)
+    assert abs(w(0) - 2e-5 / 2001) < 1e-12 and abs(w(1999) - 2e-5 * 2000 / 2001) < 1e-11 and abs(w(2000) - 2e-5) < 1e-12
+    assert abs(float(M.alpha_dash(torch.tensor(25.0))) - 0.25 * (1 - 25 / 201) ** 2) < 1e-7
+    assert float(M.identity(None, torch.tensor([1.0, 3.0]))) == 2.0
+    assert M.preferred_dtype_code() == 0
+    M.configure(mixed_precision=True)
+    try:
+        assert M.preferred_dtype_code() == 2 and isinstance(M.default_optimizer(), M.LossScaleOptimizer)
+    finally:
+        M.configure(mixed_precision=False)
+    with pytest.raises(AttributeError):
+        M.configure(no_such_knob=1)
+    M.configure(block_depth=1)
+    try:
+        with pytest.raises(NotImplementedError):
+            M.Block(8)
+    finally:
+        M.configure(block_depth=0)
+
+
+def test_bench_flop_model_matches_survey_appendix_b():
+    import bench
+    import gan_class_transfer2_amd as g
+    t = g.Topology(128, 512, 6)
+    assert abs(bench.f_train_per_image(t, 128, 128) / 1e9 - 32.1314) < 1e-3
+    assert abs(bench.f_train_per_image(t, 64, 64) / 1e9 - 8.0328) < 1e-3
+    assert abs(bench.f_train_per_image(g.Topology(128, 512, 5), 32, 32) / 1e9 - 1.9705) < 1e-3

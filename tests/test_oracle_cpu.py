@@ -1,0 +1,133 @@
+"""CPU tier: pins the oracle itself (it is the parity anchor for every GPU test).
+
+The reference holds no golden vectors, so the oracle is pinned by
+  (1) definition-level pure-Python loops of SURVEY.md A.2/A.3 at tiny shapes,
+  (2) an independent torch.nn.functional + autograd derivation of the whole step,
+  (3) analytic identities (convT is the vjp of conv; linearity),
+  (4) the committed golden fixture (regression of the restatement itself).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser_oracle as O
+from oracle import torch_cross as T
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_step.npz")
+
+
+def test_vectorised_matches_definition_loops():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 4, 6, 3)); b = rng.standard_normal(5)
+    w = rng.standard_normal((4, 4, 3, 5))
+    assert np.abs(O.naive_conv4s2_fwd(x, w, b) - O.conv4s2_fwd(x, w, b)).max() < 1e-12
+    wt = rng.standard_normal((4, 4, 5, 3))
+    assert np.abs(O.naive_convT4s2_fwd(x, wt, b) - O.convT4s2_fwd(x, wt, b)).max() < 1e-12
+
+
+def test_convT_is_vjp_of_conv_and_interior_tap_count():
+    """A.3: Conv2DTranspose == gradient of Conv2D w.r.t. its input, no spatial flip; interior pixels get 2x2 taps."""
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1, 6, 6, 4)); w = rng.standard_normal((4, 4, 4, 7)); dz = rng.standard_normal((1, 3, 3, 7))
+    dx, _, _ = O.conv4s2_bwd(x, w, dz)
+    assert np.abs(dx - O.convT4s2_fwd(dz, w, np.zeros(4))).max() < 1e-12
+    ones = O.convT4s2_fwd(np.ones((1, 3, 3, 1)), np.ones((4, 4, 1, 1)), np.zeros(1))[0, :, :, 0]
+    assert ones[2, 2] == 4 and ones[0, 0] == 1 and ones[0, 2] == 2 and ones.shape == (6, 6)
+
+
+def test_same_padding_rule_even_input():
+    """A.2: 'same' with k=4, s=2, even input -> pad 1/1, out = in/2; the first tap row reads x[-1] = 0."""
+    x = np.zeros((1, 4, 4, 1)); x[0, 0, 0, 0] = 1.0
+    w = np.zeros((4, 4, 1, 1)); w[1, 1, 0, 0] = 1.0          # tap (kh,kw)=(1,1) reads x[2oh, 2ow]
+    z = O.conv4s2_fwd(x, w, np.zeros(1))
+    assert z.shape == (1, 2, 2, 1) and z[0, 0, 0, 0] == 1.0 and z.sum() == 1.0
+
+
+@pytest.mark.parametrize("cfgkw", [dict(size=16, pixel_size=8, max_size=16, octaves=2, batch_size=2),
+                                   dict(size=16, pixel_size=4, max_size=8, octaves=3, batch_size=1)])
+def test_full_step_numpy_vs_torch_autograd(cfgkw):
+    cfg = O.OracleConfig(**cfgkw)
+    params = O.init_params(cfg, seed=7)
+    for k in params:
+        if k.endswith(".b"):
+            params[k] = np.random.default_rng(3).standard_normal(params[k].shape) * 0.1
+    x, t_int, eps = O.synthetic_batch(cfg, seed=2)
+    l1, p1, g1, _ = O.trainer_step(params, x, t_int, eps, cfg)
+    l2, p2, g2 = T.trainer_step(params, x, t_int, eps, cfg)
+    assert abs(l1 - l2) < 1e-12 and np.abs(p1 - p2).max() < 1e-12
+    for k in g1:
+        assert np.abs(g1[k] - g2[k]).max() <= 1e-12 * max(1.0, np.abs(g2[k]).max()), k
+
+
+def test_golden_fixture_regression():
+    z = np.load(GOLDEN)
+    cfg = O.OracleConfig(size=16, pixel_size=8, max_size=16, octaves=2, batch_size=2)
+    params = {k[6:]: z[k] for k in z.files if k.startswith("param/")}
+    loss, pred, grads, noised = O.trainer_step(params, z["x"], z["t_int"], z["eps"], cfg)
+    assert abs(loss - float(z["loss"])) < 1e-13 and np.abs(pred - z["pred"]).max() < 1e-12
+    for k in grads:
+        assert np.abs(grads[k] - z["grad/" + k]).max() < 1e-12
+
+
+def test_topology_channel_rule_and_parameter_count():
+    """41,691,660 parameters at the reference defaults, 29,107,724 at octaves 5."""
+    cfg = O.OracleConfig(size=128)
+    assert [cfg.down_filters(i) for i in range(6)] == [128, 256, 512, 512, 512, 512]
+    assert [cfg.up_filters(i) for i in range(6)] == [64, 128, 256, 512, 512, 512]
+    assert [cfg.up_in_channels(i) for i in range(6)] == [256, 512, 1024, 1024, 1024, 512]
+    assert sum(int(np.prod(s)) for s in O.param_shapes(cfg).values()) == 41_691_660
+    assert sum(int(np.prod(s)) for s in O.param_shapes(O.OracleConfig(size=32, octaves=5)).values()) == 29_107_724
+    with pytest.raises(ValueError):
+        O.OracleConfig(size=32, octaves=6).check_legal()       # App. B: size % 2**octaves != 0
+
+
+def test_alpha_dash_and_warmup():
+    assert abs(float(O.alpha_dash(0)) - 0.25) < 1e-15                       # train.py:93
+    assert abs(float(O.alpha_dash(200)) - 0.25 * (1 - 200 / 201) ** 2) < 1e-18
+    assert abs(O.warmup_lr(0) - 2e-5 / 2001) < 1e-12                        # train.py:61-63
+    assert abs(O.warmup_lr(1999) - 2e-5 * 2000 / 2001) < 1e-11
+    assert abs(O.warmup_lr(2000) - 2e-5) < 1e-12 and abs(O.warmup_lr(10 ** 6) - 2e-5) < 1e-12
+
+
+def test_keras_adam_definition_and_epsilon_placement():
+    """A.6: eps is added to sqrt(v) (not sqrt(v_hat)); differs from torch.optim.Adam even with eps=1e-7."""
+    cfg = O.OracleConfig()
+    g = np.full(4, 1e-5, dtype=np.float32); p = np.zeros(4, dtype=np.float32)     # p = 0: the update is not absorbed
+    p1, m1, v1 = O.keras_adam_step(p, g, np.zeros(4, np.float32), np.zeros(4, np.float32), 0, cfg)
+    lr = 2e-5 / 2001
+    m, v = 0.1 * 1e-5, 0.001 * 1e-10
+    expect = -lr * np.sqrt(1 - 0.999) / (1 - 0.9) * m / (np.sqrt(v) + 1e-7)
+    assert np.allclose(p1, expect, rtol=1e-5, atol=0) and np.allclose(m1, m) and np.allclose(v1, v)
+    tp = torch.zeros(4, requires_grad=True); opt = torch.optim.Adam([tp], lr=lr, eps=1e-7)
+    tp.grad = torch.full((4,), 1e-5); opt.step()
+    upd_keras, upd_torch = -float(p1[0]), -float(tp[0])
+    assert abs(upd_keras - upd_torch) / upd_torch > 0.2
+
+
+def test_loss_scale_state_machine():
+    s = O.LossScaleState(growth_interval=3)
+    assert [s.update(True), s.update(True)] == [True, True] and s.scale == 2.0 ** 15
+    assert s.update(True) and s.scale == 2.0 ** 16 and s.good_steps == 0
+    assert not s.update(False) and s.scale == 2.0 ** 15 and s.good_steps == 0
+
+
+def test_operand_rounding_model_bf16():
+    a = np.array([1.0, 1.00390625, 1.005859375, -3.14159, 1e-40], dtype=np.float64)
+    r = O.round_bf16(a)
+    ref = torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    assert np.array_equal(r, ref)
+    cfg = O.OracleConfig(size=16, pixel_size=8, max_size=16, octaves=2, batch_size=2)
+    params = O.init_params(cfg, 1); x, t, e = O.synthetic_batch(cfg, 1)
+    l0 = O.trainer_step(params, x, t, e, cfg)[0]
+    l1 = O.trainer_step(params, x, t, e, cfg, operand_round="bf16")[0]
+    assert 0 < abs(l0 - l1) / l0 < 2e-2
+
+
+def test_oracle_trainer_two_steps_decrease_nothing_weird():
+    cfg = O.OracleConfig(size=16, pixel_size=8, max_size=16, octaves=2, batch_size=2)
+    tr = O.OracleTrainer(cfg, O.init_params(cfg, 3))
+    x, t, e = O.synthetic_batch(cfg, 4)
+    l0 = tr.train_step(x, t, e)[0]; l1 = tr.train_step(x, t, e)[0]
+    assert tr.iterations == 2 and np.isfinite(l0) and np.isfinite(l1) and l1 < l0     # same batch twice: loss must drop
