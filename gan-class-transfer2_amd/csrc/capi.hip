@@ -11,6 +11,10 @@ int tapgemm_direct(int dtype, int form, int epi, const TapGemmParams& p, hipStre
 bool wgrad_mfma_supported(int dtype, const WgradParams& p);
 int wgrad_mfma(int dtype, WgradParams p, hipStream_t s);
 int wgrad_direct(int dtype, const WgradParams& p, hipStream_t s);
+bool rgb_fwd_supported(int dtype, const TapGemmParams& p);
+int rgb_fwd(int dtype, const TapGemmParams& p, hipStream_t s);
+bool rgb_wgrad_supported(int dtype, const WgradParams& p);
+int rgb_wgrad(int dtype, const WgradParams& p, hipStream_t s);
 int pw_rng_uniform_int(uint64_t, uint64_t, uint64_t, int32_t*, size_t, int, int, hipStream_t);
 int pw_rng_normal(uint64_t, uint64_t, uint64_t, float*, size_t, hipStream_t);
 int pw_noise(int, const float*, const int32_t*, const float*, void*, int, int, int, int, int, hipStream_t);
@@ -27,6 +31,13 @@ int pw_ls_update(gct2_loss_scale_state*, int, hipStream_t);
 
 static thread_local char g_err[512] = "";
 static int g_force_direct = 0;   // test hook: route every conv through the direct kernels
+static float* g_ws = nullptr;    // caller-owned split-K scratch (gct2_set_workspace)
+static size_t g_ws_bytes = 0;
+
+float* gct2_workspace(size_t* bytes) {
+  *bytes = g_ws_bytes;
+  return g_ws;
+}
 
 int gct2_fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -69,6 +80,13 @@ int gct2_abi_version(void) { return 1; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
 
+int gct2_set_workspace(void* ws, size_t bytes) {
+  if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "set_workspace: pointer must be 16-byte aligned");
+  g_ws = ws ? reinterpret_cast<float*>(ws) : nullptr;
+  g_ws_bytes = ws ? bytes : 0;
+  return GCT2_OK;
+}
+
 int gct2_device_check(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return gct2_fail(GCT2_ENODEV, "no HIP device");
@@ -84,6 +102,7 @@ int gct2_conv4s2_fwd(int dtype, const void* x, int ldx, const void* w, const flo
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: H=%d W=%d must be even (skip concat, train.py:114-119)", H, W);
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: ld smaller than channel count");
   TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H / 2, W / 2, Cin, Cout, relu, 0};
+  if (!g_force_direct && rgb_fwd_supported(dtype, p)) return rgb_fwd(dtype, p, S(stream));   // image layer (Cin <= 4)
   return run_tapgemm(dtype, FORM_CONV, EPI_BIAS_ACT, p, stream);
 }
 
@@ -102,7 +121,9 @@ int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int ld
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: H=%d W=%d must be even", H, W);
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: ld smaller than channel count");
   WgradParams p{x, ldx, dz, lddz, dw, B, H / 2, W / 2, Cin, Cout, 1};
-  if (int e = run_wgrad(dtype, p, stream)) return e;
+  if (!g_force_direct && rgb_wgrad_supported(dtype, p)) {
+    if (int e = rgb_wgrad(dtype, p, S(stream))) return e;
+  } else if (int e = run_wgrad(dtype, p, stream)) return e;
   if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, S(stream));
   return GCT2_OK;
 }

@@ -105,7 +105,11 @@ struct TapGemmParams {
   int B, Hs, Ws;                 // SMALL grid
   int K, N;                      // reduction channels per tap, output channels
   int relu, accumulate;
+  float* ws; int ksplit;         // split-K: fp32 partial slabs [ksplit][out pixels][N] in the registered workspace
 };
+
+// caller-registered scratch (gct2_set_workspace); null when absent
+float* gct2_workspace(size_t* bytes);
 
 // wgrad: dw[tap][cb][cs] += sum_r big[pix_big(r,tap)][cb] * small[r][cs], r over the SMALL grid.
 struct WgradParams {

@@ -191,6 +191,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dz, i
   __syncthreads();
   if (rl == 0 && c < C) atomicAdd(db + c, ws[threadIdx.x] + ws[threadIdx.x + 64] + ws[threadIdx.x + 128] + ws[threadIdx.x + 192]);
 }
+// 16-bit types, 16-byte loads: thread = (8-channel chunk of a 64-wide tile, one of 32 row lanes)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ dz, int ld, float* __restrict__ db, size_t M, int C,
+                                                         int rows_per_block) {
+  const int c8 = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 64 + c8 * 8;
+  const size_t r0 = (size_t)blockIdx.y * rows_per_block;
+  const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    for (size_t r = r0 + rl; r < r1; r += 32) {
+      const u32x4_t v = gload128(dz + r * ld + c);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { acc[2 * k] += unpack_lo<T>(v[k]); acc[2 * k + 1] += unpack_hi<T>(v[k]); }
+    }
+  }
+  __shared__ float ws[32][65];
+#pragma unroll
+  for (int k = 0; k < 8; k++) ws[rl][c8 * 8 + k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; r++) s += ws[r][threadIdx.x];
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < C) atomicAdd(db + cc, s);
+  }
+}
+
 // ---- Keras Adam over a flat arena ------------------------------------------------------------------------
 template <typename S, bool HAS_SHADOW>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
@@ -343,6 +372,13 @@ static int colsum_t(const void* dz, int ld, float* db, size_t M, int C, hipStrea
   if (rblocks > cap) rblocks = cap;
   if (rblocks < 1) rblocks = 1;
   const int rows_per_block = (int)((M + rblocks - 1) / rblocks);
+  if constexpr (sizeof(T) == 2) {
+    if (C % 8 == 0 && ld % 8 == 0 && (uintptr_t)dz % 16 == 0) {
+      hipLaunchKernelGGL(colsum_vec_kernel<T>, dim3(ctiles, rblocks), dim3(256), 0, s, reinterpret_cast<const T*>(dz), ld, db, M, C,
+                         rows_per_block);
+      return gct2_check_launch("colsum_vec");
+    }
+  }
   hipLaunchKernelGGL(colsum_kernel<T>, dim3(ctiles, rblocks), dim3(256), 0, s, reinterpret_cast<const T*>(dz), ld, db, M, C, rows_per_block);
   return gct2_check_launch("colsum");
 }

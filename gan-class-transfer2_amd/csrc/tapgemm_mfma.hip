@@ -15,6 +15,7 @@
 // MFMA orientation: A operand = weights (rows = n), B operand = activations (cols = m), so every lane ends
 // with 4 consecutive output channels of one pixel -> 8-byte NHWC stores.
 #include "gct2_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -41,8 +42,9 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmParams p) {
   const int Hs = p.Hs, Ws = p.Ws, K = p.K, N = p.N;
   const int M = p.B * Hs * Ws;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int ph = (FORM == FORM_CONVT) ? (int)(blockIdx.z >> 1) : 0;
+  const int ph = (FORM == FORM_CONVT) ? (int)((blockIdx.z & 3) >> 1) : 0;
   const int pw = (FORM == FORM_CONVT) ? (int)(blockIdx.z & 1) : 0;
+  const int kslice = (FORM == FORM_CONVT) ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
   const int Hsrc = (FORM == FORM_CONV) ? 2 * Hs : Hs, Wsrc = (FORM == FORM_CONV) ? 2 * Ws : Ws;
   const T* __restrict__ xsrc = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ wsrc = reinterpret_cast<const T*>(p.w);
@@ -123,12 +125,17 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  gload(0);
-  sstore(0);
+  // split-K: this workgroup reduces iterations [it_lo, it_hi) only and leaves an fp32 partial slab
+  const int it_per = (niter + p.ksplit - 1) / p.ksplit;
+  const int it_lo = kslice * it_per, it_hi = min(niter, it_lo + it_per);
+  if (it_lo < it_hi) {
+    gload(it_lo);
+    sstore(0);
+  }
   __syncthreads();
-  for (int it = 0; it < niter; it++) {
-    const int buf = it & 1;
-    if (it + 1 < niter) gload(it + 1);
+  for (int it = it_lo; it < it_hi; it++) {
+    const int buf = (it - it_lo) & 1;
+    if (it + 1 < it_hi) gload(it + 1);
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
       u32x4_t wf[4], af[4];
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
     }
-    if (it + 1 < niter) sstore(buf ^ 1);
+    if (it + 1 < it_hi) sstore(buf ^ 1);
     __syncthreads();
   }
 
@@ -165,6 +172,11 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmParams p) {
       const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4);
       if (n >= N) continue;
       f32x4_t v = acc[i][j];
+      if (p.ksplit > 1) {   // partial sum: the finalize kernel adds the slabs and applies the epilogue
+        const size_t npix = (size_t)M * (FORM == FORM_CONVT ? 4 : 1);
+        *reinterpret_cast<f32x4_t*>(p.ws + ((size_t)kslice * npix + opix) * N + n) = v;
+        continue;
+      }
       if (EPI == EPI_BIAS_ACT) {
         if (p.bias) {
           const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(p.bias + n);
@@ -194,10 +206,65 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmParams p) {
   }
 }
 
+// sums the split-K slabs and applies the epilogue the GEMM kernel skipped; 4 channels per thread
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, size_t npix) {
+  const int N = p.N, n4 = N >> 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npix * n4) return;
+  const size_t opix = idx / n4;
+  const int n = (int)(idx - opix * n4) * 4;
+  f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.ksplit; s++) v += *reinterpret_cast<const f32x4_t*>(p.ws + ((size_t)s * npix + opix) * N + n);
+  T* __restrict__ yout = reinterpret_cast<T*>(p.y);
+  if (EPI == EPI_BIAS_ACT) {
+    if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+    if (p.relu) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+    }
+  } else {
+    if (p.act) {
+      const u32x2_t a2 = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const T*>(p.act) + opix * p.ldact + n);
+      if (!(unpack_lo<T>(a2[0]) > 0.f)) v[0] = 0.f;
+      if (!(unpack_hi<T>(a2[0]) > 0.f)) v[1] = 0.f;
+      if (!(unpack_lo<T>(a2[1]) > 0.f)) v[2] = 0.f;
+      if (!(unpack_hi<T>(a2[1]) > 0.f)) v[3] = 0.f;
+    }
+    if (p.accumulate) {
+      const u32x2_t o2 = *reinterpret_cast<const u32x2_t*>(yout + opix * p.ldy + n);
+      v[0] += unpack_lo<T>(o2[0]); v[1] += unpack_hi<T>(o2[0]);
+      v[2] += unpack_lo<T>(o2[1]); v[3] += unpack_hi<T>(o2[1]);
+    }
+  }
+  u32x2_t o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+  *reinterpret_cast<u32x2_t*>(yout + opix * p.ldy + n) = o;
+}
+
 template <typename T, int FORM, int BM, int BN, int EPI>
-int launch(const TapGemmParams& p, hipStream_t s) {
+int launch(TapGemmParams p, hipStream_t s) {
   const int M = p.B * p.Hs * p.Ws;
-  dim3 grid((M + BM - 1) / BM, (p.N + BN - 1) / BN, FORM == FORM_CONVT ? 4 : 1);
+  constexpr int PH = FORM == FORM_CONVT ? 4 : 1;
+  const int tiles = ((M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * PH;
+  const int niter = (FORM == FORM_CONV ? 16 : 4) * ((p.K + BK - 1) / BK);
+  const size_t npix = (size_t)M * PH;
+  // small-M layers (bottleneck of the U-Net) cannot fill 256 CUs with output tiles: split the reduction
+  p.ksplit = 1;
+  p.ws = nullptr;
+  size_t ws_bytes = 0;
+  float* ws = gct2_workspace(&ws_bytes);
+  if (ws && tiles < 192 && niter >= 4) {
+    int want = (512 + tiles - 1) / tiles;
+    const size_t slab = npix * p.N * sizeof(float);
+    want = (int)std::min<size_t>((size_t)want, ws_bytes / slab);
+    want = std::min(want, niter / 2);
+    if (want >= 2) {
+      const int per = (niter + want - 1) / want;
+      p.ksplit = (niter + per - 1) / per;
+      p.ws = ws;
+    }
+  }
+  dim3 grid((M + BM - 1) / BM, (p.N + BN - 1) / BN, PH * p.ksplit);
   constexpr int A_BYTES = BM * 128;
   constexpr int W_BYTES = (FORM == FORM_CONV) ? 64 * 256 : BN * 128;
   const size_t lds = 2 * (A_BYTES + W_BYTES);
@@ -208,6 +275,10 @@ int launch(const TapGemmParams& p, hipStream_t s) {
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  if (p.ksplit > 1) {
+    const size_t total = npix * (p.N >> 2);
+    hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, npix);
+  }
   return gct2_check_launch("tapgemm_mfma");
 }
 

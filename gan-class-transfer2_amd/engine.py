@@ -149,7 +149,8 @@ class UNetEngine:
 
     def __init__(self, topo: Topology, dtype: int = BF16, device: Optional[torch.device] = None, steps: int = 200,
                  base_lr: float = 2e-5, warm_up: int = 2000, beta_1: float = 0.9, beta_2: float = 0.999,
-                 epsilon: float = 1e-7, loss_scaling: bool = False, seed: int = 1234, rng_seed: int = 0):
+                 epsilon: float = 1e-7, loss_scaling: bool = False, seed: int = 1234, rng_seed: int = 0,
+                 workspace_mb: int = 64):
         self.lib = _lib.load()
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         if self.device.type != "cuda":
@@ -165,6 +166,10 @@ class UNetEngine:
         self.iterations = 0            # optimizer.iterations [TF]
         self.rng_seed, self.rng_offset_t, self.rng_offset_eps = rng_seed, 0, 0
         self._bufs: Dict[Tuple[int, int, int], _Buffers] = {}
+        # split-K scratch for the bottleneck layers (include/gct2.h gct2_set_workspace); caller-owned = this tensor
+        self.workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
+        call("gct2_set_workspace", self.workspace.data_ptr() if workspace_mb else None,
+             self.workspace.numel() * 4 if workspace_mb else 0)
         self.ls_state = None
         if loss_scaling:
             self.ls_state = torch.zeros(4, dtype=torch.int32, device=self.device)  # 16-byte gct2_loss_scale_state

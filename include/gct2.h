@@ -42,6 +42,10 @@ const char* gct2_last_error(void);          /* host string describing the last n
 int gct2_device_check(void);                /* GCT2_OK iff the current device is gfx950 */
 /* test hook: non-zero routes every convolution through the direct (non-MFMA) kernels */
 void gct2_debug_force_direct(int on);
+/* optional caller-owned device scratch (16-byte aligned) for the split-K partial sums of layers whose output
+ * is too small to fill the chip (the U-Net's bottleneck levels).  Process-wide; kernels that use it must be
+ * enqueued on ONE stream at a time.  ws = NULL disables split-K (same results, slower small layers). */
+int gct2_set_workspace(void* ws, size_t bytes);
 
 /* ---- DownShuffle = Conv2D(f, 4, 2, 'same', relu)   train.py:158-169 ------------------------- */
 /* y[b,oh,ow,o] = act(bias[o] + sum_{kh,kw,i} x[b,2oh+kh-1,2ow+kw-1,i] * w[kh,kw,i,o])

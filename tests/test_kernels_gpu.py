@@ -50,7 +50,9 @@ CONV_SHAPES = [
     (2, 8, 8, 64, 128),      # one full tile
     (1, 4, 12, 72, 136),     # K and N ragged w.r.t. 64/128, M ragged
     (3, 2, 2, 256, 64),      # tiny spatial grid (bottleneck regime), deep K
-    (2, 16, 16, 3, 8),       # image layer: Cin = 3 -> direct kernels
+    (2, 16, 16, 3, 8),       # image layer: Cin = 3 -> rgb_mfma kernels (16-bit) / direct (fp32)
+    (3, 32, 32, 3, 128),     # image layer at the real channel count, several r-steps per workgroup
+    (1, 8, 8, 4, 136),       # Cin = 4, ragged N
     (1, 6, 10, 5, 7),        # nothing aligned -> direct kernels
 ]
 
@@ -185,6 +187,50 @@ def test_convT4s2_wgrad(gpu, dt, shape):
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu().numpy(), dw_ref) <= TOL_F32OUT[dt]
     assert rel_l2(db.cpu().numpy(), db_ref) <= TOL_F32OUT[dt]
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_splitk_bottleneck_layers(gpu, dt):
+    """small-M / deep-K layers (U-Net bottleneck) with a registered workspace: split-K slabs + finalize kernel."""
+    L = lib()
+    ws = torch.empty(32 << 18, dtype=torch.float32, device=gpu)        # 32 MiB, deliberately NOT zeroed
+    ws.fill_(float("nan"))
+    L.call("gct2_set_workspace", ws.data_ptr(), ws.numel() * 4)
+    try:
+        B, H, W, Cin, Cout = 4, 4, 4, 512, 256
+        rng = np.random.default_rng(11)
+        x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+        # Conv2D forward + its input gradient
+        w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.05, dt)
+        b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+        xd, wd, bd = dev(x, dt, gpu), dev(w, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
+        y = torch.zeros(B, H // 2, W // 2, Cout, dtype=TDT[dt], device=gpu)
+        L.call("gct2_conv4s2_fwd", dt, xd.data_ptr(), Cin, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), Cout, B, H, W, Cin, Cout, 1, stream())
+        torch.cuda.synchronize()
+        assert rel_l2(y.double().cpu().numpy(), np.maximum(O.conv4s2_fwd(x, w, b), 0)) <= TOL_OUT[dt]
+        dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+        prev = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+        dxd = dev(prev, dt, gpu)
+        L.call("gct2_conv4s2_dgrad", dt, dev(dz, dt, gpu).data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dxd.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 1, stream())
+        torch.cuda.synchronize()
+        assert rel_l2(dxd.double().cpu().numpy(), O.conv4s2_bwd(x, w, dz)[0] * (x > 0) + prev) <= TOL_OUT[dt]
+        # Conv2DTranspose forward + its input gradient
+        wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.05, dt)
+        wtd = dev(wt, dt, gpu)
+        yt = torch.zeros(B, 2 * H, 2 * W, Cout, dtype=TDT[dt], device=gpu)
+        L.call("gct2_convT4s2_fwd", dt, xd.data_ptr(), Cin, wtd.data_ptr(), bd.data_ptr(), yt.data_ptr(), Cout, B, H, W, Cin, Cout, 1, stream())
+        torch.cuda.synchronize()
+        assert rel_l2(yt.double().cpu().numpy(), np.maximum(O.convT4s2_fwd(x, wt, b), 0)) <= TOL_OUT[dt]
+        dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+        dxt = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
+        L.call("gct2_convT4s2_dgrad", dt, dev(dzt, dt, gpu).data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dxt.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 0, stream())
+        torch.cuda.synchronize()
+        assert rel_l2(dxt.double().cpu().numpy(), O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)) <= TOL_OUT[dt]
+        assert not bool(torch.isnan(ws).all())                          # the slabs were really used
+    finally:
+        L.call("gct2_set_workspace", None, 0)
 
 
 def test_mfma_and_direct_paths_agree(gpu):
