@@ -11,7 +11,11 @@
 //     weights are the Keras kernel viewed as [tap][N][K] (K contiguous)  -> "N image" in LDS.
 //
 // Tile: BM x BN outputs per 256-thread workgroup (4 waves, each 64x64 = 4x4 MFMA 16x16x32 tiles), BK = 64
-// channels of one tap per step, register-staged double-buffered LDS (one barrier per step).
+// channels of one tap per step.  Staging is LDS-DMA (buffer_load_dwordx4 ... lds): every wave-instruction
+// deposits 1 KiB lane-linearly, so the XOR swizzle of the LDS images is applied to each lane's SOURCE address;
+// zero padding (image border, ragged M/K/N) is an out-of-range buffer offset, which the hardware turns into
+// zeros in LDS (probed: tests/hw_probe/probe_glds.hip).  Two LDS buffers: the DMA of step t+1 is issued before
+// the MFMAs of step t, one vmcnt(0)+barrier per step.
 // MFMA orientation: A operand = weights (rows = n), B operand = activations (cols = m), so every lane ends
 // with 4 consecutive output channels of one pixel -> 8-byte NHWC stores.
 #include "gct2_common.h"
@@ -20,24 +24,34 @@
 namespace {
 
 constexpr int BK = 64;
+constexpr unsigned OOB = 0x80000000u;            // >= num_records of every descriptor below
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)OOB, 0x00020000);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
+}
 
 template <typename T, int FORM, int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmParams p) {
+__global__ __launch_bounds__(256, 2) void tapgemm_kernel(TapGemmParams p) {
   static_assert((BM / 64) * (BN / 64) == 4, "4 waves of 64x64");
   static_assert(FORM == FORM_CONVT || BN == 128, "T image is 128 columns wide");
   constexpr int WAVES_N = BN / 64;
-  constexpr int NA = BM / 32;                      // 16-byte chunks per thread, activation tile
+  constexpr int NA = BM / 32;                      // 1-KiB pieces per wave, activation tile (8 rows each)
   constexpr int NW = (FORM == FORM_CONV) ? 4 : BN / 32;
   constexpr int A_BYTES = BM * 128;
   constexpr int W_BYTES = (FORM == FORM_CONV) ? 64 * 256 : BN * 128;
   constexpr int NTAPS = (FORM == FORM_CONV) ? 16 : 4;
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* a_img[2]; char* w_img[2];
-  a_img[0] = smem; a_img[1] = smem + A_BYTES + W_BYTES;
-  w_img[0] = smem + A_BYTES; w_img[1] = smem + 2 * A_BYTES + W_BYTES;
+  // two DISTINCT LDS objects: lets hipcc prove that the DMA into one buffer does not alias the ds_reads of the
+  // other one, so it does not drain vmcnt before every read (cdna_hip_programming.md, "Three .s-level traps" (a))
+  __shared__ __attribute__((aligned(16))) char lds0[A_BYTES + W_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds1[A_BYTES + W_BYTES];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WAVES_N, wm = wave / WAVES_N;
   const int Hs = p.Hs, Ws = p.Ws, K = p.K, N = p.N;
   const int M = p.B * Hs * Ws;
@@ -46,76 +60,80 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmParams p) {
   const int pw = (FORM == FORM_CONVT) ? (int)(blockIdx.z & 1) : 0;
   const int kslice = (FORM == FORM_CONVT) ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
   const int Hsrc = (FORM == FORM_CONV) ? 2 * Hs : Hs, Wsrc = (FORM == FORM_CONV) ? 2 * Ws : Ws;
-  const T* __restrict__ xsrc = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ wsrc = reinterpret_cast<const T*>(p.w);
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x), rs_w = make_rsrc(p.w);
+  const int ldx2 = p.ldx * 2;                      // bytes per source pixel
 
-  // ---- per-thread staging descriptors (fixed over the whole K loop) ----
-  const int a_chunk = tid & 7, a_row0 = tid >> 3;
-  int a_h[NA], a_w[NA], a_pix[NA];                 // source pixel base per staged row; a_pix < 0: row >= M
+  // ---- per-lane DMA descriptors (fixed over the whole K loop) ------------------------------------------
+  // activation tile (N image): piece q = wave + 4 i holds rows 8q .. 8q+7; lane -> row 8q + (lane>>3),
+  // physical chunk lane&7 = logical chunk ^ ((row>>1)&7)
+  const int a_lchunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+  unsigned a_off[NA];                              // byte offset of (row's tap-origin pixel, logical chunk)
+  unsigned a_mask[NA];                             // bit t: tap t reads inside the image for this row
 #pragma unroll
   for (int i = 0; i < NA; i++) {
-    const int m = m0 + a_row0 + 32 * i;
+    const int m = m0 + 8 * (wave + 4 * i) + (lane >> 3);
+    a_off[i] = 0; a_mask[i] = 0;
     if (m < M) {
       const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
-      a_pix[i] = b * Hsrc * Wsrc;
-      a_h[i] = (FORM == FORM_CONV) ? 2 * sh - 1 : sh + ph;
-      a_w[i] = (FORM == FORM_CONV) ? 2 * sw - 1 : sw + pw;
-    } else {
-      a_pix[i] = -1; a_h[i] = 0; a_w[i] = 0;
+      // origin = the tap with the smallest row/column: (2sh-1, 2sw-1) for conv, (sh+ph-1, sw+pw-1) for convT
+      const int h0 = (FORM == FORM_CONV) ? 2 * sh - 1 : sh + ph - 1;
+      const int w0 = (FORM == FORM_CONV) ? 2 * sw - 1 : sw + pw - 1;
+      a_off[i] = (unsigned)(((b * Hsrc + h0) * Wsrc + w0) * ldx2 + a_lchunk * 16);   // may wrap below 0: only used when valid
+      constexpr int TW = (FORM == FORM_CONV) ? 4 : 2;
+#pragma unroll
+      for (int t2 = 0; t2 < NTAPS; t2++) {
+        const int dh = t2 / TW, dw = t2 % TW;
+        if ((unsigned)(h0 + dh) < (unsigned)Hsrc && (unsigned)(w0 + dw) < (unsigned)Wsrc) a_mask[i] |= 1u << t2;
+      }
     }
   }
+  // weight tile
+  unsigned w_off[NW];
+  bool w_nok[NW];                                  // column (n) part of the validity
+  int w_k[NW];                                     // FORM_CONV: k row inside the 64-step; FORM_CONVT: unused
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    if (FORM == FORM_CONV) {                       // T image: piece = 4 k-rows x 16 chunks
+      const int k = 4 * (wave + 4 * i) + (lane >> 4);
+      const int lc = ((((lane & 15) >> 1) ^ timg_swz(k)) << 1) | (lane & 1);
+      w_k[i] = k;
+      w_nok[i] = (n0 + lc * 8) < N;
+      w_off[i] = (unsigned)((k * N + n0 + lc * 8) * 2);
+    } else {                                       // N image: piece = 8 n-rows x 8 chunks
+      const int n = 8 * (wave + 4 * i) + (lane >> 3);
+      w_k[i] = a_lchunk * 8;                       // first k of this lane's chunk
+      w_nok[i] = (n0 + n) < N;
+      w_off[i] = (unsigned)(((n0 + n) * K + a_lchunk * 8) * 2);
+    }
+  }
+
   const int nk = (K + BK - 1) / BK;
   const int niter = NTAPS * nk;
 
-  u32x4_t a_reg[NA], w_reg[NW];
-  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-
-  auto gload = [&](int it) {
+  auto issue = [&](int it, char* abase) {
     const int tap = it / nk, c0 = (it - tap * nk) * BK;
-    int dh, dw_, tap16;
-    if (FORM == FORM_CONV) { dh = tap >> 2; dw_ = tap & 3; tap16 = tap; }
+    int tap16, dh, dw;
+    if (FORM == FORM_CONV) { tap16 = tap; dh = tap >> 2; dw = tap & 3; }
     else {
+      // source row sh+ph-a  = origin + (1-a); kernel row kh = 1-ph+2a
       const int a = tap >> 1, c = tap & 1;
-      dh = -a; dw_ = -c;
+      dh = 1 - a; dw = 1 - c;
       tap16 = (1 - ph + 2 * a) * 4 + (1 - pw + 2 * c);
     }
-    const bool cok = (c0 + a_chunk * 8) < K;
+    const int abit = (FORM == FORM_CONV) ? tap : dh * 2 + dw;
+    const unsigned tapoff = (unsigned)((dh * Wsrc + dw) * ldx2 + c0 * 2);
+    const bool a_cok = (c0 + a_lchunk * 8) < K;
 #pragma unroll
     for (int i = 0; i < NA; i++) {
-      const int h = a_h[i] + dh, w = a_w[i] + dw_;
-      const bool ok = cok && a_pix[i] >= 0 && (unsigned)h < (unsigned)Hsrc && (unsigned)w < (unsigned)Wsrc;
-      a_reg[i] = zero4;
-      if (ok) a_reg[i] = gload128(xsrc + (size_t)(a_pix[i] + h * Wsrc + w) * p.ldx + c0 + a_chunk * 8);
+      const bool ok = a_cok && ((a_mask[i] >> abit) & 1u);
+      dma16(rs_x, abase + (wave + 4 * i) * 1024, ok ? a_off[i] + tapoff : OOB);
     }
-    if (FORM == FORM_CONV) {                       // [tap][K][N]: 64 k-rows x 16 chunks of 8 n
-      const int c = tid & 15;
+    char* wbase = abase + A_BYTES;
+    const unsigned wtap = (FORM == FORM_CONV) ? (unsigned)(((tap16 * K + c0) * N) * 2) : (unsigned)((tap16 * N * K + c0) * 2);
 #pragma unroll
-      for (int i = 0; i < NW; i++) {
-        const int kr = (tid >> 4) + 16 * i;
-        const bool ok = (c0 + kr) < K && (n0 + c * 8) < N;
-        w_reg[i] = zero4;
-        if (ok) w_reg[i] = gload128(wsrc + ((size_t)tap16 * K + c0 + kr) * N + n0 + c * 8);
-      }
-    } else {                                       // [tap][N][K]: BN n-rows x 8 chunks of 8 k
-      const int c = tid & 7;
-#pragma unroll
-      for (int i = 0; i < NW; i++) {
-        const int nr = (tid >> 3) + 32 * i;
-        const bool ok = (n0 + nr) < N && (c0 + c * 8) < K;
-        w_reg[i] = zero4;
-        if (ok) w_reg[i] = gload128(wsrc + ((size_t)tap16 * N + n0 + nr) * K + c0 + c * 8);
-      }
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NA; i++) lds_write128(a_img[buf], nimg_off(a_row0 + 32 * i, a_chunk), a_reg[i]);
-    if (FORM == FORM_CONV) {
-#pragma unroll
-      for (int i = 0; i < NW; i++) lds_write128(w_img[buf], timg_off((tid >> 4) + 16 * i, tid & 15), w_reg[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NW; i++) lds_write128(w_img[buf], nimg_off((tid >> 3) + 32 * i, tid & 7), w_reg[i]);
+    for (int i = 0; i < NW; i++) {
+      const bool ok = w_nok[i] && (c0 + w_k[i]) < K;
+      dma16(rs_w, wbase + (wave + 4 * i) * 1024, ok ? w_off[i] + wtap : OOB);
     }
   };
 
@@ -128,29 +146,35 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmParams p) {
   // split-K: this workgroup reduces iterations [it_lo, it_hi) only and leaves an fp32 partial slab
   const int it_per = (niter + p.ksplit - 1) / p.ksplit;
   const int it_lo = kslice * it_per, it_hi = min(niter, it_lo + it_per);
-  if (it_lo < it_hi) {
-    gload(it_lo);
-    sstore(0);
-  }
-  __syncthreads();
-  for (int it = it_lo; it < it_hi; it++) {
-    const int buf = (it - it_lo) & 1;
-    if (it + 1 < it_hi) gload(it + 1);
+  auto compute = [&](const char* a_img) {
+    const char* w_img = a_img + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
       u32x4_t wf[4], af[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        wf[i] = (FORM == FORM_CONV) ? timg_frag(w_img[buf], wn * 64 + i * 16, kk, lane)
-                                    : nimg_frag(w_img[buf], wn * 64 + i * 16, kk, lane);
-        af[i] = nimg_frag(a_img[buf], wm * 64 + i * 16, kk, lane);
+        wf[i] = (FORM == FORM_CONV) ? timg_frag(w_img, wn * 64 + i * 16, kk, lane)
+                                    : nimg_frag(w_img, wn * 64 + i * 16, kk, lane);
+        af[i] = nimg_frag(a_img, wm * 64 + i * 16, kk, lane);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
     }
-    if (it + 1 < it_hi) sstore(buf ^ 1);
+  };
+  if (it_lo < it_hi) issue(it_lo, lds0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int it = it_lo; it < it_hi; it += 2) {      // two steps per trip: buffer roles are compile-time
+    if (it + 1 < it_hi) issue(it + 1, lds1);
+    compute(lds0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 1 >= it_hi) break;
+    if (it + 2 < it_hi) issue(it + 2, lds0);
+    compute(lds1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -265,16 +289,8 @@ int launch(TapGemmParams p, hipStream_t s) {
     }
   }
   dim3 grid((M + BM - 1) / BM, (p.N + BN - 1) / BN, PH * p.ksplit);
-  constexpr int A_BYTES = BM * 128;
-  constexpr int W_BYTES = (FORM == FORM_CONV) ? 64 * 256 : BN * 128;
-  const size_t lds = 2 * (A_BYTES + W_BYTES);
   auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, p);
   if (p.ksplit > 1) {
     const size_t total = npix * (p.N >> 2);
     hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, npix);
@@ -296,7 +312,7 @@ int dispatch(int form, int epi, const TapGemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-// true when the MFMA path can take this problem (16-byte aligned rows, whole 8-channel chunks)
+// true when the MFMA path can take this problem (16-byte aligned rows, whole 8-channel chunks, 31-bit byte offsets)
 bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {
   if (dtype != GCT2_BF16 && dtype != GCT2_F16) return false;
   if (p.K % 8 || p.N % 8 || p.ldx % 8 || p.ldy % 4) return false;
@@ -304,6 +320,10 @@ bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {
   if ((uintptr_t)p.x % 16 || (uintptr_t)p.w % 16 || (uintptr_t)p.y % 8) return false;
   if (p.act && (uintptr_t)p.act % 8) return false;
   if (p.bias && (uintptr_t)p.bias % 16) return false;
+  // buffer descriptors address 2 GiB: source tensor (BIG grid for conv-form) and the 16-tap weight tensor
+  const size_t src_bytes = (size_t)p.B * p.Hs * p.Ws * 4 * p.ldx * 2;
+  const size_t w_bytes = (size_t)16 * p.K * p.N * 2;
+  if (src_bytes >= 0x7ff00000u || w_bytes >= 0x7ff00000u) return false;
   return true;
 }
 

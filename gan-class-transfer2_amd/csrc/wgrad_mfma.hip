@@ -7,21 +7,31 @@
 //   Conv2DTranspose : big = dz (Cb = Cout),            small = x  (Cs = Cin)   -> dW (4,4,Cout,Cin)
 // Both operands have the REDUCTION index r as their slow (row) index in memory, so both LDS tiles are
 // "T images" ([64 r][128 channels]) consumed through ds_read_tr16_b64.  128 x 128 output tile per
-// 256-thread workgroup, 64 rows of r per step, register-staged double-buffered LDS, split over r across
-// gridDim.z with fp32 atomics into the (pre-zeroed / running) gradient arena.
+// 256-thread workgroup, 64 rows of r per step, LDS-DMA staging (buffer_load ... lds; swizzle on the source
+// address, out-of-range offset = zero fill) into two LDS buffers, split over r across gridDim.z with fp32
+// atomics into the (pre-zeroed / running) gradient arena.
 #include "gct2_common.h"
 
 namespace {
 
-template <typename T>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
-  constexpr int IMG = 64 * 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* b_img[2]; char* s_img[2];
-  b_img[0] = smem; b_img[1] = smem + 2 * IMG;
-  s_img[0] = smem + IMG; s_img[1] = smem + 3 * IMG;
+constexpr unsigned OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void lds_void_t;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)OOB, 0x00020000);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
+  constexpr int IMG = 64 * 256;
+  __shared__ __attribute__((aligned(16))) char lds0[2 * IMG];     // [big image | small image]
+  __shared__ __attribute__((aligned(16))) char lds1[2 * IMG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wm = wave >> 1;
   const int Hs = p.Hs, Ws = p.Ws, Cb = p.Cb, Cs = p.Cs;
   const int Hb = 2 * Hs, Wb = 2 * Ws;
@@ -36,48 +46,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int step_hi = min(steps_total, step_lo + steps_per);
   if (step_lo >= step_hi) return;
 
-  const T* __restrict__ big = reinterpret_cast<const T*>(p.big);
-  const T* __restrict__ small = reinterpret_cast<const T*>(p.small);
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.big), rs_s = make_rsrc(p.small);
 
-  const int c = tid & 15, rr0 = tid >> 4;          // chunk (8 channels) and first row of this thread
-  const int gc = gc0 + c * 8;
+  // piece q = wave + 4 i of a T image = rows 4q .. 4q+3; lane -> row 4q + (lane>>4), physical 16-byte chunk lane&15
+  const int row0 = 4 * wave + (lane >> 4);                       // row of piece i is row0 + 16 i
+  const int lc = ((((lane & 15) >> 1) ^ timg_swz(row0)) << 1) | (lane & 1);   // logical chunk (same for every i)
+  const int gc = gc0 + lc * 8;
   const bool gc_ok = gc < GC;
   const int tap = gc_ok ? gc / Cb : 0, cb = gc_ok ? gc - tap * Cb : 0;
   const int kh = tap >> 2, kw = tap & 3;
-  const bool cs_ok = (cs0 + c * 8) < Cs;
+  const bool cs_ok = (cs0 + lc * 8) < Cs;
+  const int ldb2 = p.ldbig * 2, lds2 = p.ldsmall * 2;
 
   // incremental (b, sh, sw) decode of r, advanced by 64 rows per step
   const int adv_w = 64 % Ws, q1 = 64 / Ws, adv_h = q1 % Hs, adv_b = q1 / Hs;
   int rb[4], rh[4], rw[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int r = step_lo * 64 + rr0 + 16 * i;
+    const int r = step_lo * 64 + row0 + 16 * i;
     rw[i] = r % Ws; const int t = r / Ws; rh[i] = t % Hs; rb[i] = t / Hs;
   }
 
-  u32x4_t b_reg[4], s_reg[4];
-  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-  auto gload = [&](int step) {
+  auto issue = [&](int step, char* base) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int r = step * 64 + rr0 + 16 * i;
+      const int r = step * 64 + row0 + 16 * i;
       const int h = 2 * rh[i] + kh - 1, w = 2 * rw[i] + kw - 1;
       const bool okb = gc_ok && r < R && (unsigned)h < (unsigned)Hb && (unsigned)w < (unsigned)Wb;
-      b_reg[i] = zero4;
-      if (okb) b_reg[i] = gload128(big + ((size_t)(rb[i] * Hb + h) * Wb + w) * p.ldbig + cb);
-      s_reg[i] = zero4;
-      if (cs_ok && r < R) s_reg[i] = gload128(small + (size_t)r * p.ldsmall + cs0 + c * 8);
+      const unsigned offb = (unsigned)(((rb[i] * Hb + h) * Wb + w) * ldb2 + cb * 2);
+      dma16(rs_b, base + (wave + 4 * i) * 1024, okb ? offb : OOB);
+      const unsigned offs = (unsigned)(r * lds2 + (cs0 + lc * 8) * 2);
+      dma16(rs_s, base + IMG + (wave + 4 * i) * 1024, (cs_ok && r < R) ? offs : OOB);
       // advance this row by 64 for the next step
       rw[i] += adv_w; rh[i] += adv_h; rb[i] += adv_b;
       if (rw[i] >= Ws) { rw[i] -= Ws; rh[i]++; }
       if (rh[i] >= Hs) { rh[i] -= Hs; rb[i]++; }
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      lds_write128(b_img[buf], timg_off(rr0 + 16 * i, c), b_reg[i]);
-      lds_write128(s_img[buf], timg_off(rr0 + 16 * i, c), s_reg[i]);
     }
   };
 
@@ -87,26 +90,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  gload(step_lo);
-  sstore(0);
-  __syncthreads();
-  for (int step = step_lo; step < step_hi; step++) {
-    const int buf = (step - step_lo) & 1;
-    if (step + 1 < step_hi) gload(step + 1);
+  auto compute = [&](const char* base) {
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
       u32x4_t bf[4], sf[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        bf[i] = timg_frag(b_img[buf], wm * 64 + i * 16, kk, lane);
-        sf[i] = timg_frag(s_img[buf], wn * 64 + i * 16, kk, lane);
+        bf[i] = timg_frag(base, wm * 64 + i * 16, kk, lane);
+        sf[i] = timg_frag(base + IMG, wn * 64 + i * 16, kk, lane);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(bf[i], sf[j], acc[i][j]);
     }
-    if (step + 1 < step_hi) sstore(buf ^ 1);
+  };
+
+  issue(step_lo, lds0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int step = step_lo; step < step_hi; step += 2) {          // two steps per trip: buffer roles are compile-time
+    if (step + 1 < step_hi) issue(step + 1, lds1);
+    compute(lds0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (step + 1 >= step_hi) break;
+    if (step + 2 < step_hi) issue(step + 2, lds0);
+    compute(lds1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -132,6 +143,8 @@ bool wgrad_mfma_supported(int dtype, const WgradParams& p) {
   if (dtype != GCT2_BF16 && dtype != GCT2_F16) return false;
   if (p.Cb % 8 || p.Cs % 8 || p.ldbig % 8 || p.ldsmall % 8) return false;
   if ((uintptr_t)p.big % 16 || (uintptr_t)p.small % 16) return false;
+  const size_t big_bytes = (size_t)p.B * p.Hs * p.Ws * 4 * p.ldbig * 2, small_bytes = (size_t)p.B * p.Hs * p.Ws * p.ldsmall * 2;
+  if (big_bytes >= 0x7ff00000u || small_bytes >= 0x7ff00000u) return false;     // 31-bit buffer offsets
   return true;
 }
 
@@ -144,11 +157,7 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
   rsplit = max(1, min(rsplit, steps_total / 4));
   p.rsplit = rsplit;
   dim3 grid(tiles, 1, rsplit);
-  const size_t lds = 4 * 64 * 256;
-  auto launch = [&](auto kern) {
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-  };
-  if (dtype == GCT2_BF16) launch(wgrad_kernel<__bf16>);
-  else launch(wgrad_kernel<_Float16>);
+  if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(wgrad_kernel<_Float16>, grid, dim3(256), 0, s, p);
   return gct2_check_launch("wgrad_mfma");
 }
