@@ -21,6 +21,8 @@ int pw_noise(int, const float*, const int32_t*, const float*, void*, int, int, i
 int pw_dense_fwd(int, const void*, int, const float*, const float*, float*, int, int, int, hipStream_t);
 int pw_dense_bwd(int, const void*, int, const float*, const float*, void*, int, float*, float*, int, int, int, int, hipStream_t);
 int pw_mse(const float*, const float*, float*, float*, float*, size_t, const float*, hipStream_t);
+int pw_dense_head_train(int, const void*, int, const float*, const float*, const float*, float*, void*, int, float*, float*, float*, float*,
+                        int, int, int, int, const float*, hipStream_t);
 int pw_colsum(int, const void*, int, float*, size_t, int, hipStream_t);
 int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, const float*, const int32_t*, int, hipStream_t);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
@@ -169,6 +171,21 @@ int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const floa
   if ((size_t)Cin * 16 + 128 * 16 + (size_t)128 * Cin * esize(dtype) > 160 * 1024)
     return gct2_fail(GCT2_EINVAL, "dense_bwd: Cin=%d too large for the LDS tile", Cin);
   return pw_dense_bwd(dtype, x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, S(stream));
+}
+
+int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, const float* b, const float* target, float* pred, void* dx,
+                          int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
+                          const float* loss_scale_ptr, void* stream) {
+  if ((dtype != GCT2_BF16 && dtype != GCT2_F16) || !x || !w || !target || !dx || !dw || !loss || !partials)
+    return gct2_fail(GCT2_EINVAL, "dense_head_train: 16-bit dtypes only / null pointer (use dense_fwd + mse_fwd_bwd + dense_bwd)");
+  if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout > 4 || ldx < Cin || ldx % 8 || lddx % 8 || Cmask % 8 || Cmask <= 0 || Cmask > Cin ||
+      lddx < Cmask || (Cin + 1) * Cout > 256)
+    return gct2_fail(GCT2_EINVAL, "dense_head_train: bad shape (need ldx, lddx, Cmask multiples of 8, (Cin+1)*Cout <= 256)");
+  if ((uintptr_t)x % 16 || (uintptr_t)dx % 16) return gct2_fail(GCT2_EINVAL, "dense_head_train: views must be 16-byte aligned");
+  if ((size_t)256 * ldx * 2 + (size_t)256 * Cmask * 2 + 256 * 16 + (size_t)ldx * 16 > 160 * 1024)
+    return gct2_fail(GCT2_EINVAL, "dense_head_train: ldx=%d too large for the LDS tile", ldx);
+  return pw_dense_head_train(dtype, x, ldx, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, loss_scale_ptr,
+                             S(stream));
 }
 
 int gct2_rng_uniform_int(uint64_t seed, uint64_t stream_id, uint64_t offset, int32_t* out, size_t n, int lo, int hi, void* stream) {

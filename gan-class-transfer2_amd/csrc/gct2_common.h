@@ -106,7 +106,20 @@ struct TapGemmParams {
   int K, N;                      // reduction channels per tap, output channels
   int relu, accumulate;
   float* ws; int ksplit;         // split-K: fp32 partial slabs [ksplit][out pixels][N] in the registered workspace
+  int m_tiles, n_tiles, xcd_chunk;   // launch geometry (filled by the launcher): see xcd_tile()
 };
+
+// XCD-aware work-group -> tile map.  The dispatcher deals consecutive work-group ids round-robin over the 8
+// XCDs (private L2 each; observed, speed only - MI355X_MICROARCH.md "Workgroup dispatch"), so ids with equal
+// id % 8 share an L2.  Each XCD walks a CONTIGUOUS band of `chunk` m-tiles, and for every m-tile runs all of
+// its `inner` siblings (n-tiles x output phases, which re-read the same source pixels) back to back.
+// Returns false for the padding ids of a ragged last band.
+__device__ __forceinline__ bool xcd_tile(int id, int m_tiles, int inner, int chunk, int& m_tile, int& in) {
+  const int xcd = id & 7, j = id >> 3;
+  in = j % inner;
+  m_tile = xcd * chunk + j / inner;
+  return (j / inner) < chunk && m_tile < m_tiles;
+}
 
 // caller-registered scratch (gct2_set_workspace); null when absent
 float* gct2_workspace(size_t* bytes);

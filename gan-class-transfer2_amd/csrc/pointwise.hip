@@ -174,6 +174,115 @@ __global__ __launch_bounds__(256) void mse_finish_kernel(const float* __restrict
   if (threadIdx.x == 0) *loss = (float)((ws[0] + ws[1] + ws[2] + ws[3]) * (double)inv_n);
 }
 
+// ---- fused head for the train step: Dense(3) forward + fp32 MSE + its gradient + Dense backward, ONE pass over R_0 -------
+// (train.py:198-202, 262-272 and their autodiff).  Per tile of 256 pixels: the 16-bit rows are copied to LDS with
+// 16-byte loads (a tile is one contiguous byte range because consecutive pixels are `ld` apart), thread = pixel
+// computes pred / dpred / the masked input gradient row (ds_read_b128; row stride ld*2 bytes is an odd multiple of
+// 16 for ld = 72, hence conflict-free), the gradient rows leave through LDS as whole 16-byte chunks, and threads
+// (i, o) accumulate dw[i][o] += x[pix][i] * dpred[pix][o] over the tile.
+template <typename T, int PIX>
+__global__ __launch_bounds__(256) void dense_head_train_kernel(const T* __restrict__ x, int ld, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const float* __restrict__ target,
+                                                               float* __restrict__ pred_out, T* __restrict__ dx, int lddx,
+                                                               float* __restrict__ dw, float* __restrict__ db,
+                                                               float* __restrict__ partials, int M, int Cin, int Cout, int Cmask,
+                                                               const float* __restrict__ loss_scale_ptr) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int nchunk = ld >> 3;                                    // 16-byte chunks per pixel row
+  T* xs = reinterpret_cast<T*>(smem_raw);                        // [PIX][ld]
+  T* dxs = xs + PIX * ld;                                        // [PIX][Cmask]
+  float* dps = reinterpret_cast<float*>(dxs + PIX * Cmask);      // [PIX][4]
+  float* wsm = dps + PIX * 4;                                    // [ld][4]  (rows >= Cin are zero)
+  const int tid = threadIdx.x;
+  for (int i = tid; i < ld * 4; i += 256) {
+    const int o = i & 3, k = i >> 2;
+    wsm[i] = (o < Cout && k < Cin) ? w[k * Cout + o] : 0.f;
+  }
+  const float gscale = (loss_scale_ptr ? *loss_scale_ptr : 1.f) * 2.0f / ((float)M * (float)Cout);
+  const int nout = (Cin + 1) * Cout;
+  const int my_i = tid / Cout, my_o = tid - my_i * Cout;
+  float wacc = 0.f, lacc = 0.f;
+  const int ntiles = (M + PIX - 1) / PIX;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int mbase = tile * PIX;
+    const int npx = min(PIX, M - mbase);
+    __syncthreads();
+    {   // stage the tile: npx * nchunk chunks, contiguous in memory
+      const u32x4_t* src = reinterpret_cast<const u32x4_t*>(x + (size_t)mbase * ld);
+      u32x4_t* dst = reinterpret_cast<u32x4_t*>(xs);
+      for (int i = tid; i < npx * nchunk; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tid < npx) {
+      const int m = mbase + tid;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      const u32x4_t* row = reinterpret_cast<const u32x4_t*>(xs + tid * ld);
+      for (int c = 0; c < nchunk; c++) {
+        const u32x4_t v = row[c];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float lo = unpack_lo<T>(v[q]), hi = unpack_hi<T>(v[q]);
+          const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wsm + 4 * (8 * c + 2 * q));
+          const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(wsm + 4 * (8 * c + 2 * q + 1));
+#pragma unroll
+          for (int o = 0; o < 4; o++) a[o] = fmaf(hi, w1[o], fmaf(lo, w0[o], a[o]));
+        }
+      }
+      float dp[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int o = 0; o < Cout; o++) {
+        const float pr = a[o] + (bias ? bias[o] : 0.f);
+        const float d = pr - target[(size_t)m * Cout + o];
+        if (pred_out) pred_out[(size_t)m * Cout + o] = pr;
+        lacc = fmaf(d, d, lacc);
+        dp[o] = d * gscale;
+      }
+      *reinterpret_cast<f32x4_t*>(dps + 4 * tid) = f32x4_t{dp[0], dp[1], dp[2], dp[3]};
+      u32x4_t* drow = reinterpret_cast<u32x4_t*>(dxs + tid * Cmask);
+      for (int c = 0; c < (Cmask >> 3); c++) {
+        const u32x4_t v = row[c];
+        u32x4_t g4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wsm + 4 * (8 * c + 2 * q));
+          const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(wsm + 4 * (8 * c + 2 * q + 1));
+          float g0 = dp[0] * w0[0] + dp[1] * w0[1] + dp[2] * w0[2] + dp[3] * w0[3];
+          float g1 = dp[0] * w1[0] + dp[1] * w1[1] + dp[2] * w1[2] + dp[3] * w1[3];
+          if (!(unpack_lo<T>(v[q]) > 0.f)) g0 = 0.f;
+          if (!(unpack_hi<T>(v[q]) > 0.f)) g1 = 0.f;
+          g4[q] = pack2<T>(g0, g1);
+        }
+        drow[c] = g4;
+      }
+    } else if (tid < PIX) {
+      *reinterpret_cast<f32x4_t*>(dps + 4 * tid) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    {   // gradient rows out: Cmask/8 chunks per pixel
+      const int cpr = Cmask >> 3;
+      for (int i = tid; i < npx * cpr; i += 256) {
+        const int pm = i / cpr, c = i - pm * cpr;
+        *reinterpret_cast<u32x4_t*>(dx + (size_t)(mbase + pm) * lddx + c * 8) = reinterpret_cast<const u32x4_t*>(dxs)[i];
+      }
+    }
+    if (tid < nout) {
+      if (my_i < Cin) {
+        for (int pm = 0; pm < npx; pm++) wacc = fmaf(to_f32(xs[pm * ld + my_i]), dps[4 * pm + my_o], wacc);
+      } else {
+        for (int pm = 0; pm < npx; pm++) wacc += dps[4 * pm + my_o];
+      }
+    }
+  }
+  if (tid < nout) {
+    if (my_i < Cin) atomicAdd(dw + my_i * Cout + my_o, wacc);
+    else if (db) atomicAdd(db + my_o, wacc);
+  }
+  for (int off = 32; off > 0; off >>= 1) lacc += __shfl_down(lacc, off, 64);
+  __shared__ float lws[4];
+  if ((tid & 63) == 0) lws[tid >> 6] = lacc;
+  __syncthreads();
+  if (tid == 0) partials[blockIdx.x] = lws[0] + lws[1] + lws[2] + lws[3];
+}
+
 // ---- bias gradient: db[c] += sum_m dz[m][c] --------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dz, int ld, float* __restrict__ db, size_t M, int C,
@@ -357,6 +466,31 @@ int pw_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float*
   if (dtype == GCT2_F32) return dense_bwd_t<float>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, s);
   if (dtype == GCT2_BF16) return dense_bwd_t<__bf16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, s);
   return dense_bwd_t<_Float16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, s);
+}
+template <typename T>
+static int dense_head_train_t(const void* x, int ld, const float* w, const float* b, const float* target, float* pred, void* dx, int lddx,
+                              float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask, const float* ls,
+                              hipStream_t s) {
+  constexpr int PIX = 256;
+  const size_t lds = (size_t)PIX * ld * 2 + (size_t)PIX * Cmask * 2 + PIX * 16 + (size_t)ld * 16;
+  const int ntiles = (M + PIX - 1) / PIX;
+  const int grid = ntiles < 1024 ? ntiles : 1024;
+  auto kern = dense_head_train_kernel<T, PIX>;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, reinterpret_cast<const T*>(x), ld, w, b, target, pred, reinterpret_cast<T*>(dx),
+                     lddx, dw, db, partials, M, Cin, Cout, Cmask, ls);
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, s, partials, grid, loss, 1.0f / ((float)M * (float)Cout));
+  return gct2_check_launch("dense_head_train");
+}
+int pw_dense_head_train(int dtype, const void* x, int ld, const float* w, const float* b, const float* target, float* pred, void* dx,
+                        int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
+                        const float* ls, hipStream_t s) {
+  if (dtype == GCT2_BF16) return dense_head_train_t<__bf16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, s);
+  return dense_head_train_t<_Float16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, s);
 }
 int pw_mse(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n, const float* ls, hipStream_t s) {
   const int nb = blocks_for(n, 1024) > 1024 ? 1024 : blocks_for(n, 1024);

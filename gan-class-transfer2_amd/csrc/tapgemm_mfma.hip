@@ -55,10 +55,15 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(TapGemmParams p) {
   const int wn = wave % WAVES_N, wm = wave / WAVES_N;
   const int Hs = p.Hs, Ws = p.Ws, K = p.K, N = p.N;
   const int M = p.B * Hs * Ws;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int ph = (FORM == FORM_CONVT) ? (int)((blockIdx.z & 3) >> 1) : 0;
-  const int pw = (FORM == FORM_CONVT) ? (int)(blockIdx.z & 1) : 0;
-  const int kslice = (FORM == FORM_CONVT) ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
+  // 1-D grid: [k-slice][XCD-aware (m-tile, n-tile, phase)]
+  constexpr int PH = (FORM == FORM_CONVT) ? 4 : 1;
+  const int inner = p.n_tiles * PH, per_slice = 8 * p.xcd_chunk * inner;
+  const int kslice = (int)blockIdx.x / per_slice;
+  int m_tile, in;
+  if (!xcd_tile((int)blockIdx.x - kslice * per_slice, p.m_tiles, inner, p.xcd_chunk, m_tile, in)) return;
+  const int phase = in % PH, n_tile = in / PH;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int ph = phase >> 1, pw = phase & 1;
   const int Hsrc = (FORM == FORM_CONV) ? 2 * Hs : Hs, Wsrc = (FORM == FORM_CONV) ? 2 * Ws : Ws;
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x), rs_w = make_rsrc(p.w);
   const int ldx2 = p.ldx * 2;                      // bytes per source pixel
@@ -288,7 +293,10 @@ int launch(TapGemmParams p, hipStream_t s) {
       p.ws = ws;
     }
   }
-  dim3 grid((M + BM - 1) / BM, (p.N + BN - 1) / BN, PH * p.ksplit);
+  p.m_tiles = (M + BM - 1) / BM;
+  p.n_tiles = (p.N + BN - 1) / BN;
+  p.xcd_chunk = (p.m_tiles + 7) / 8;
+  dim3 grid(8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
   auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI>;
   hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, p);
   if (p.ksplit > 1) {

@@ -38,11 +38,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   const int R = p.B * Hs * Ws;
   const int GC = 16 * Cb;
   const int tiles_n = (Cs + 127) / 128;
-  const int gc0 = (blockIdx.x / tiles_n) * 128, cs0 = (blockIdx.x % tiles_n) * 128;
+  // XCD-aware 1-D grid: all output tiles of one r-split re-read the same rows of both operands, so a whole split
+  // runs on ONE XCD (ids with equal id % 8 share an L2); with fewer than 8 splits the plain order is kept
+  const int tiles = ((GC + 127) / 128) * tiles_n;
+  int tile, split;
+  if (p.rsplit >= 8) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % tiles;
+    split = (j / tiles) * 8 + xcd;
+    if (split >= p.rsplit) return;
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
+  const int gc0 = (tile / tiles_n) * 128, cs0 = (tile % tiles_n) * 128;
   // r range of this split, in whole 64-row steps
   const int steps_total = (R + 63) / 64;
   const int steps_per = (steps_total + p.rsplit - 1) / p.rsplit;
-  const int step_lo = blockIdx.z * steps_per;
+  const int step_lo = split * steps_per;
   const int step_hi = min(steps_total, step_lo + steps_per);
   if (step_lo >= step_hi) return;
 
@@ -156,7 +169,7 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
   int rsplit = (768 + tiles - 1) / tiles;
   rsplit = max(1, min(rsplit, steps_total / 4));
   p.rsplit = rsplit;
-  dim3 grid(tiles, 1, rsplit);
+  dim3 grid(rsplit >= 8 ? tiles * 8 * ((rsplit + 7) / 8) : tiles * rsplit);
   if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(wgrad_kernel<_Float16>, grid, dim3(256), 0, s, p);
   return gct2_check_launch("wgrad_mfma");

@@ -160,6 +160,7 @@ class UNetEngine:
         self.base_lr, self.warm_up = base_lr, warm_up
         self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
         self.loss_scaling = loss_scaling
+        self.use_fused_head = True     # False: dense_fwd + mse_fwd_bwd + dense_bwd as three kernels
         self.arena = ParamArena(topo, dtype, self.device)
         self.arena.glorot_init(seed)
         self.arena.refresh_shadow(self._stream())
@@ -250,8 +251,9 @@ class UNetEngine:
         t = self.topo
         b.R[0][..., t.fu(0):t.fu(0) + 3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
 
-    def forward(self, b: _Buffers) -> torch.Tensor:
-        """Denoiser.call (train.py:206-215): R_0's image slice must already hold the network input."""
+    def forward(self, b: _Buffers, head: bool = True) -> torch.Tensor:
+        """Denoiser.call (train.py:206-215): R_0's image slice must already hold the network input.
+        head=False stops before Dense(3) (the train step runs the fused head kernel instead)."""
         t, n, s, dt, A = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena
         for i in range(n):                                      # DownShuffle_i  (train.py:184)
             H, W = b.hw[i]
@@ -269,6 +271,8 @@ class UNetEngine:
                 x, ldx = b.Dlast.data_ptr(), t.fd(i)
             call("gct2_convT4s2_fwd", dt, x, ldx, A.wptr(f"U{i}.w"), A.pptr(f"U{i}.b"), b.R[i].data_ptr(), b.ld[i],
                  b.B, Hi, Wi, t.up_in(i), t.fu(i), 1, s)
+        if not head:
+            return b.pred
         M = b.B * b.H * b.W                                     # Dense(3)       (train.py:198-202)
         call("gct2_dense_fwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"), b.pred.data_ptr(),
              M, t.fu(0) + 3, 3, s)
@@ -281,16 +285,30 @@ class UNetEngine:
              b.partials.data_ptr(), b.pred.numel(), ls_ptr, self._stream())
         return b.loss
 
+    def fused_head_ok(self) -> bool:
+        return self.use_fused_head and self.dtype != F32 and self.topo.fu(0) % 8 == 0
+
+    def head_train(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
+        """Dense(3) + fp32 MSE + both of their gradients in one pass over R_0 (gct2_dense_head_train)."""
+        t, A = self.topo, self.arena
+        ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
+        call("gct2_dense_head_train", self.dtype, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"),
+             target.data_ptr(), b.pred.data_ptr(), b.dR[0].data_ptr(), b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"),
+             b.loss.data_ptr(), b.partials.data_ptr(), b.B * b.H * b.W, t.fu(0) + 3, 3, t.fu(0), ls_ptr, self._stream())
+        return b.loss
+
     def _ready(self, layer: str) -> None:
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(layer)
 
-    def backward(self, b: _Buffers) -> None:
-        """reverse pass (what tape.gradient does inside Keras fit, train.py:516); fills the g arena."""
+    def backward(self, b: _Buffers, head_done: bool = False) -> None:
+        """reverse pass (what tape.gradient does inside Keras fit, train.py:516); fills the g arena.
+        head_done: dR_0 and the Dense gradients were already produced by head_train."""
         t, n, s, dt, A = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena
         M = b.B * b.H * b.W
-        call("gct2_dense_bwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), b.dpred.data_ptr(), b.dR[0].data_ptr(),
-             b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), s)
+        if not head_done:
+            call("gct2_dense_bwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), b.dpred.data_ptr(), b.dR[0].data_ptr(),
+                 b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), s)
         self._ready("dense")
         for i in range(n):                                      # UpShuffle_i backward, outermost first
             Hi, Wi = b.hw[i + 1]
@@ -388,9 +406,10 @@ class UNetEngine:
         if eps is not None:
             b.eps.copy_(eps.to(self.device, torch.float32))
         self.noise_into_r0(b, x)
-        self.forward(b)
-        loss = self.loss_and_dpred(b, x)
-        self.backward(b)
+        fused = self.fused_head_ok()
+        self.forward(b, head=not fused)
+        loss = self.head_train(b, x) if fused else self.loss_and_dpred(b, x)
+        self.backward(b, head_done=fused)
         if apply:
             self.check_finite()
             self.apply_adam()

@@ -101,6 +101,16 @@ int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const floa
                    int lddx, float* dw, float* db, int M, int Cin, int Cout, int Cmask,
                    void* stream);
 
+/* fused train-step head (16-bit dtypes): dense_fwd + mse_fwd_bwd + dense_bwd in ONE pass over x (= R_0):
+ *   pred = x w + b;  loss = mean((pred - target)^2);  dpred = loss_scale * 2 (pred - target) / (M Cout);
+ *   dx[m, i < Cmask] = (x > 0) * dpred w^T;  dw += x^T dpred;  db += sum dpred.
+ * target: fp32 [M,Cout]; pred: fp32 [M,Cout] or NULL; loss: 1 float; partials: >= 1024 floats scratch.
+ * Replaces train.py:198-202 + 262-272 and their autodiff inside Keras fit (train.py:516). */
+int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, const float* b,
+                          const float* target, float* pred, void* dx, int lddx, float* dw, float* db,
+                          float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
+                          const float* loss_scale_ptr, void* stream);
+
 /* ---- Trainer.call pieces   train.py:223-272 -------------------------------------------------- */
 /* t_int[b] ~ U{1..steps} (train.py:224-226) and eps ~ N(0,1) (train.py:227) from a counter-based
  * Philox4x32-10 stream keyed by (seed, stream_id); `offset` = elements already drawn. */

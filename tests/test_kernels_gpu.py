@@ -278,6 +278,38 @@ def test_dense_fwd_bwd(gpu, dt):
     assert rel_l2(db.cpu().numpy(), dy.sum(0)) <= 2e-5
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("M", [1000, 256 * 5])
+def test_dense_head_train_fused(gpu, dt, M):
+    """fused Dense(3) + MSE + both gradients == the three separate kernels' definitions (ragged last tile at M=1000)."""
+    Cin, Cout, ld, Cmask = 67, 3, 72, 64
+    rng = np.random.default_rng(12)
+    x = rnd(np.maximum(rng.standard_normal((M, Cin)), 0), dt)
+    w = rng.standard_normal((Cin, Cout)).astype(np.float32).astype(np.float64)
+    b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+    tgt = rng.uniform(-1, 1, (M, Cout)).astype(np.float32).astype(np.float64)
+    xb = torch.zeros(M, ld, dtype=TDT[dt], device=gpu)
+    xb[:, :Cin] = dev(x, dt, gpu)
+    t32 = lambda a: torch.tensor(a, dtype=torch.float32, device=gpu)
+    wd, bd, td = t32(w), t32(b), t32(tgt)
+    pred = torch.zeros(M, Cout, device=gpu); dxb = torch.full((M, ld), 5.0, dtype=TDT[dt], device=gpu)
+    dw = torch.zeros(Cin, Cout, device=gpu); db = torch.zeros(Cout, device=gpu)
+    loss = torch.zeros(1, device=gpu); part = torch.zeros(1024, device=gpu)
+    scale = torch.tensor([8.0], device=gpu)
+    lib().call("gct2_dense_head_train", dt, xb.data_ptr(), ld, wd.data_ptr(), bd.data_ptr(), td.data_ptr(), pred.data_ptr(),
+               dxb.data_ptr(), ld, dw.data_ptr(), db.data_ptr(), loss.data_ptr(), part.data_ptr(), M, Cin, Cout, Cmask,
+               scale.data_ptr(), stream())
+    torch.cuda.synchronize()
+    pr = x @ w + b
+    d = pr - tgt
+    dp = 8.0 * 2 * d / d.size
+    assert rel_l2(pred.cpu().numpy(), pr) <= 2e-6
+    assert abs(float(loss[0]) - np.mean(d * d)) <= 2e-6 * np.mean(d * d)
+    assert rel_l2(dxb[:, :Cmask].double().cpu().numpy(), ((dp @ w.T) * (x > 0))[:, :Cmask]) <= TOL_OUT[dt]
+    assert float((dxb[:, Cmask:].float() - 5).abs().max()) == 0
+    assert rel_l2(dw.cpu().numpy(), x.T @ dp) <= 2e-5 and rel_l2(db.cpu().numpy(), dp.sum(0)) <= 2e-5
+
+
 def test_noise_mse(gpu):
     B, HW, C, steps = 5, 64, 3, 200
     rng = np.random.default_rng(9)
