@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="tapgemm tile variant hook (0 auto, 2, 3): A/B timing only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +165,8 @@ def main():
     from gan_class_transfer2_amd.distributed import DataParallelStep
 
     dtype = {"bf16": g.BF16, "f16": g.F16, "f32": g.F32}[args.dtype]
+    if args.variant:
+        _lib.load().gct2_debug_tapgemm_variant(args.variant)
     topo = g.Topology(128, 512, 6)                      # reference defaults, train.py:18-21
     eng = g.UNetEngine(topo, dtype, dev, rng_seed=rank, loss_scaling=(args.dtype == "f16" and world == 1))
     dp = DataParallelStep(eng)

@@ -31,6 +31,7 @@ SIGNATURES = {
     "gct2_device_check": [],
     "gct2_debug_force_direct": [_i],
     "gct2_set_workspace": [_vp, _sz],
+    "gct2_debug_tapgemm_variant": [_i],
     "gct2_conv4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_conv4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_conv4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -68,7 +69,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = None if name == "gct2_debug_force_direct" else _i
+        fn.restype = None if name.startswith("gct2_debug_") else _i
     lib.gct2_last_error.argtypes = []
     lib.gct2_last_error.restype = C.c_char_p
     _lib = lib

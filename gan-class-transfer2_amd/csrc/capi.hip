@@ -8,6 +8,7 @@
 bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p);
 int tapgemm_mfma(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
 int tapgemm_direct(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
+void tapgemm_set_variant(int v);
 bool wgrad_mfma_supported(int dtype, const WgradParams& p);
 int wgrad_mfma(int dtype, WgradParams p, hipStream_t s);
 int wgrad_direct(int dtype, const WgradParams& p, hipStream_t s);
@@ -81,6 +82,7 @@ extern "C" {
 int gct2_abi_version(void) { return 1; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
+void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v); }
 
 int gct2_set_workspace(void* ws, size_t bytes) {
   if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "set_workspace: pointer must be 16-byte aligned");

@@ -107,6 +107,7 @@ struct TapGemmParams {
   int relu, accumulate;
   float* ws; int ksplit;         // split-K: fp32 partial slabs [ksplit][out pixels][N] in the registered workspace
   int m_tiles, n_tiles, xcd_chunk;   // launch geometry (filled by the launcher): see xcd_tile()
+  int ablate;                        // timing-only ablation bits (gct2_debug_tapgemm_variant >> 8)
 };
 
 // XCD-aware work-group -> tile map.  The dispatcher deals consecutive work-group ids round-robin over the 8

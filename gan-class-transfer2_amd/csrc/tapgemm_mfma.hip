@@ -24,31 +24,52 @@
 namespace {
 
 constexpr int BK = 64;
+int g_tapgemm_ablate = 0;                        // timing-only ablation: bit 0 = no DMA in the K loop, bit 1 = no MFMAs (wrong results)
+int g_tapgemm_variant = 0;                       // 0 = auto, 2 = force the 4-wave/2-buffer tile, 3 = force the 8-wave/3-buffer tile
 constexpr unsigned OOB = 0x80000000u;            // >= num_records of every descriptor below
+// s_waitcnt immediate that waits for vmcnt <= n only (expcnt / lgkmcnt fields at their no-wait maxima), gfx9 encoding
+#define VMCNT_ONLY(n) ((((n) & 0xF) | 0x70 | 0xF00 | ((((n) >> 4) & 3) << 14)))
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)OOB, 0x00020000);
 }
+// HIDDEN = false: the builtin; hipcc counts the DMA in its own vmcnt bookkeeping (and drains it to 0 at the head of a
+// loop that keeps more than one step in flight).  HIDDEN = true: the same instruction from inline asm, invisible to
+// that bookkeeping; every wait for it is then placed by hand (the 3-buffer loop).  M0 = LDS address of the piece is
+// written in the same statement that uses it (cdna_hip_programming.md §5.7).
+template <bool HIDDEN>
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
+  if constexpr (HIDDEN) {
+    const unsigned lds_addr = (unsigned)(uintptr_t)(lds_void_t*)lds_piece;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
+                 : "memory", "m0");
+  } else {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
+  }
 }
 
-template <typename T, int FORM, int BM, int BN, int EPI>
-__global__ __launch_bounds__(256, 2) void tapgemm_kernel(TapGemmParams p) {
-  static_assert((BM / 64) * (BN / 64) == 4, "4 waves of 64x64");
+// NBUF = 2: 4 waves (256 threads), 2 work-groups per CU cover each other's DMA latency, vmcnt(0) per step.
+// NBUF = 3: 8 waves (512 threads, 256 x 128 tile), 1 work-group per CU, the DMA of step t+2 stays in flight
+//           across the barrier that publishes step t+1 (counted vmcnt + raw s_barrier).
+template <typename T, int FORM, int BM, int BN, int EPI, int NBUF>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void tapgemm_kernel(TapGemmParams p) {
+  constexpr int NWV = (BM / 64) * (BN / 64);       // waves, each a 64 x 64 sub-tile
+  static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
   static_assert(FORM == FORM_CONVT || BN == 128, "T image is 128 columns wide");
   constexpr int WAVES_N = BN / 64;
-  constexpr int NA = BM / 32;                      // 1-KiB pieces per wave, activation tile (8 rows each)
-  constexpr int NW = (FORM == FORM_CONV) ? 4 : BN / 32;
+  constexpr int NA = BM / 8 / NWV;                 // 1-KiB pieces per wave, activation tile (8 rows each)
+  constexpr int NW = ((FORM == FORM_CONV) ? 16 : BN / 8) / NWV;
+  constexpr int NDMA = NA + NW;                    // DMA instructions per wave per step
   constexpr int A_BYTES = BM * 128;
   constexpr int W_BYTES = (FORM == FORM_CONV) ? 64 * 256 : BN * 128;
   constexpr int NTAPS = (FORM == FORM_CONV) ? 16 : 4;
 
-  // two DISTINCT LDS objects: lets hipcc prove that the DMA into one buffer does not alias the ds_reads of the
-  // other one, so it does not drain vmcnt before every read (cdna_hip_programming.md, "Three .s-level traps" (a))
+  // DISTINCT LDS objects: lets hipcc prove that the DMA into one buffer does not alias the ds_reads of another,
+  // so it does not drain vmcnt before every read (cdna_hip_programming.md, "Three .s-level traps" (a))
   __shared__ __attribute__((aligned(16))) char lds0[A_BYTES + W_BYTES];
-  __shared__ __attribute__((aligned(16))) char lds1[A_BYTES + W_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds1[NBUF >= 2 ? A_BYTES + W_BYTES : 16];
+  __shared__ __attribute__((aligned(16))) char lds2[NBUF == 3 ? A_BYTES + W_BYTES : 16];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,12 +92,12 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(TapGemmParams p) {
   // ---- per-lane DMA descriptors (fixed over the whole K loop) ------------------------------------------
   // activation tile (N image): piece q = wave + 4 i holds rows 8q .. 8q+7; lane -> row 8q + (lane>>3),
   // physical chunk lane&7 = logical chunk ^ ((row>>1)&7)
-  const int a_lchunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+  const int a_lchunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);   // 4*NWV*i is a multiple of 8
   unsigned a_off[NA];                              // byte offset of (row's tap-origin pixel, logical chunk)
   unsigned a_mask[NA];                             // bit t: tap t reads inside the image for this row
 #pragma unroll
   for (int i = 0; i < NA; i++) {
-    const int m = m0 + 8 * (wave + 4 * i) + (lane >> 3);
+    const int m = m0 + 8 * (wave + NWV * i) + (lane >> 3);
     a_off[i] = 0; a_mask[i] = 0;
     if (m < M) {
       const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
@@ -99,13 +120,13 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(TapGemmParams p) {
 #pragma unroll
   for (int i = 0; i < NW; i++) {
     if (FORM == FORM_CONV) {                       // T image: piece = 4 k-rows x 16 chunks
-      const int k = 4 * (wave + 4 * i) + (lane >> 4);
+      const int k = 4 * (wave + NWV * i) + (lane >> 4);
       const int lc = ((((lane & 15) >> 1) ^ timg_swz(k)) << 1) | (lane & 1);
       w_k[i] = k;
       w_nok[i] = (n0 + lc * 8) < N;
       w_off[i] = (unsigned)((k * N + n0 + lc * 8) * 2);
     } else {                                       // N image: piece = 8 n-rows x 8 chunks
-      const int n = 8 * (wave + 4 * i) + (lane >> 3);
+      const int n = 8 * (wave + NWV * i) + (lane >> 3);
       w_k[i] = a_lchunk * 8;                       // first k of this lane's chunk
       w_nok[i] = (n0 + n) < N;
       w_off[i] = (unsigned)(((n0 + n) * K + a_lchunk * 8) * 2);
@@ -131,14 +152,14 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(TapGemmParams p) {
 #pragma unroll
     for (int i = 0; i < NA; i++) {
       const bool ok = a_cok && ((a_mask[i] >> abit) & 1u);
-      dma16(rs_x, abase + (wave + 4 * i) * 1024, ok ? a_off[i] + tapoff : OOB);
+      dma16<NBUF == 3>(rs_x, abase + (wave + NWV * i) * 1024, ok ? a_off[i] + tapoff : OOB);
     }
     char* wbase = abase + A_BYTES;
     const unsigned wtap = (FORM == FORM_CONV) ? (unsigned)(((tap16 * K + c0) * N) * 2) : (unsigned)((tap16 * N * K + c0) * 2);
 #pragma unroll
     for (int i = 0; i < NW; i++) {
       const bool ok = w_nok[i] && (c0 + w_k[i]) < K;
-      dma16(rs_w, wbase + (wave + 4 * i) * 1024, ok ? w_off[i] + wtap : OOB);
+      dma16<NBUF == 3>(rs_w, wbase + (wave + NWV * i) * 1024, ok ? w_off[i] + wtap : OOB);
     }
   };
 
@@ -168,27 +189,69 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(TapGemmParams p) {
         for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
     }
   };
-  if (it_lo < it_hi) issue(it_lo, lds0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int it = it_lo; it < it_hi; it += 2) {      // two steps per trip: buffer roles are compile-time
-    if (it + 1 < it_hi) issue(it + 1, lds1);
-    compute(lds0);
+  if constexpr (NBUF == 1) {
+    // one LDS buffer (32 KiB): no overlap inside a work-group; 4 work-groups per CU cover each other instead
+    for (int it = it_lo; it < it_hi; it++) {
+      if (!(p.ablate & 1) || it == it_lo) issue(it, lds0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (!(p.ablate & 2)) compute(lds0);
+      __syncthreads();
+    }
+  } else if constexpr (NBUF == 2) {
+    if (it_lo < it_hi) issue(it_lo, lds0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (it + 1 >= it_hi) break;
-    if (it + 2 < it_hi) issue(it + 2, lds0);
-    compute(lds1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    for (int it = it_lo; it < it_hi; it += 2) {    // two steps per trip: buffer roles are compile-time
+      if (it + 1 < it_hi && !(p.ablate & 1)) issue(it + 1, lds1);
+      if (!(p.ablate & 2)) compute(lds0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (it + 1 >= it_hi) break;
+      if (it + 2 < it_hi && !(p.ablate & 1)) issue(it + 2, lds0);
+      if (!(p.ablate & 2)) compute(lds1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // step t: issue the DMA of step t+2, run the MFMAs of step t, then wait until only those NDMA newest DMAs are
+    // outstanding (=> this wave's pieces of step t+1 have landed) and meet the other waves at a raw barrier
+    // (a __syncthreads() here would drain vmcnt to 0).  Step t+1 is read only after that barrier.
+    auto step = [&](int it, const char* cur, char* tgt) {
+      const bool more = it + 2 < it_hi;
+      if (more && !(p.ablate & 1)) issue(it + 2, tgt);
+      if (!(p.ablate & 2)) compute(cur);
+      if (more) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(NDMA));   // the builtin (not asm) so hipcc's own vmcnt bookkeeping sees it
+      else __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(0));
+      __builtin_amdgcn_s_barrier();
+    };
+    if (it_lo < it_hi) issue(it_lo, lds0);
+    if (it_lo + 1 < it_hi) {
+      issue(it_lo + 1, lds1);
+      __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(NDMA));
+    } else {
+      __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(0));
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int it = it_lo; it < it_hi; it += 3) {    // three steps per trip: buffer roles are compile-time
+      step(it, lds0, lds2);
+      if (it + 1 >= it_hi) break;
+      step(it + 1, lds1, lds0);
+      if (it + 2 >= it_hi) break;
+      step(it + 2, lds2, lds1);
+    }
   }
 
   // ---- epilogue: lane holds out[m = .. + (lane&15)][n = .. + 4*(lane>>4) + r], r = 0..3 ----
   T* __restrict__ yout = reinterpret_cast<T*>(p.y);
   const T* __restrict__ actp = reinterpret_cast<const T*>(p.act);
+  // an opaque copy of the lane id: keeps hipcc from hoisting the 16 tiles' output addresses above the K loop,
+  // where they would occupy ~100 registers for the whole kernel (spills in the 8-wave variant)
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+    const int m = m0 + wm * 64 + j * 16 + (elane & 15);
     if (m >= M) continue;
     size_t opix;
     if (FORM == FORM_CONV) opix = (size_t)m;
@@ -198,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(TapGemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4);
+      const int n = n0 + wn * 64 + i * 16 + 4 * (elane >> 4);
       if (n >= N) continue;
       f32x4_t v = acc[i][j];
       if (p.ksplit > 1) {   // partial sum: the finalize kernel adds the slabs and applies the epilogue
@@ -232,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(TapGemmParams p) {
       u32x2_t o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
       *reinterpret_cast<u32x2_t*>(yout + opix * p.ldy + n) = o;
     }
+    __builtin_amdgcn_sched_barrier(0);   // one 16-pixel column of the tile at a time: bounds the epilogue's live registers
   }
 }
 
@@ -270,7 +334,7 @@ __global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, 
   *reinterpret_cast<u32x2_t*>(yout + opix * p.ldy + n) = o;
 }
 
-template <typename T, int FORM, int BM, int BN, int EPI>
+template <typename T, int FORM, int BM, int BN, int EPI, int NBUF>
 int launch(TapGemmParams p, hipStream_t s) {
   const int M = p.B * p.Hs * p.Ws;
   constexpr int PH = FORM == FORM_CONVT ? 4 : 1;
@@ -280,6 +344,7 @@ int launch(TapGemmParams p, hipStream_t s) {
   // small-M layers (bottleneck of the U-Net) cannot fill 256 CUs with output tiles: split the reduction
   p.ksplit = 1;
   p.ws = nullptr;
+  p.ablate = g_tapgemm_ablate;
   size_t ws_bytes = 0;
   float* ws = gct2_workspace(&ws_bytes);
   if (ws && tiles < 192 && niter >= 4) {
@@ -297,8 +362,8 @@ int launch(TapGemmParams p, hipStream_t s) {
   p.n_tiles = (p.N + BN - 1) / BN;
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   dim3 grid(8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
-  auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI>;
-  hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, p);
+  auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF>;
+  hipLaunchKernelGGL(kern, grid, dim3((BM / 64) * (BN / 64) * 64), 0, s, p);
   if (p.ksplit > 1) {
     const size_t total = npix * (p.N >> 2);
     hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, npix);
@@ -308,14 +373,40 @@ int launch(TapGemmParams p, hipStream_t s) {
 
 template <typename T>
 int dispatch(int form, int epi, const TapGemmParams& p, hipStream_t s) {
+  // big layers: 256 x 128 tile, 8 waves, 3 LDS buffers; layers with few output pixels keep the 128 x 128 tile
+  // (more work-groups + split-K); N <= 64 (UpShuffle_0) uses the 256 x 64 tile
+  const int M = p.B * p.Hs * p.Ws;
+  const bool big = g_tapgemm_variant == 3;   // measured r01: the 4-wave tile at 2 work-groups per CU is faster (profiles/)
+  // automatic choice (per-layer A/B in scripts/bench_layer.py, profiles/r01_layer_variants.txt): the 256 x 128 single-
+  // buffer tile moves 25 % fewer L2->LDS bytes per FLOP and wins 5-14 % where it still yields >= 2 work-groups per CU,
+  // except for the Conv2D forward (bias epilogue), where the 128 x 128 double-buffered tile stays ahead.
+  const int tiles256 = ((M + 255) / 256) * ((p.N + 127) / 128) * (form == FORM_CONVT ? 4 : 1);
+  const bool auto5 = g_tapgemm_variant == 0 && tiles256 >= 512 && !(form == FORM_CONV && epi == EPI_BIAS_ACT);
+  if ((g_tapgemm_variant == 5 || auto5) && p.N > 64) {   // 256 x 128 tile, 8 waves, one LDS buffer (48 KiB), 2 work-groups per CU
+    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 128, EPI_BIAS_ACT, 1>(p, s)
+                                                      : launch<T, FORM_CONV, 256, 128, EPI_MASK, 1>(p, s);
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 128, EPI_BIAS_ACT, 1>(p, s)
+                               : launch<T, FORM_CONVT, 256, 128, EPI_MASK, 1>(p, s);
+  }
+  if (g_tapgemm_variant == 1) {
+    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 1>(p, s)
+                                                      : launch<T, FORM_CONV, 128, 128, EPI_MASK, 1>(p, s);
+    if (p.N > 64) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT, 1>(p, s)
+                                             : launch<T, FORM_CONVT, 128, 128, EPI_MASK, 1>(p, s);
+  }
   if (form == FORM_CONV) {
-    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT>(p, s)
-                               : launch<T, FORM_CONV, 128, 128, EPI_MASK>(p, s);
+    if (big) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 128, EPI_BIAS_ACT, 3>(p, s)
+                                        : launch<T, FORM_CONV, 256, 128, EPI_MASK, 3>(p, s);
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 2>(p, s)
+                               : launch<T, FORM_CONV, 128, 128, EPI_MASK, 2>(p, s);
   }
   const bool narrow = p.N <= 64;
-  if (epi == EPI_BIAS_ACT)
-    return narrow ? launch<T, FORM_CONVT, 256, 64, EPI_BIAS_ACT>(p, s) : launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT>(p, s);
-  return narrow ? launch<T, FORM_CONVT, 256, 64, EPI_MASK>(p, s) : launch<T, FORM_CONVT, 128, 128, EPI_MASK>(p, s);
+  if (epi == EPI_BIAS_ACT) {
+    if (narrow) return launch<T, FORM_CONVT, 256, 64, EPI_BIAS_ACT, 2>(p, s);
+    return big ? launch<T, FORM_CONVT, 256, 128, EPI_BIAS_ACT, 3>(p, s) : launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT, 2>(p, s);
+  }
+  if (narrow) return launch<T, FORM_CONVT, 256, 64, EPI_MASK, 2>(p, s);
+  return big ? launch<T, FORM_CONVT, 256, 128, EPI_MASK, 3>(p, s) : launch<T, FORM_CONVT, 128, 128, EPI_MASK, 2>(p, s);
 }
 
 }  // namespace
@@ -334,6 +425,8 @@ bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {
   if (src_bytes >= 0x7ff00000u || w_bytes >= 0x7ff00000u) return false;
   return true;
 }
+
+void tapgemm_set_variant(int v) { g_tapgemm_variant = v & 0xff; g_tapgemm_ablate = (v >> 8) & 3; }
 
 int tapgemm_mfma(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s) {
   if (dtype == GCT2_BF16) return dispatch<__bf16>(form, epi, p, s);

@@ -42,6 +42,9 @@ const char* gct2_last_error(void);          /* host string describing the last n
 int gct2_device_check(void);                /* GCT2_OK iff the current device is gfx950 */
 /* test hook: non-zero routes every convolution through the direct (non-MFMA) kernels */
 void gct2_debug_force_direct(int on);
+/* tuning hook: 0 = automatic tile choice, 2 = always the 4-wave / 2-buffer 128x128 tile, 3 = always the 8-wave /
+ * 3-buffer 256x128 tile (same results; used by tests to cover both and by bench.py --variant for A/B timing) */
+void gct2_debug_tapgemm_variant(int v);
 /* optional caller-owned device scratch (16-byte aligned) for the split-K partial sums of layers whose output
  * is too small to fill the chip (the U-Net's bottleneck levels).  Process-wide; kernels that use it must be
  * enqueued on ONE stream at a time.  ws = NULL disables split-K (same results, slower small layers). */

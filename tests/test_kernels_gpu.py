@@ -233,6 +233,42 @@ def test_splitk_bottleneck_layers(gpu, dt):
         L.call("gct2_set_workspace", None, 0)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 5])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 12, 20, 72, 136), (3, 2, 2, 256, 64), (1, 32, 32, 128, 256)])
+def test_tapgemm_tile_variants(gpu, variant, shape):
+    """both tile variants (4-wave/2-buffer 128x128 and 8-wave/3-buffer 256x128 with counted vmcnt) on every use."""
+    B, H, W, Cin, Cout = shape
+    dt = BF16
+    L = lib()
+    L.load().gct2_debug_tapgemm_variant(variant)
+    try:
+        rng = np.random.default_rng(13)
+        x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+        w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+        wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+        b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+        xd, wd, wtd, bd = dev(x, dt, gpu), dev(w, dt, gpu), dev(wt, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
+        y = torch.zeros(B, H // 2, W // 2, Cout, dtype=TDT[dt], device=gpu)
+        L.call("gct2_conv4s2_fwd", dt, xd.data_ptr(), Cin, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), Cout, B, H, W, Cin, Cout, 1, stream())
+        yt = torch.zeros(B, 2 * H, 2 * W, Cout, dtype=TDT[dt], device=gpu)
+        L.call("gct2_convT4s2_fwd", dt, xd.data_ptr(), Cin, wtd.data_ptr(), bd.data_ptr(), yt.data_ptr(), Cout, B, H, W, Cin, Cout, 1, stream())
+        dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+        dx = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
+        L.call("gct2_conv4s2_dgrad", dt, dev(dz, dt, gpu).data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dx.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 0, stream())
+        dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+        dxt = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
+        L.call("gct2_convT4s2_dgrad", dt, dev(dzt, dt, gpu).data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dxt.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 0, stream())
+        torch.cuda.synchronize()
+        assert rel_l2(y.double().cpu().numpy(), np.maximum(O.conv4s2_fwd(x, w, b), 0)) <= TOL_OUT[dt]
+        assert rel_l2(yt.double().cpu().numpy(), np.maximum(O.convT4s2_fwd(x, wt, b), 0)) <= TOL_OUT[dt]
+        assert rel_l2(dx.double().cpu().numpy(), O.conv4s2_bwd(x, w, dz)[0] * (x > 0)) <= TOL_OUT[dt]
+        assert rel_l2(dxt.double().cpu().numpy(), O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)) <= TOL_OUT[dt]
+    finally:
+        L.load().gct2_debug_tapgemm_variant(0)
+
+
 def test_mfma_and_direct_paths_agree(gpu):
     """the same bf16 problem through the MFMA path and the direct path (forced): independent kernels."""
     B, H, W, Cin, Cout = 2, 8, 8, 128, 128
