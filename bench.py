@@ -168,7 +168,7 @@ def main():
     if args.variant:
         _lib.load().gct2_debug_tapgemm_variant(args.variant)
     topo = g.Topology(128, 512, 6)                      # reference defaults, train.py:18-21
-    eng = g.UNetEngine(topo, dtype, dev, rng_seed=rank, loss_scaling=(args.dtype == "f16" and world == 1))
+    eng = g.UNetEngine(topo, dtype, dev, rng_seed=rank, loss_scaling=(args.dtype == "f16"))
     dp = DataParallelStep(eng)
     dp.broadcast_parameters(0)
 

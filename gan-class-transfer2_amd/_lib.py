@@ -45,7 +45,7 @@ SIGNATURES = {
     "gct2_rng_normal": [_u64, _u64, _u64, _vp, _sz, _vp],
     "gct2_noise_image": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gct2_mse_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
-    "gct2_adam_keras_multi": [_vp, _vp, _vp, _vp, _vp, _i, _sz, _f, _f, _f, _f, _vp, _vp, _i, _vp],
+    "gct2_adam_keras_multi": [_vp, _vp, _vp, _vp, _vp, _i, _sz, _f, _f, _f, _f, _f, _vp, _vp, _i, _vp],
     "gct2_cast_from_f32": [_i, _vp, _vp, _sz, _vp],
     "gct2_loss_scale_init": [_vp, _f, _vp],
     "gct2_loss_scale_begin": [_vp, _vp],

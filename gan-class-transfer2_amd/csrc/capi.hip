@@ -9,6 +9,7 @@ bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p);
 int tapgemm_mfma(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
 int tapgemm_direct(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
 void tapgemm_set_variant(int v);
+void wgrad_set_variant(int v);
 bool wgrad_mfma_supported(int dtype, const WgradParams& p);
 int wgrad_mfma(int dtype, WgradParams p, hipStream_t s);
 int wgrad_direct(int dtype, const WgradParams& p, hipStream_t s);
@@ -25,7 +26,7 @@ int pw_mse(const float*, const float*, float*, float*, float*, size_t, const flo
 int pw_dense_head_train(int, const void*, int, const float*, const float*, const float*, float*, void*, int, float*, float*, float*, float*,
                         int, int, int, int, const float*, hipStream_t);
 int pw_colsum(int, const void*, int, float*, size_t, int, hipStream_t);
-int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, const float*, const int32_t*, int, hipStream_t);
+int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const float*, const int32_t*, int, hipStream_t);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
 int pw_ls_init(gct2_loss_scale_state*, float, hipStream_t);
 int pw_ls_begin(gct2_loss_scale_state*, hipStream_t);
@@ -79,10 +80,10 @@ int run_wgrad(int dtype, const WgradParams& p, void* stream) {
 
 extern "C" {
 
-int gct2_abi_version(void) { return 1; }
+int gct2_abi_version(void) { return 2; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
-void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v); }
+void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant(v >> 16); }
 
 int gct2_set_workspace(void* ws, size_t bytes) {
   if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "set_workspace: pointer must be 16-byte aligned");
@@ -213,12 +214,13 @@ int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float
 }
 
 int gct2_adam_keras_multi(float* p, float* m, float* v, float* g, void* shadow, int shadow_dtype, size_t n, float alpha, float beta1,
-                          float beta2, float eps, const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad, void* stream) {
+                          float beta2, float eps, float grad_mul, const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad,
+                          void* stream) {
   if (!p || !m || !v || !g) return gct2_fail(GCT2_EINVAL, "adam_keras_multi: null pointer");
   if (shadow && !dtype_ok(shadow_dtype)) return gct2_fail(GCT2_EINVAL, "adam_keras_multi: bad shadow dtype");
   if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) % 16 || (shadow && (uintptr_t)shadow % 8))
     return gct2_fail(GCT2_EINVAL, "adam_keras_multi: arenas must be 16-byte aligned");
-  return pw_adam(p, m, v, g, shadow, shadow_dtype, n, alpha, beta1, beta2, eps, inv_scale_ptr, found_inf, zero_grad, S(stream));
+  return pw_adam(p, m, v, g, shadow, shadow_dtype, n, alpha, beta1, beta2, eps, grad_mul, inv_scale_ptr, found_inf, zero_grad, S(stream));
 }
 
 int gct2_cast_from_f32(int dtype, const float* src, void* dst, size_t n, void* stream) {

@@ -131,5 +131,7 @@ struct WgradParams {
   const void* small; int ldsmall; // tensor on the SMALL grid, Cs channels
   float* dw;                      // fp32 [16][Cb][Cs]
   int B, Hs, Ws, Cb, Cs;
-  int rsplit;                     // number of r-range splits (gridDim.z)
+  int rsplit;                     // number of r-range splits
+  int ablate;                     // timing-only ablation bits
+  float* ws;                      // partial-tile slabs [rsplit][16*Cb][Cs] in the registered workspace, or null (atomics)
 };

@@ -333,10 +333,11 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ d
 template <typename S, bool HAS_SHADOW>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ g, S* __restrict__ shadow, size_t n, float alpha,
-                                                   float b1, float b2, float eps, const float* __restrict__ inv_scale_ptr,
+                                                   float b1, float b2, float eps, float grad_mul,
+                                                   const float* __restrict__ inv_scale_ptr,
                                                    const int32_t* __restrict__ found_inf, int zero_grad) {
   const bool skip = found_inf && *found_inf != 0;
-  const float inv_scale = inv_scale_ptr ? *inv_scale_ptr : 1.f;
+  const float inv_scale = (inv_scale_ptr ? *inv_scale_ptr : 1.f) * grad_mul;
   const size_t n4 = n >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const float ob1 = 1.f - b1, ob2 = 1.f - b2;
@@ -522,10 +523,10 @@ int pw_colsum(int dtype, const void* dz, int ld, float* db, size_t M, int C, hip
   return colsum_t<_Float16>(dz, ld, db, M, C, s);
 }
 int pw_adam(float* p, float* m, float* v, float* g, void* shadow, int sdt, size_t n, float alpha, float b1, float b2, float eps,
-            const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad, hipStream_t s) {
+            float grad_mul, const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad, hipStream_t s) {
   if (n == 0) return GCT2_OK;
   const int nb = blocks_for(n / 4 + 4, 256);
-#define GCT2_ADAM(S, HS) hipLaunchKernelGGL((adam_kernel<S, HS>), dim3(nb), dim3(256), 0, s, p, m, v, g, reinterpret_cast<S*>(shadow), n, alpha, b1, b2, eps, inv_scale_ptr, found_inf, zero_grad)
+#define GCT2_ADAM(S, HS) hipLaunchKernelGGL((adam_kernel<S, HS>), dim3(nb), dim3(256), 0, s, p, m, v, g, reinterpret_cast<S*>(shadow), n, alpha, b1, b2, eps, grad_mul, inv_scale_ptr, found_inf, zero_grad)
   if (!shadow) GCT2_ADAM(float, false);
   else if (sdt == GCT2_BF16) GCT2_ADAM(__bf16, true);
   else if (sdt == GCT2_F16) GCT2_ADAM(_Float16, true);

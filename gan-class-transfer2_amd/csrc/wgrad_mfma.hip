@@ -15,6 +15,7 @@
 namespace {
 
 constexpr unsigned OOB = 0x80000000u;
+int g_wgrad_variant = 0, g_wgrad_ablate = 0;     // tuning / timing hooks (gct2_debug_tapgemm_variant)
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -24,11 +25,11 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_pie
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
+template <typename T, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradParams p) {
   constexpr int IMG = 64 * 256;
   __shared__ __attribute__((aligned(16))) char lds0[2 * IMG];     // [big image | small image]
-  __shared__ __attribute__((aligned(16))) char lds1[2 * IMG];
+  __shared__ __attribute__((aligned(16))) char lds1[NBUF == 2 ? 2 * IMG : 16];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,22 +120,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     }
   };
 
-  issue(step_lo, lds0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int step = step_lo; step < step_hi; step += 2) {          // two steps per trip: buffer roles are compile-time
-    if (step + 1 < step_hi) issue(step + 1, lds1);
-    compute(lds0);
+  const bool no_dma = p.ablate & 1, no_mfma = p.ablate & 2;      // timing-only ablations (wrong results)
+  if constexpr (NBUF == 1) {
+    // one 32-KiB buffer, 4 work-groups per CU cover each other's DMA latency
+    for (int step = step_lo; step < step_hi; step++) {
+      if (!no_dma || step == step_lo) issue(step, lds0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (!no_mfma) compute(lds0);
+      __syncthreads();
+    }
+  } else {
+    issue(step_lo, lds0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (step + 1 >= step_hi) break;
-    if (step + 2 < step_hi) issue(step + 2, lds0);
-    compute(lds1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    for (int step = step_lo; step < step_hi; step += 2) {        // two steps per trip: buffer roles are compile-time
+      if (step + 1 < step_hi && !no_dma) issue(step + 1, lds1);
+      if (!no_mfma) compute(lds0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (step + 1 >= step_hi) break;
+      if (step + 2 < step_hi && !no_dma) issue(step + 2, lds0);
+      if (!no_mfma) compute(lds1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
+  if (p.ablate & 4) {          // timing-only: keep the accumulators alive but skip the atomics
+    if (acc[0][0][0] == 12345.678f) p.dw[0] = acc[3][3][3] + acc[1][2][0];
+    return;
+  }
   // lane holds dW[gc = .. + 4*(lane>>4) + r][cs = .. + (lane&15)]
+  //   rsplit == 1        : the tile has one owner -> plain read-add-write (no atomic unit, reproducible)
+  //   slabs (p.ws)       : plain stores of the partial tile into slab[split]; wgrad_reduce_kernel adds the slabs in a fixed
+  //                        order (reproducible, and plain stores run ~4x the chip-wide float-atomic rate)
+  //   otherwise          : fp32 atomics
+  float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
+  const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -144,10 +167,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int col = cs0 + wn * 64 + j * 16 + (lane & 15);
-        if (col < Cs) atomicAdd(p.dw + (size_t)row * Cs + col, acc[i][j][r]);
+        if (col >= Cs) continue;
+        float* q = out + (size_t)row * Cs + col;
+        if (mode == 2) *q = acc[i][j][r];
+        else if (mode == 1) *q += acc[i][j][r];
+        else atomicAdd(q, acc[i][j][r]);
       }
     }
   }
+}
+
+// dw[e] += sum_s slab[s][e], 4 elements per thread, slabs added in index order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n4, int nsplit) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4_t a = reinterpret_cast<const f32x4_t*>(ws)[i];
+  for (int s = 1; s < nsplit; s++) a += reinterpret_cast<const f32x4_t*>(ws)[(size_t)s * n4 + i];
+  reinterpret_cast<f32x4_t*>(dw)[i] += a;
 }
 
 }  // namespace
@@ -165,12 +201,34 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
   const int R = p.B * p.Hs * p.Ws;
   const int tiles = ((16 * p.Cb + 127) / 128) * ((p.Cs + 127) / 128);
   const int steps_total = (R + 63) / 64;
-  // aim at ~768 workgroups (3 per CU) but keep >= 4 steps of 64 rows per split
-  int rsplit = (768 + tiles - 1) / tiles;
+  // aim at ~768 workgroups (3 per CU) but keep >= 4 steps of 64 rows per split; one owner per tile once the tiles
+  // alone give every CU a work-group
+  int rsplit = tiles >= 512 ? 1 : (768 + tiles - 1) / tiles;
   rsplit = max(1, min(rsplit, steps_total / 4));
+  const int per = (steps_total + rsplit - 1) / rsplit;
+  rsplit = (steps_total + per - 1) / per;            // every split non-empty (each one owns a slab)
   p.rsplit = rsplit;
+  p.ablate = g_wgrad_ablate;
+  p.ws = nullptr;
+  const size_t n = (size_t)16 * p.Cb * p.Cs;
+  size_t ws_bytes = 0;
+  float* ws = gct2_workspace(&ws_bytes);
+  // measured (scripts/bench_wgrad.py): slabs beat atomics up to ~24 splits; beyond that (UpShuffle_0: 16 tiles x 48
+  // splits) the many 1-MiB slabs cost more than the atomics they replace
+  if (rsplit > 1 && rsplit <= 24 && ws && n % 4 == 0 && (uintptr_t)p.dw % 16 == 0 && n * sizeof(float) * rsplit <= ws_bytes &&
+      g_wgrad_variant != 7)
+    p.ws = ws;
   dim3 grid(rsplit >= 8 ? tiles * 8 * ((rsplit + 7) / 8) : tiles * rsplit);
-  if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad_kernel<__bf16>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(wgrad_kernel<_Float16>, grid, dim3(256), 0, s, p);
+  const bool one_buf = g_wgrad_variant == 1;
+  if (dtype == GCT2_BF16) {
+    if (one_buf) hipLaunchKernelGGL((wgrad_kernel<__bf16, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<__bf16, 2>), grid, dim3(256), 0, s, p);
+  } else {
+    if (one_buf) hipLaunchKernelGGL((wgrad_kernel<_Float16, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<_Float16, 2>), grid, dim3(256), 0, s, p);
+  }
+  if (p.ws) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, p.ws, p.dw, n / 4, rsplit);
   return gct2_check_launch("wgrad_mfma");
 }
+
+void wgrad_set_variant(int v) { g_wgrad_variant = v & 0xff; g_wgrad_ablate = (v >> 8) & 7; }

@@ -83,8 +83,6 @@ class DataParallelStep:
         self.reducer = BucketedAllReducer(A.g, engine.topo.layer_order(), A.layer_ranges, bucket_elems, group)
         engine.grad_ready_hook = self.reducer.grad_ready
         self.world = self.reducer.world
-        if self.world > 1 and engine.ls_state is not None:
-            raise NotImplementedError("dynamic loss scaling across ranks needs a found_inf all-reduce (not built yet)")
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world > 1:
@@ -95,8 +93,16 @@ class DataParallelStep:
         eng, red = self.engine, self.reducer
         red.begin()
         loss = eng.train_step(x, t_int, eps, apply=False)      # backward fires grad_ready per layer
-        for idx in range(len(red.buckets)):
-            lo, hi = red.wait_bucket(idx)
-            eng.apply_adam(lo, hi, grad_div=float(self.world))  # mean over ranks folded into the gradient read
+        if eng.ls_state is not None:
+            # fp16 + dynamic loss scale (train.py:82-83): an inf/nan on ANY rank survives the SUM all-reduce, so the
+            # finite check of the reduced arena gives every rank the same skip decision without a second collective
+            for idx in range(len(red.buckets)):
+                red.wait_bucket(idx)
+            eng.check_finite()
+            eng.apply_adam(grad_div=float(self.world))
+        else:
+            for idx in range(len(red.buckets)):
+                lo, hi = red.wait_bucket(idx)
+                eng.apply_adam(lo, hi, grad_div=float(self.world))  # mean over ranks folded into the gradient read
         eng.finish_step()
         return loss

@@ -354,25 +354,14 @@ class UNetEngine:
         grad_div > 1 folds the data-parallel mean (sum over ranks / world size) into the gradient read."""
         A, s = self.arena, self._stream()
         hi = A.total if hi is None else hi
-        if self.ls_state is not None:
-            if grad_div != 1.0:
-                raise _lib.Gct2Error("loss scaling with data parallelism: average the gradients before unscaling")
+        if self.ls_state is not None:      # device-resident inv_scale / found_inf of the loss-scale state
             inv_ptr, inf_ptr = self.ls_state.data_ptr() + 4, self.ls_state.data_ptr() + 12
         else:
             inv_ptr, inf_ptr = None, None
-        if grad_div != 1.0:
-            inv_ptr = self._const_scalar(1.0 / grad_div).data_ptr()
         shadow = None if A.shadow is None else A.shadow.data_ptr() + 2 * lo
         call("gct2_adam_keras_multi", A.p.data_ptr() + 4 * lo, A.m.data_ptr() + 4 * lo, A.v.data_ptr() + 4 * lo,
              A.g.data_ptr() + 4 * lo, shadow, self.dtype, hi - lo, self.adam_alpha(), self.beta_1, self.beta_2,
-             self.epsilon, inv_ptr, inf_ptr, 1, s)
-
-    def _const_scalar(self, v: float) -> torch.Tensor:
-        if not hasattr(self, "_consts"):
-            self._consts = {}
-        if v not in self._consts:
-            self._consts[v] = torch.tensor([v], dtype=torch.float32, device=self.device)
-        return self._consts[v]
+             self.epsilon, 1.0 / grad_div, inv_ptr, inf_ptr, 1, s)
 
     def finish_step(self) -> None:
         if self.ls_state is not None:

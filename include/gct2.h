@@ -135,13 +135,14 @@ int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float
 
 /* ---- optimizer   train.py:50-65, 75 (Keras Adam + WarmUp) ------------------------------------ */
 /* Keras ResourceApplyAdam over a flat fp32 arena of n parameters:
- *   g' = g * (*inv_scale_ptr or 1);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+ *   g' = g * grad_mul * (*inv_scale_ptr or 1);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
  *   p -= alpha * m / (sqrt(v) + eps),  alpha = lr_k * sqrt(1-b2^t)/(1-b1^t) computed by the host
- *   (lr_k from the WarmUp schedule).  Skipped entirely when *found_inf != 0 (LossScaleOptimizer,
- *   train.py:82-83).  shadow (may be NULL): low-precision copy of p in `shadow_dtype` written in the
- *   same pass.  zero_grad != 0: g is zeroed after use (the wgrad kernels accumulate). */
+ *   (lr_k from the WarmUp schedule).  grad_mul: host scalar (1/world_size turns the all-reduced SUM into the
+ *   data-parallel mean).  Skipped entirely when *found_inf != 0 (LossScaleOptimizer, train.py:82-83).
+ *   shadow (may be NULL): low-precision copy of p in `shadow_dtype` written in the same pass.
+ *   zero_grad != 0: g is zeroed after use (the wgrad kernels accumulate). */
 int gct2_adam_keras_multi(float* p, float* m, float* v, float* g, void* shadow, int shadow_dtype,
-                          size_t n, float alpha, float beta1, float beta2, float eps,
+                          size_t n, float alpha, float beta1, float beta2, float eps, float grad_mul,
                           const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad,
                           void* stream);
 

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gct2.h but not exported"
     # and the ctypes table binds exactly the declared entry points (minus last_error, bound separately)
     assert sorted(set(g._lib.SIGNATURES) | {"gct2_last_error"}) == names
-    assert g._lib.load().gct2_abi_version() == 1
+    assert g._lib.load().gct2_abi_version() == 2
 
 
 def test_argument_validation_needs_no_gpu():
@@ -42,7 +42,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.gct2_convT4s2_fwd(0, 16, 4, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1     # ld < channels
     assert L.gct2_dense_fwd(0, 16, 67, 16, None, 16, 10, 67, 5, None) == 1                 # Cout > 4
     with pytest.raises(g.Gct2Error):
-        g._lib.call("gct2_adam_keras_multi", 4, 16, 16, 16, None, 0, 8, 1e-3, 0.9, 0.999, 1e-7, None, None, 0, None)  # misaligned
+        g._lib.call("gct2_adam_keras_multi", 4, 16, 16, 16, None, 0, 8, 1e-3, 0.9, 0.999, 1e-7, 1.0, None, None, 0, None)  # misaligned
 
 
 def test_product_path_fails_loudly_without_device_or_library(monkeypatch):

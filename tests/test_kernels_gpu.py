@@ -170,6 +170,29 @@ def test_conv4s2_wgrad(gpu, dt, shape):
     assert rel_l2(dw.cpu().numpy(), 2 * dw_ref) <= TOL_F32OUT[dt]
 
 
+@pytest.mark.parametrize("shape", [(4, 32, 32, 64, 128), (2, 16, 16, 72, 136), (4, 8, 8, 256, 512)])
+def test_wgrad_reduction_modes_agree(gpu, shape):
+    """split reduction through workspace slabs (deterministic) == fp32 atomics == oracle; one-owner tiles (rsplit 1)."""
+    B, H, W, Cin, Cout = shape
+    dt = BF16
+    rng = np.random.default_rng(14)
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+    _, dw_ref, _ = O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)
+    xd, dzd = dev(x, dt, gpu), dev(dz, dt, gpu)
+    ws = torch.full((16 << 18,), float("nan"), dtype=torch.float32, device=gpu)
+    res = []
+    for use_ws in (False, True, True):
+        lib().call("gct2_set_workspace", ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0)
+        dw = torch.ones(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)       # running buffer: the call ACCUMULATES
+        lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, stream())
+        torch.cuda.synchronize()
+        res.append(dw.cpu().numpy())
+    lib().call("gct2_set_workspace", None, 0)
+    assert rel_l2(res[0] - 1, dw_ref) <= TOL_F32OUT[dt] and rel_l2(res[1] - 1, dw_ref) <= TOL_F32OUT[dt]
+    assert np.array_equal(res[1], res[2])          # slab path is bitwise reproducible
+
+
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
 @pytest.mark.parametrize("shape", WGRAD_SHAPES)
 def test_convT4s2_wgrad(gpu, dt, shape):
@@ -407,8 +430,9 @@ def test_adam_keras(gpu, sdt):
     t = lambda a: torch.tensor(a, device=gpu)
     pd_, md, vd, gd = t(p), t(m), t(v), t(g)
     sh = torch.zeros(n, dtype=TDT[sdt], device=gpu)
+    gd.mul_(4.0)    # as if summed over 4 data-parallel ranks: grad_mul = 1/4 restores the mean
     lib().call("gct2_adam_keras_multi", pd_.data_ptr(), md.data_ptr(), vd.data_ptr(), gd.data_ptr(), sh.data_ptr(), sdt, n,
-               alpha, cfg.beta_1, cfg.beta_2, cfg.epsilon, None, None, 1, stream())
+               alpha, cfg.beta_1, cfg.beta_2, cfg.epsilon, 0.25, None, None, 1, stream())
     torch.cuda.synchronize()
     assert rel_l2(pd_.cpu().numpy(), pr) <= 1e-6 and rel_l2(md.cpu().numpy(), mr) <= 1e-6 and rel_l2(vd.cpu().numpy(), vr) <= 1e-6
     assert float(gd.abs().max()) == 0                       # zero_grad
@@ -434,7 +458,7 @@ def test_loss_scale_state_machine(gpu):
         L.call("gct2_scale_check_finite", gg.data_ptr(), gg.numel(), st.data_ptr(), stream())
         p_before = p.clone()
         L.call("gct2_adam_keras_multi", p.data_ptr(), m.data_ptr(), v.data_ptr(), gg.data_ptr(), None, 0, 1000, 1e-3, 0.9, 0.999,
-               1e-7, st.data_ptr() + 4, st.data_ptr() + 12, 1, stream())
+               1e-7, 1.0, st.data_ptr() + 4, st.data_ptr() + 12, 1, stream())
         L.call("gct2_loss_scale_update", st.data_ptr(), 3, stream())
         torch.cuda.synchronize()
         finite = bool(torch.isfinite(g).all())

@@ -163,6 +163,28 @@ def test_trainer_compile_fit_api(gpu):
         g.configure(size=256, pixel_size=128, max_size=512, octaves=6, compute_dtype=None)
 
 
+def test_data_parallel_wrapper_single_rank_equals_plain_step(gpu):
+    """DataParallelStep at world size 1 (bucketed, per-bucket Adam) == UNetEngine.train_step (one Adam launch)."""
+    from gan_class_transfer2_amd.distributed import DataParallelStep
+    cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
+    params = O.init_params(cfg, seed=5)
+    outs = []
+    for wrapped in (False, True):
+        eng = make_engine(cfg, 1, gpu)
+        eng.set_params(params)
+        stepper = DataParallelStep(eng, bucket_elems=100_000) if wrapped else eng
+        if wrapped:
+            assert stepper.world == 1 and len(stepper.reducer.buckets) >= 3
+        for step in range(2):
+            x, t_int, eps = O.synthetic_batch(cfg, seed=step)
+            stepper.train_step(torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32))
+        torch.cuda.synchronize()
+        assert eng.iterations == 2
+        outs.append(eng.get_params())
+    for k in outs[0]:
+        assert rel_l2(outs[1][k], outs[0][k]) <= 1e-6, k       # only fp32 atomics order may differ (UpShuffle_0-like splits)
+
+
 def test_fp16_loss_scaling_step(gpu):
     """mixed_precision=True path (train.py:34,43-45,82-83): fp16 operands, dynamic loss scale, finite grads applied."""
     cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
