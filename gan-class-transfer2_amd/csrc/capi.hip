@@ -20,12 +20,13 @@ int rgb_wgrad(int dtype, const WgradParams& p, hipStream_t s);
 int pw_rng_uniform_int(uint64_t, uint64_t, uint64_t, int32_t*, size_t, int, int, hipStream_t);
 int pw_rng_normal(uint64_t, uint64_t, uint64_t, float*, size_t, hipStream_t);
 int pw_noise(int, const float*, const int32_t*, const float*, void*, int, int, int, int, int, hipStream_t);
+int pw_noise_rng(int, const float*, const int32_t*, uint64_t, uint64_t, uint64_t, float*, void*, int, int, int, int, int, hipStream_t);
 int pw_dense_fwd(int, const void*, int, const float*, const float*, float*, int, int, int, hipStream_t);
 int pw_dense_bwd(int, const void*, int, const float*, const float*, void*, int, float*, float*, int, int, int, int, hipStream_t);
 int pw_mse(const float*, const float*, float*, float*, float*, size_t, const float*, hipStream_t);
 int pw_dense_head_train(int, const void*, int, const float*, const float*, const float*, float*, void*, int, float*, float*, float*, float*,
-                        int, int, int, int, const float*, hipStream_t);
-int pw_colsum(int, const void*, int, float*, size_t, int, hipStream_t);
+                        int, int, int, int, const float*, float*, hipStream_t);
+int pw_colsum(int, const void*, int, float*, size_t, int, float, hipStream_t);
 int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const float*, const int32_t*, int, hipStream_t);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
 int pw_ls_init(gct2_loss_scale_state*, float, hipStream_t);
@@ -72,6 +73,26 @@ int run_tapgemm(int dtype, int form, int epi, const TapGemmParams& p, void* stre
   if (!g_force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(dtype, form, epi, p, S(stream));
   return tapgemm_direct(dtype, form, epi, p, S(stream));
 }
+// input-gradient launch with optional fused bias gradient: db (+)= column sums of the masked gradient THIS call produces
+// (channels [0, split) -> db, the rest -> db2).  MFMA path: fused into the epilogue / split-K finalize.  Direct path:
+// column sums of the output view after the launch, minus those before it when the launch accumulates.
+int run_dgrad(int dtype, int form, TapGemmParams p, size_t out_pixels, float* db, int split, float* db2, void* stream) {
+  if (split < 0 || split > p.N) return gct2_fail(GCT2_EINVAL, "dgrad: db_split out of range");
+  if (!g_force_direct && tapgemm_mfma_supported(dtype, p)) {
+    p.db = db; p.db_split = split; p.db2 = db2;
+    return tapgemm_mfma(dtype, form, EPI_MASK, p, S(stream));
+  }
+  const size_t es = esize(dtype);
+  auto sums = [&](float sign) -> int {
+    if (db && split > 0) if (int e = pw_colsum(dtype, p.y, p.ldy, db, out_pixels, split, sign, S(stream))) return e;
+    if (db2 && split < p.N)
+      if (int e = pw_colsum(dtype, (const char*)p.y + (size_t)split * es, p.ldy, db2, out_pixels, p.N - split, sign, S(stream))) return e;
+    return GCT2_OK;
+  };
+  if ((db || db2) && p.accumulate) if (int e = sums(-1.f)) return e;
+  if (int e = tapgemm_direct(dtype, form, EPI_MASK, p, S(stream))) return e;
+  return (db || db2) ? sums(1.f) : GCT2_OK;
+}
 int run_wgrad(int dtype, const WgradParams& p, void* stream) {
   if (!g_force_direct && wgrad_mfma_supported(dtype, p)) return wgrad_mfma(dtype, p, S(stream));
   return wgrad_direct(dtype, p, S(stream));
@@ -80,7 +101,7 @@ int run_wgrad(int dtype, const WgradParams& p, void* stream) {
 
 extern "C" {
 
-int gct2_abi_version(void) { return 2; }
+int gct2_abi_version(void) { return 3; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
 void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant(v >> 16); }
@@ -112,12 +133,12 @@ int gct2_conv4s2_fwd(int dtype, const void* x, int ldx, const void* w, const flo
 }
 
 int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
-                       int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+                       int H, int W, int Cin, int Cout, int accumulate, float* db, int db_split, float* db2, void* stream) {
   if (int e = check_conv_args("conv4s2_dgrad", dtype, dz, w, dx, B, H, W, Cin, Cout)) return e;
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: H=%d W=%d must be even", H, W);
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: ld smaller than channel count");
   TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H / 2, W / 2, Cout, Cin, 0, accumulate};
-  return run_tapgemm(dtype, FORM_CONVT, EPI_MASK, p, stream);
+  return run_dgrad(dtype, FORM_CONVT, p, (size_t)B * H * W, db, db_split, db2, stream);
 }
 
 int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
@@ -129,7 +150,7 @@ int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int ld
   if (!g_force_direct && rgb_wgrad_supported(dtype, p)) {
     if (int e = rgb_wgrad(dtype, p, S(stream))) return e;
   } else if (int e = run_wgrad(dtype, p, stream)) return e;
-  if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, S(stream));
+  if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, 1.f, S(stream));
   return GCT2_OK;
 }
 
@@ -142,11 +163,11 @@ int gct2_convT4s2_fwd(int dtype, const void* x, int ldx, const void* w, const fl
 }
 
 int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
-                        int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+                        int H, int W, int Cin, int Cout, int accumulate, float* db, int db_split, float* db2, void* stream) {
   if (int e = check_conv_args("convT4s2_dgrad", dtype, dz, w, dx, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "convT4s2_dgrad: ld smaller than channel count");
   TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H, W, Cout, Cin, 0, accumulate};
-  return run_tapgemm(dtype, FORM_CONV, EPI_MASK, p, stream);
+  return run_dgrad(dtype, FORM_CONV, p, (size_t)B * H * W, db, db_split, db2, stream);
 }
 
 int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
@@ -155,7 +176,7 @@ int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int l
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: ld smaller than channel count");
   WgradParams p{dz, lddz, x, ldx, dw, B, H, W, Cout, Cin, 1};
   if (int e = run_wgrad(dtype, p, stream)) return e;
-  if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, S(stream));
+  if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, 1.f, S(stream));
   return GCT2_OK;
 }
 
@@ -178,7 +199,7 @@ int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const floa
 
 int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, const float* b, const float* target, float* pred, void* dx,
                           int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
-                          const float* loss_scale_ptr, void* stream) {
+                          const float* loss_scale_ptr, float* db_dx, void* stream) {
   if ((dtype != GCT2_BF16 && dtype != GCT2_F16) || !x || !w || !target || !dx || !dw || !loss || !partials)
     return gct2_fail(GCT2_EINVAL, "dense_head_train: 16-bit dtypes only / null pointer (use dense_fwd + mse_fwd_bwd + dense_bwd)");
   if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout > 4 || ldx < Cin || ldx % 8 || lddx % 8 || Cmask % 8 || Cmask <= 0 || Cmask > Cin ||
@@ -188,7 +209,7 @@ int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, con
   if ((size_t)256 * ldx * 2 + (size_t)256 * Cmask * 2 + 256 * 16 + (size_t)ldx * 16 > 160 * 1024)
     return gct2_fail(GCT2_EINVAL, "dense_head_train: ldx=%d too large for the LDS tile", ldx);
   return pw_dense_head_train(dtype, x, ldx, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, loss_scale_ptr,
-                             S(stream));
+                             db_dx, S(stream));
 }
 
 int gct2_rng_uniform_int(uint64_t seed, uint64_t stream_id, uint64_t offset, int32_t* out, size_t n, int lo, int hi, void* stream) {
@@ -205,6 +226,13 @@ int gct2_noise_image(int dtype, const float* x, const int32_t* t_int, const floa
   if (!dtype_ok(dtype) || !x || !t_int || !eps || !out) return gct2_fail(GCT2_EINVAL, "noise_image: bad dtype or null pointer");
   if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || steps <= 0) return gct2_fail(GCT2_EINVAL, "noise_image: bad shape");
   return pw_noise(dtype, x, t_int, eps, out, ldout, B, HW, C, steps, S(stream));
+}
+
+int gct2_noise_image_rng(int dtype, const float* x, const int32_t* t_int, uint64_t seed, uint64_t stream_id, uint64_t offset,
+                         float* eps_out, void* out, int ldout, int B, int HW, int C, int steps, void* stream) {
+  if (!dtype_ok(dtype) || !x || !t_int || !out) return gct2_fail(GCT2_EINVAL, "noise_image_rng: bad dtype or null pointer");
+  if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || steps <= 0) return gct2_fail(GCT2_EINVAL, "noise_image_rng: bad shape");
+  return pw_noise_rng(dtype, x, t_int, seed, stream_id, offset, eps_out, out, ldout, B, HW, C, steps, S(stream));
 }
 
 int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n,

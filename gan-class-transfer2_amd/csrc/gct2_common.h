@@ -108,6 +108,8 @@ struct TapGemmParams {
   float* ws; int ksplit;         // split-K: fp32 partial slabs [ksplit][out pixels][N] in the registered workspace
   int m_tiles, n_tiles, xcd_chunk;   // launch geometry (filled by the launcher): see xcd_tile()
   int ablate;                        // timing-only ablation bits (gct2_debug_tapgemm_variant >> 8)
+  float* db; int db_split; float* db2;   // EPI_MASK: bias-gradient targets (column sums of the masked result), may be null
+  float* dbws;                           // 64 x N replica rows in the workspace that take the bias-gradient atomics, or null
 };
 
 // XCD-aware work-group -> tile map.  The dispatcher deals consecutive work-group ids round-robin over the 8

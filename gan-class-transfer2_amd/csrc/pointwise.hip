@@ -38,18 +38,38 @@ __global__ void rng_uniform_int_kernel(uint64_t seed, uint64_t stream_id, uint64
 }
 
 // element e uses counter e>>2; lanes (0,1) of the counter feed elements 4c,4c+1, lanes (2,3) feed 4c+2,4c+3
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t stream_id, uint64_t e) {
+  uint32_t r[4];
+  philox4x32_10(seed, stream_id, e >> 2, r);
+  const int pair = (int)((e >> 1) & 1);
+  const float u1 = ((float)(r[2 * pair] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(r[2 * pair + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float rad = sqrtf(-2.0f * logf(u1));
+  const float ang = 6.283185307179586f * u2;
+  return (e & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
 __global__ void rng_normal_kernel(uint64_t seed, uint64_t stream_id, uint64_t offset, float* out, size_t n) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint64_t e = offset + i;
-    uint32_t r[4];
-    philox4x32_10(seed, stream_id, e >> 2, r);
-    const int pair = (int)((e >> 1) & 1);
-    const float u1 = ((float)(r[2 * pair] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(r[2 * pair + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float rad = sqrtf(-2.0f * logf(u1));
-    const float ang = 6.283185307179586f * u2;
-    out[i] = (e & 1) ? rad * sinf(ang) : rad * cosf(ang);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = philox_normal(seed, stream_id, offset + i);
+}
+
+// noising with eps drawn on the fly from the same stream positions rng_normal_kernel would use: one thread per pixel
+template <typename T>
+__global__ void noise_rng_kernel(const float* __restrict__ x, const int32_t* __restrict__ t_int, uint64_t seed, uint64_t stream_id,
+                                 uint64_t offset, float* __restrict__ eps_out, T* __restrict__ out, int ldout, size_t npix, int HW,
+                                 int C, float inv_steps1) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += stride) {
+    const int b = (int)(pix / HW);
+    const float t = (float)t_int[b] * inv_steps1;
+    const float a = (1.f - t) * (1.f - t) * 0.25f;
+    const float sa = sqrtf(a), sb = sqrtf(1.f - a);
+    for (int c = 0; c < C; c++) {
+      const size_t i = pix * C + c;
+      const float e = philox_normal(seed, stream_id, offset + i);
+      if (eps_out) eps_out[i] = e;
+      out[pix * ldout + c] = from_f32<T>(x[i] * sa + e * sb);
+    }
   }
 }
 
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(256) void dense_head_train_kernel(const T* __restri
                                                                float* __restrict__ pred_out, T* __restrict__ dx, int lddx,
                                                                float* __restrict__ dw, float* __restrict__ db,
                                                                float* __restrict__ partials, int M, int Cin, int Cout, int Cmask,
-                                                               const float* __restrict__ loss_scale_ptr) {
+                                                               const float* __restrict__ loss_scale_ptr, float* __restrict__ db_dx) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int nchunk = ld >> 3;                                    // 16-byte chunks per pixel row
   T* xs = reinterpret_cast<T*>(smem_raw);                        // [PIX][ld]
@@ -201,7 +221,7 @@ __global__ __launch_bounds__(256) void dense_head_train_kernel(const T* __restri
   const float gscale = (loss_scale_ptr ? *loss_scale_ptr : 1.f) * 2.0f / ((float)M * (float)Cout);
   const int nout = (Cin + 1) * Cout;
   const int my_i = tid / Cout, my_o = tid - my_i * Cout;
-  float wacc = 0.f, lacc = 0.f;
+  float wacc = 0.f, lacc = 0.f, bacc = 0.f;   // bacc: column sum of the gradient rows for channel tid (db of the layer below)
   const int ntiles = (M + PIX - 1) / PIX;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int mbase = tile * PIX;
@@ -271,11 +291,16 @@ __global__ __launch_bounds__(256) void dense_head_train_kernel(const T* __restri
         for (int pm = 0; pm < npx; pm++) wacc += dps[4 * pm + my_o];
       }
     }
+    if (db_dx && tid >= 256 - Cmask) {           // the last Cmask threads (idle above) sum the stored gradient rows
+      const int c = tid - (256 - Cmask);
+      for (int pm = 0; pm < npx; pm++) bacc += to_f32(dxs[pm * Cmask + c]);
+    }
   }
   if (tid < nout) {
     if (my_i < Cin) atomicAdd(dw + my_i * Cout + my_o, wacc);
     else if (db) atomicAdd(db + my_o, wacc);
   }
+  if (db_dx && tid >= 256 - Cmask) atomicAdd(db_dx + (tid - (256 - Cmask)), bacc);
   for (int off = 32; off > 0; off >>= 1) lacc += __shfl_down(lacc, off, 64);
   __shared__ float lws[4];
   if ((tid & 63) == 0) lws[tid >> 6] = lacc;
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(256) void dense_head_train_kernel(const T* __restri
 // ---- bias gradient: db[c] += sum_m dz[m][c] --------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dz, int ld, float* __restrict__ db, size_t M, int C,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, float sign) {
   // thread = (channel within a 64-wide tile, one of 4 row lanes)
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
@@ -298,12 +323,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dz, i
   __shared__ float ws[256];
   ws[threadIdx.x] = acc;
   __syncthreads();
-  if (rl == 0 && c < C) atomicAdd(db + c, ws[threadIdx.x] + ws[threadIdx.x + 64] + ws[threadIdx.x + 128] + ws[threadIdx.x + 192]);
+  if (rl == 0 && c < C) atomicAdd(db + c, sign * (ws[threadIdx.x] + ws[threadIdx.x + 64] + ws[threadIdx.x + 128] + ws[threadIdx.x + 192]));
 }
 // 16-bit types, 16-byte loads: thread = (8-channel chunk of a 64-wide tile, one of 32 row lanes)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ dz, int ld, float* __restrict__ db, size_t M, int C,
-                                                         int rows_per_block) {
+                                                         int rows_per_block, float sign) {
   const int c8 = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c = blockIdx.x * 64 + c8 * 8;
   const size_t r0 = (size_t)blockIdx.y * rows_per_block;
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ d
 #pragma unroll
     for (int r = 0; r < 32; r++) s += ws[r][threadIdx.x];
     const int cc = blockIdx.x * 64 + threadIdx.x;
-    if (cc < C) atomicAdd(db + cc, s);
+    if (cc < C) atomicAdd(db + cc, sign * s);
   }
 }
 
@@ -439,6 +464,20 @@ int pw_noise(int dtype, const float* x, const int32_t* t, const float* eps, void
   return noise_t<_Float16>(x, t, eps, out, ldout, B, HW, C, steps, s);
 }
 template <typename T>
+static int noise_rng_t(const float* x, const int32_t* t, uint64_t seed, uint64_t sid, uint64_t off, float* eps_out, void* out, int ldout,
+                       int B, int HW, int C, int steps, hipStream_t s) {
+  const size_t npix = (size_t)B * HW;
+  hipLaunchKernelGGL(noise_rng_kernel<T>, dim3(blocks_for(npix, 256)), dim3(256), 0, s, x, t, seed, sid, off, eps_out,
+                     reinterpret_cast<T*>(out), ldout, npix, HW, C, 1.0f / (float)(steps + 1));
+  return gct2_check_launch("noise_image_rng");
+}
+int pw_noise_rng(int dtype, const float* x, const int32_t* t, uint64_t seed, uint64_t sid, uint64_t off, float* eps_out, void* out,
+                 int ldout, int B, int HW, int C, int steps, hipStream_t s) {
+  if (dtype == GCT2_F32) return noise_rng_t<float>(x, t, seed, sid, off, eps_out, out, ldout, B, HW, C, steps, s);
+  if (dtype == GCT2_BF16) return noise_rng_t<__bf16>(x, t, seed, sid, off, eps_out, out, ldout, B, HW, C, steps, s);
+  return noise_rng_t<_Float16>(x, t, seed, sid, off, eps_out, out, ldout, B, HW, C, steps, s);
+}
+template <typename T>
 static int dense_fwd_t(const void* x, int ldx, const float* w, const float* b, float* y, int M, int Cin, int Cout, hipStream_t s) {
   hipLaunchKernelGGL(dense_fwd_kernel<T>, dim3(blocks_for(M, 256)), dim3(256), Cin * 4 * sizeof(float), s, reinterpret_cast<const T*>(x), ldx,
                      w, b, y, M, Cin, Cout);
@@ -471,7 +510,7 @@ int pw_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float*
 template <typename T>
 static int dense_head_train_t(const void* x, int ld, const float* w, const float* b, const float* target, float* pred, void* dx, int lddx,
                               float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask, const float* ls,
-                              hipStream_t s) {
+                              float* db_dx, hipStream_t s) {
   constexpr int PIX = 256;
   const size_t lds = (size_t)PIX * ld * 2 + (size_t)PIX * Cmask * 2 + PIX * 16 + (size_t)ld * 16;
   const int ntiles = (M + PIX - 1) / PIX;
@@ -483,15 +522,15 @@ static int dense_head_train_t(const void* x, int ld, const float* w, const float
     attr_lds = lds;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, reinterpret_cast<const T*>(x), ld, w, b, target, pred, reinterpret_cast<T*>(dx),
-                     lddx, dw, db, partials, M, Cin, Cout, Cmask, ls);
+                     lddx, dw, db, partials, M, Cin, Cout, Cmask, ls, db_dx);
   hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, s, partials, grid, loss, 1.0f / ((float)M * (float)Cout));
   return gct2_check_launch("dense_head_train");
 }
 int pw_dense_head_train(int dtype, const void* x, int ld, const float* w, const float* b, const float* target, float* pred, void* dx,
                         int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
-                        const float* ls, hipStream_t s) {
-  if (dtype == GCT2_BF16) return dense_head_train_t<__bf16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, s);
-  return dense_head_train_t<_Float16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, s);
+                        const float* ls, float* db_dx, hipStream_t s) {
+  if (dtype == GCT2_BF16) return dense_head_train_t<__bf16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, s);
+  return dense_head_train_t<_Float16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, s);
 }
 int pw_mse(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n, const float* ls, hipStream_t s) {
   const int nb = blocks_for(n, 1024) > 1024 ? 1024 : blocks_for(n, 1024);
@@ -500,7 +539,7 @@ int pw_mse(const float* pred, const float* target, float* dpred, float* loss, fl
   return gct2_check_launch("mse_fwd_bwd");
 }
 template <typename T>
-static int colsum_t(const void* dz, int ld, float* db, size_t M, int C, hipStream_t s) {
+static int colsum_t(const void* dz, int ld, float* db, size_t M, int C, float sign, hipStream_t s) {
   const int ctiles = (C + 63) / 64;
   int rblocks = (int)((M + 511) / 512);
   const int cap = (1024 + ctiles - 1) / ctiles;
@@ -510,17 +549,17 @@ static int colsum_t(const void* dz, int ld, float* db, size_t M, int C, hipStrea
   if constexpr (sizeof(T) == 2) {
     if (C % 8 == 0 && ld % 8 == 0 && (uintptr_t)dz % 16 == 0) {
       hipLaunchKernelGGL(colsum_vec_kernel<T>, dim3(ctiles, rblocks), dim3(256), 0, s, reinterpret_cast<const T*>(dz), ld, db, M, C,
-                         rows_per_block);
+                         rows_per_block, sign);
       return gct2_check_launch("colsum_vec");
     }
   }
-  hipLaunchKernelGGL(colsum_kernel<T>, dim3(ctiles, rblocks), dim3(256), 0, s, reinterpret_cast<const T*>(dz), ld, db, M, C, rows_per_block);
+  hipLaunchKernelGGL(colsum_kernel<T>, dim3(ctiles, rblocks), dim3(256), 0, s, reinterpret_cast<const T*>(dz), ld, db, M, C, rows_per_block, sign);
   return gct2_check_launch("colsum");
 }
-int pw_colsum(int dtype, const void* dz, int ld, float* db, size_t M, int C, hipStream_t s) {
-  if (dtype == GCT2_F32) return colsum_t<float>(dz, ld, db, M, C, s);
-  if (dtype == GCT2_BF16) return colsum_t<__bf16>(dz, ld, db, M, C, s);
-  return colsum_t<_Float16>(dz, ld, db, M, C, s);
+int pw_colsum(int dtype, const void* dz, int ld, float* db, size_t M, int C, float sign, hipStream_t s) {
+  if (dtype == GCT2_F32) return colsum_t<float>(dz, ld, db, M, C, sign, s);
+  if (dtype == GCT2_BF16) return colsum_t<__bf16>(dz, ld, db, M, C, sign, s);
+  return colsum_t<_Float16>(dz, ld, db, M, C, sign, s);
 }
 int pw_adam(float* p, float* m, float* v, float* g, void* shadow, int sdt, size_t n, float alpha, float b1, float b2, float eps,
             float grad_mul, const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad, hipStream_t s) {

@@ -21,6 +21,8 @@
 #include "gct2_common.h"
 #include <algorithm>
 
+int pw_colsum(int dtype, const void* dz, int ld, float* db, size_t M, int C, float sign, hipStream_t s);   // pointwise.hip
+
 namespace {
 
 constexpr int BK = 64;
@@ -47,6 +49,12 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_pie
   } else {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
   }
+}
+
+// bias gradient = column sums of the masked gradient a dgrad launch produces: db[n] (+)= sum over pixels.  Channels
+// [0, db_split) go to p.db, the rest to p.db2 (the output of an UpShuffle dgrad spans two layers' pre-activations).
+__device__ __forceinline__ float* db_target(const TapGemmParams& p, int n) {
+  return n < p.db_split ? (p.db ? p.db + n : nullptr) : (p.db2 ? p.db2 + (n - p.db_split) : nullptr);
 }
 
 // NBUF = 2: 4 waves (256 threads), 2 work-groups per CU cover each other's DMA latency, vmcnt(0) per step.
@@ -249,6 +257,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
   // where they would occupy ~100 registers for the whole kernel (spills in the 8-wave variant)
   int elane = lane;
   asm volatile("" : "+v"(elane));
+  f32x4_t bsum[4];                                  // bias-gradient partial sums: [n-fragment i][r], over this lane's pixels
+#pragma unroll
+  for (int i = 0; i < 4; i++) bsum[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int m = m0 + wm * 64 + j * 16 + (elane & 15);
@@ -286,6 +297,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
           if (!(unpack_lo<T>(a2[1]) > 0.f)) v[2] = 0.f;
           if (!(unpack_hi<T>(a2[1]) > 0.f)) v[3] = 0.f;
         }
+        bsum[i] += v;
         if (p.accumulate) {
           const u32x2_t o2 = *reinterpret_cast<const u32x2_t*>(yout + opix * p.ldy + n);
           v[0] += unpack_lo<T>(o2[0]); v[1] += unpack_hi<T>(o2[0]);
@@ -297,41 +309,83 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
     }
     __builtin_amdgcn_sched_barrier(0);   // one 16-pixel column of the tile at a time: bounds the epilogue's live registers
   }
-}
-
-// sums the split-K slabs and applies the epilogue the GEMM kernel skipped; 4 channels per thread
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, size_t npix) {
-  const int N = p.N, n4 = N >> 2;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= npix * n4) return;
-  const size_t opix = idx / n4;
-  const int n = (int)(idx - opix * n4) * 4;
-  f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < p.ksplit; s++) v += *reinterpret_cast<const f32x4_t*>(p.ws + ((size_t)s * npix + opix) * N + n);
-  T* __restrict__ yout = reinterpret_cast<T*>(p.y);
-  if (EPI == EPI_BIAS_ACT) {
-    if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
-    if (p.relu) {
+  if (EPI == EPI_MASK && (p.db || p.db2) && p.ksplit == 1) {
+    // column sums over the wave's 64 pixels: butterfly over the 16 lanes that share (lane>>4), then one atomic per channel
 #pragma unroll
-      for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
-    }
-  } else {
-    if (p.act) {
-      const u32x2_t a2 = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const T*>(p.act) + opix * p.ldact + n);
-      if (!(unpack_lo<T>(a2[0]) > 0.f)) v[0] = 0.f;
-      if (!(unpack_hi<T>(a2[0]) > 0.f)) v[1] = 0.f;
-      if (!(unpack_lo<T>(a2[1]) > 0.f)) v[2] = 0.f;
-      if (!(unpack_hi<T>(a2[1]) > 0.f)) v[3] = 0.f;
-    }
-    if (p.accumulate) {
-      const u32x2_t o2 = *reinterpret_cast<const u32x2_t*>(yout + opix * p.ldy + n);
-      v[0] += unpack_lo<T>(o2[0]); v[1] += unpack_hi<T>(o2[0]);
-      v[2] += unpack_lo<T>(o2[1]); v[3] += unpack_hi<T>(o2[1]);
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float t = bsum[i][r];
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+        const int n = n0 + wn * 64 + i * 16 + 4 * (elane >> 4) + r;
+        if ((elane & 15) == 0 && n < N) {
+          // every work-group of the launch adds to the same N addresses: spread the adds over 64 replica rows in the
+          // workspace (summed by a column-sum kernel afterwards) - direct atomics cost +450 us/step of pure contention
+          float* q = p.dbws ? p.dbws + (size_t)(blockIdx.x & 63) * N + n : db_target(p, n);
+          if (q) atomicAdd(q, t);
+        }
+      }
     }
   }
-  u32x2_t o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-  *reinterpret_cast<u32x2_t*>(yout + opix * p.ldy + n) = o;
+}
+
+// sums the split-K slabs and applies the epilogue the GEMM kernel skipped.  Work-group = 8 pixels x 128 channels,
+// thread = 4 channels of one pixel (split-K layers have few pixels: keep the grid wide), and the bias-gradient
+// column sums of the 8 pixels are reduced in LDS before the atomics.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, size_t npix) {
+  const int N = p.N;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int n = blockIdx.y * 128 + tx * 4;
+  const size_t pix0 = (size_t)blockIdx.x * 8;
+  T* __restrict__ yout = reinterpret_cast<T*>(p.y);
+  f32x4_t bsum = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    for (int k = 0; k < 1; k++) {
+      const size_t opix = pix0 + ty;
+      if (opix >= npix) break;
+      f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < p.ksplit; s++) v += *reinterpret_cast<const f32x4_t*>(p.ws + ((size_t)s * npix + opix) * N + n);
+      if (EPI == EPI_BIAS_ACT) {
+        if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+        }
+      } else {
+        if (p.act) {
+          const u32x2_t a2 = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const T*>(p.act) + opix * p.ldact + n);
+          if (!(unpack_lo<T>(a2[0]) > 0.f)) v[0] = 0.f;
+          if (!(unpack_hi<T>(a2[0]) > 0.f)) v[1] = 0.f;
+          if (!(unpack_lo<T>(a2[1]) > 0.f)) v[2] = 0.f;
+          if (!(unpack_hi<T>(a2[1]) > 0.f)) v[3] = 0.f;
+        }
+        bsum += v;
+        if (p.accumulate) {
+          const u32x2_t o2 = *reinterpret_cast<const u32x2_t*>(yout + opix * p.ldy + n);
+          v[0] += unpack_lo<T>(o2[0]); v[1] += unpack_hi<T>(o2[0]);
+          v[2] += unpack_lo<T>(o2[1]); v[3] += unpack_hi<T>(o2[1]);
+        }
+      }
+      u32x2_t o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+      *reinterpret_cast<u32x2_t*>(yout + opix * p.ldy + n) = o;
+    }
+  }
+  if (EPI == EPI_MASK && (p.db || p.db2)) {
+    __shared__ f32x4_t red[8][32];
+    red[ty][tx] = bsum;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+      f32x4_t t = red[0][tx];
+#pragma unroll
+      for (int k = 1; k < 8; k++) t += red[k][tx];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float* q = db_target(p, n + r);
+        if (q) atomicAdd(q, t[r]);
+      }
+    }
+  }
 }
 
 template <typename T, int FORM, int BM, int BN, int EPI, int NBUF>
@@ -363,10 +417,22 @@ int launch(TapGemmParams p, hipStream_t s) {
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   dim3 grid(8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
   auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF>;
+  // fused bias gradient without split-K: 64 replica rows at the tail of the workspace take the atomics
+  p.dbws = nullptr;
+  const size_t dbws_bytes = (size_t)64 * p.N * sizeof(float);
+  if (EPI == EPI_MASK && (p.db || p.db2) && p.ksplit == 1 && ws && ws_bytes >= dbws_bytes) {
+    p.dbws = ws + (ws_bytes - dbws_bytes) / sizeof(float) / 4 * 4;
+    (void)hipMemsetAsync(p.dbws, 0, dbws_bytes, s);
+  }
   hipLaunchKernelGGL(kern, grid, dim3((BM / 64) * (BN / 64) * 64), 0, s, p);
   if (p.ksplit > 1) {
-    const size_t total = npix * (p.N >> 2);
-    hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, npix);
+    hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)((npix + 7) / 8), (p.N + 127) / 128), dim3(256), 0, s, p, npix);
+  }
+  if (p.dbws) {
+    if (p.db && p.db_split > 0)
+      if (int e = pw_colsum(GCT2_F32, p.dbws, p.N, p.db, 64, p.db_split, 1.f, s)) return e;
+    if (p.db2 && p.db_split < p.N)
+      if (int e = pw_colsum(GCT2_F32, p.dbws + p.db_split, p.N, p.db2, 64, p.N - p.db_split, 1.f, s)) return e;
   }
   return gct2_check_launch("tapgemm_mfma");
 }

@@ -241,6 +241,16 @@ class UNetEngine:
         self.rng_offset_t += b.B
         self.rng_offset_eps += b.eps.numel()
 
+    def sample_and_noise_into_r0(self, b: _Buffers, x: torch.Tensor, keep_eps: bool = False) -> None:
+        """train.py:224-234 in two launches: t_int, then noising with eps drawn inside the kernel (same stream positions
+        as sample_noise + noise_into_r0, bit-identical result, no eps round trip through HBM)."""
+        s, t = self._stream(), self.topo
+        call("gct2_rng_uniform_int", self.rng_seed, 1, self.rng_offset_t, b.t_int.data_ptr(), b.B, 1, self.steps, s)
+        call("gct2_noise_image_rng", self.dtype, x.data_ptr(), b.t_int.data_ptr(), self.rng_seed, 2, self.rng_offset_eps,
+             b.eps.data_ptr() if keep_eps else None, self._slice_ptr(b.R[0], t.fu(0)), b.ld[0], b.B, b.H * b.W, 3, self.steps, s)
+        self.rng_offset_t += b.B
+        self.rng_offset_eps += b.eps.numel()
+
     def noise_into_r0(self, b: _Buffers, x: torch.Tensor) -> None:
         t = self.topo
         call("gct2_noise_image", self.dtype, x.data_ptr(), b.t_int.data_ptr(), b.eps.data_ptr(),
@@ -294,7 +304,8 @@ class UNetEngine:
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
         call("gct2_dense_head_train", self.dtype, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"),
              target.data_ptr(), b.pred.data_ptr(), b.dR[0].data_ptr(), b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"),
-             b.loss.data_ptr(), b.partials.data_ptr(), b.B * b.H * b.W, t.fu(0) + 3, 3, t.fu(0), ls_ptr, self._stream())
+             b.loss.data_ptr(), b.partials.data_ptr(), b.B * b.H * b.W, t.fu(0) + 3, 3, t.fu(0), ls_ptr, A.gptr("U0.b"),
+             self._stream())
         return b.loss
 
     def _ready(self, layer: str) -> None:
@@ -317,11 +328,17 @@ class UNetEngine:
             else:
                 x, ldx, dx, lddx = b.Dlast.data_ptr(), t.fd(i), b.dDlast.data_ptr(), t.fd(i)
             dz, lddz = b.dR[i].data_ptr(), b.ld[i]
-            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), A.gptr(f"U{i}.b"), b.B, Hi, Wi,
-                 t.up_in(i), t.fu(i), s)
+            # bias gradients are column sums of pre-activation gradients: each dgrad launch adds the sums of the tensor
+            # it writes (fused into its epilogue), so only U_0's bias needs the wgrad entry point's db when the head is unfused
+            db_u = A.gptr(f"U{i}.b") if (i == 0 and not head_done) else None
+            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), s)
             self._ready(f"U{i}")
+            if i < n - 1:       # dx = dR_{i+1}: channels [0, Fu_{i+1}) belong to U_{i+1}, the rest to D_i
+                db, split, db2 = A.gptr(f"U{i + 1}.b"), t.fu(i + 1), A.gptr(f"D{i}.b")
+            else:               # dx = gradient of D_{n-1}'s output
+                db, split, db2 = A.gptr(f"D{i}.b"), t.fd(i), None
             call("gct2_convT4s2_dgrad", dt, dz, lddz, A.wptr(f"U{i}.w"), x, ldx, dx, lddx, b.B, Hi, Wi, t.up_in(i),
-                 t.fu(i), 0, s)
+                 t.fu(i), 0, db, split, db2, s)
         for i in reversed(range(n)):                            # DownShuffle_i backward, innermost first
             H, W = b.hw[i]
             if i < n - 1:
@@ -329,12 +346,11 @@ class UNetEngine:
             else:
                 dz, lddz = b.dDlast.data_ptr(), t.fd(i)
             x, ldx = self._slice_ptr(b.R[i], t.fu(i)), b.ld[i]
-            call("gct2_conv4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"D{i}.w"), A.gptr(f"D{i}.b"), b.B, H, W, t.cx(i),
-                 t.fd(i), s)
+            call("gct2_conv4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), s)
             self._ready(f"D{i}")
             if i > 0:                                           # the image itself needs no gradient
                 call("gct2_conv4s2_dgrad", dt, dz, lddz, A.wptr(f"D{i}.w"), x, ldx, self._slice_ptr(b.dR[i], t.fu(i)),
-                     b.ld[i], b.B, H, W, t.cx(i), t.fd(i), 1, s)
+                     b.ld[i], b.B, H, W, t.cx(i), t.fd(i), 1, A.gptr(f"D{i - 1}.b"), t.cx(i), None, s)
 
     # ---- optimizer (train.py:50-65,75) -----------------------------------------------------------
     def learning_rate(self, k: Optional[int] = None) -> float:
@@ -388,13 +404,16 @@ class UNetEngine:
         B, H, W, _ = x.shape
         b = self.buffers(B, H, W)
         self.begin_step()
-        if t_int is None or eps is None:
-            self.sample_noise(b)
-        if t_int is not None:
-            b.t_int.copy_(t_int.to(self.device, torch.int32))
-        if eps is not None:
-            b.eps.copy_(eps.to(self.device, torch.float32))
-        self.noise_into_r0(b, x)
+        if t_int is None and eps is None:
+            self.sample_and_noise_into_r0(b, x)                 # the normal training path: eps never touches HBM
+        else:
+            if t_int is None or eps is None:
+                self.sample_noise(b)
+            if t_int is not None:
+                b.t_int.copy_(t_int.to(self.device, torch.int32))
+            if eps is not None:
+                b.eps.copy_(eps.to(self.device, torch.float32))
+            self.noise_into_r0(b, x)
         fused = self.fused_head_ok()
         self.forward(b, head=not fused)
         loss = self.head_train(b, x) if fused else self.loss_and_dpred(b, x)

@@ -63,10 +63,13 @@ int gct2_conv4s2_fwd(int dtype, const void* x, int ldx, const void* w, const flo
  * dz: [B,H/2,W/2,Cout] PRE-activation gradient;  dx: [B,H,W,Cin] view.
  * act (may be NULL): [B,H,W,Cin] view of the tensor whose ReLU produced x; mask = act > 0, so dx is
  * again a pre-activation gradient.  accumulate != 0: dx += result (skip branch of the concat,
- * train.py:114-119), else dx = result. */
+ * train.py:114-119), else dx = result.
+ * Fused bias gradients (optional): since dx is the gradient w.r.t. the PRE-activation of the layer(s) that produced
+ * `act`, its column sums are those layers' bias gradients.  db (+)= sums of THIS call's masked result over channels
+ * [0, db_split), db2 (+)= over channels [db_split, Cin) (a concat buffer spans two layers); NULL = not wanted. */
 int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act,
                        int ldact, void* dx, int lddx, int B, int H, int W, int Cin, int Cout,
-                       int accumulate, void* stream);
+                       int accumulate, float* db, int db_split, float* db2, void* stream);
 
 /* weight + bias gradient: dw[kh,kw,i,o] += sum_{b,oh,ow} x[b,2oh+kh-1,2ow+kw-1,i]*dz[b,oh,ow,o],
  * db[o] += sum dz[..,o].  dw: fp32 (4,4,Cin,Cout), db: fp32[Cout] or NULL.  ACCUMULATES: the caller
@@ -85,7 +88,7 @@ int gct2_convT4s2_fwd(int dtype, const void* x, int ldx, const void* w, const fl
  * dz: [B,2H,2W,Cout];  dx/act: [B,H,W,Cin] views;  mask/accumulate as for conv4s2_dgrad. */
 int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act,
                         int ldact, void* dx, int lddx, int B, int H, int W, int Cin, int Cout,
-                        int accumulate, void* stream);
+                        int accumulate, float* db, int db_split, float* db2, void* stream);
 
 /* dw[kh,kw,o,i] += sum_{b,ih,iw} x[b,ih,iw,i] * dz[b,2ih+kh-1,2iw+kw-1,o]; db[o] += sum dz. */
 int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
@@ -112,7 +115,8 @@ int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const floa
 int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, const float* b,
                           const float* target, float* pred, void* dx, int lddx, float* dw, float* db,
                           float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
-                          const float* loss_scale_ptr, void* stream);
+                          const float* loss_scale_ptr, float* db_dx /* += column sums of dx, or NULL */,
+                          void* stream);
 
 /* ---- Trainer.call pieces   train.py:223-272 -------------------------------------------------- */
 /* t_int[b] ~ U{1..steps} (train.py:224-226) and eps ~ N(0,1) (train.py:227) from a counter-based
@@ -126,6 +130,13 @@ int gct2_rng_normal(uint64_t seed, uint64_t stream_id, uint64_t offset, float* o
  * x, eps: fp32 [B, HW, C] contiguous; t_int: int32[B]; out: view [B*HW, C] of `dtype` with ldout. */
 int gct2_noise_image(int dtype, const float* x, const int32_t* t_int, const float* eps, void* out,
                      int ldout, int B, int HW, int C, int steps, void* stream);
+
+/* the same with eps drawn inside the kernel from the positions [offset, offset + B*HW*C) of the gct2_rng_normal stream
+ * (seed, stream_id): bit-identical to gct2_rng_normal followed by gct2_noise_image, without the eps round trip through HBM.
+ * eps_out (may be NULL) receives the draws. */
+int gct2_noise_image_rng(int dtype, const float* x, const int32_t* t_int, uint64_t seed, uint64_t stream_id,
+                         uint64_t offset, float* eps_out, void* out, int ldout, int B, int HW, int C, int steps,
+                         void* stream);
 
 /* loss = mean((target - pred)^2) in fp32 (train.py:272); dpred = loss_scale * 2 (pred-target)/n.
  * `loss` (1 float) is overwritten; `partials` is caller scratch of >= 1024 floats.

@@ -1,7 +1,7 @@
 """print the per-dispatch timeline of the last train step in a rocprofv3 kernel-trace CSV (diagnostic)."""
 import csv, sys, re
-rows = list(csv.DictReader(open(sys.argv[1])))
-idx = [i for i, r in enumerate(rows) if 'noise_kernel' in r['Kernel_Name']]
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'noise_' in r['Kernel_Name']]
 seg = rows[idx[-2]:idx[-1]]
 t0 = int(seg[0]['Start_Timestamp']); tot = 0
 def short(n):

@@ -116,7 +116,7 @@ def test_conv4s2_dgrad(gpu, dt, shape, accumulate):
     dzd, wd, actd = dev(dz, dt, gpu), dev(w, dt, gpu), dev(x, dt, gpu)
     dxd = dev(prev, dt, gpu)
     lib().call("gct2_conv4s2_dgrad", dt, dzd.data_ptr(), Cout, wd.data_ptr(), actd.data_ptr(), Cin, dxd.data_ptr(), Cin,
-               B, H, W, Cin, Cout, accumulate, stream())
+               B, H, W, Cin, Cout, accumulate, None, 0, None, stream())
     torch.cuda.synchronize()
     assert rel_l2(dxd.double().cpu().numpy(), ref) <= TOL_OUT[dt]
 
@@ -134,12 +134,12 @@ def test_convT4s2_dgrad(gpu, dt, shape):
     dzd, wd, actd = dev(dz, dt, gpu), dev(w, dt, gpu), dev(x, dt, gpu)
     dxd = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
     lib().call("gct2_convT4s2_dgrad", dt, dzd.data_ptr(), Cout, wd.data_ptr(), actd.data_ptr(), Cin, dxd.data_ptr(), Cin,
-               B, H, W, Cin, Cout, 0, stream())
+               B, H, W, Cin, Cout, 0, None, 0, None, stream())
     torch.cuda.synchronize()
     assert rel_l2(dxd.double().cpu().numpy(), ref) <= TOL_OUT[dt]
     # no mask: plain input gradient
     lib().call("gct2_convT4s2_dgrad", dt, dzd.data_ptr(), Cout, wd.data_ptr(), None, 0, dxd.data_ptr(), Cin,
-               B, H, W, Cin, Cout, 0, stream())
+               B, H, W, Cin, Cout, 0, None, 0, None, stream())
     torch.cuda.synchronize()
     assert rel_l2(dxd.double().cpu().numpy(), dx_ref) <= TOL_OUT[dt]
 
@@ -234,8 +234,9 @@ def test_splitk_bottleneck_layers(gpu, dt):
         dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
         prev = rnd(rng.standard_normal((B, H, W, Cin)), dt)
         dxd = dev(prev, dt, gpu)
-        L.call("gct2_conv4s2_dgrad", dt, dev(dz, dt, gpu).data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dxd.data_ptr(), Cin,
-               B, H, W, Cin, Cout, 1, stream())
+        dz_dev = dev(dz, dt, gpu)     # named: a temporary would be freed (and reused) before the kernel runs
+        L.call("gct2_conv4s2_dgrad", dt, dz_dev.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dxd.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 1, None, 0, None, stream())
         torch.cuda.synchronize()
         assert rel_l2(dxd.double().cpu().numpy(), O.conv4s2_bwd(x, w, dz)[0] * (x > 0) + prev) <= TOL_OUT[dt]
         # Conv2DTranspose forward + its input gradient
@@ -246,9 +247,10 @@ def test_splitk_bottleneck_layers(gpu, dt):
         torch.cuda.synchronize()
         assert rel_l2(yt.double().cpu().numpy(), np.maximum(O.convT4s2_fwd(x, wt, b), 0)) <= TOL_OUT[dt]
         dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+        dzt_dev = dev(dzt, dt, gpu)     # named: a temporary would be freed (and reused) before the kernel runs
         dxt = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
-        L.call("gct2_convT4s2_dgrad", dt, dev(dzt, dt, gpu).data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dxt.data_ptr(), Cin,
-               B, H, W, Cin, Cout, 0, stream())
+        L.call("gct2_convT4s2_dgrad", dt, dzt_dev.data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dxt.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 0, None, 0, None, stream())
         torch.cuda.synchronize()
         assert rel_l2(dxt.double().cpu().numpy(), O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)) <= TOL_OUT[dt]
         assert not bool(torch.isnan(ws).all())                          # the slabs were really used
@@ -276,13 +278,15 @@ def test_tapgemm_tile_variants(gpu, variant, shape):
         yt = torch.zeros(B, 2 * H, 2 * W, Cout, dtype=TDT[dt], device=gpu)
         L.call("gct2_convT4s2_fwd", dt, xd.data_ptr(), Cin, wtd.data_ptr(), bd.data_ptr(), yt.data_ptr(), Cout, B, H, W, Cin, Cout, 1, stream())
         dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+        dz_dev = dev(dz, dt, gpu)       # named: a temporary would be freed (and reused) before the kernel runs
         dx = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
-        L.call("gct2_conv4s2_dgrad", dt, dev(dz, dt, gpu).data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dx.data_ptr(), Cin,
-               B, H, W, Cin, Cout, 0, stream())
+        L.call("gct2_conv4s2_dgrad", dt, dz_dev.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dx.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 0, None, 0, None, stream())
         dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+        dzt_dev = dev(dzt, dt, gpu)
         dxt = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
-        L.call("gct2_convT4s2_dgrad", dt, dev(dzt, dt, gpu).data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dxt.data_ptr(), Cin,
-               B, H, W, Cin, Cout, 0, stream())
+        L.call("gct2_convT4s2_dgrad", dt, dzt_dev.data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dxt.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 0, None, 0, None, stream())
         torch.cuda.synchronize()
         assert rel_l2(y.double().cpu().numpy(), np.maximum(O.conv4s2_fwd(x, w, b), 0)) <= TOL_OUT[dt]
         assert rel_l2(yt.double().cpu().numpy(), np.maximum(O.convT4s2_fwd(x, wt, b), 0)) <= TOL_OUT[dt]
@@ -290,6 +294,51 @@ def test_tapgemm_tile_variants(gpu, variant, shape):
         assert rel_l2(dxt.double().cpu().numpy(), O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)) <= TOL_OUT[dt]
     finally:
         L.load().gct2_debug_tapgemm_variant(0)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape,use_ws", [((2, 16, 16, 64, 128), False), ((1, 12, 20, 72, 136), False), ((4, 4, 4, 512, 256), True),
+                                          ((1, 6, 10, 5, 7), False)])
+def test_dgrad_fused_bias_gradients(gpu, dt, shape, use_ws):
+    """db/db2 of the dgrad entry points = column sums of the masked gradient THIS call produced, split at db_split,
+    on the MFMA epilogue, the split-K finalize kernel (use_ws) and the direct path (fp32 / unaligned), incl. accumulate."""
+    B, H, W, Cin, Cout = shape
+    L = lib()
+    ws = torch.empty(32 << 18, dtype=torch.float32, device=gpu)
+    L.call("gct2_set_workspace", ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0)
+    try:
+        rng = np.random.default_rng(15)
+        x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+        split = (Cin // 2) // 8 * 8 if Cin >= 16 else 2
+        tol = 2e-3 if dt == BF16 else 2e-5
+        # Conv2D input gradient, accumulate into a running buffer
+        w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+        dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+        prev = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+        contrib = O.conv4s2_bwd(x, w, dz)[0] * (x > 0)
+        dxd, dzd, wd, xd = dev(prev, dt, gpu), dev(dz, dt, gpu), dev(w, dt, gpu), dev(x, dt, gpu)   # keep every operand alive
+        db = torch.full((split,), 3.0, device=gpu); db2 = torch.full((Cin - split,), -1.0, device=gpu)
+        L.call("gct2_conv4s2_dgrad", dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin,
+               dxd.data_ptr(), Cin, B, H, W, Cin, Cout, 1, db.data_ptr(), split, db2.data_ptr(), stream())
+        torch.cuda.synchronize()
+        cs = contrib.reshape(-1, Cin).sum(0)
+        scale = np.abs(contrib).reshape(-1, Cin).sum(0).max()
+        assert np.abs(db.cpu().numpy() - 3.0 - cs[:split]).max() <= tol * scale
+        assert np.abs(db2.cpu().numpy() + 1.0 - cs[split:]).max() <= tol * scale
+        assert rel_l2(dxd.double().cpu().numpy(), contrib + prev) <= TOL_OUT[dt]
+        # Conv2DTranspose input gradient, only the second range wanted
+        wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+        dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+        contrib_t = O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)
+        dxt, dztd, wtd = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu), dev(dzt, dt, gpu), dev(wt, dt, gpu)
+        db2.zero_()
+        L.call("gct2_convT4s2_dgrad", dt, dztd.data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin,
+               dxt.data_ptr(), Cin, B, H, W, Cin, Cout, 0, None, split, db2.data_ptr(), stream())
+        torch.cuda.synchronize()
+        cst = contrib_t.reshape(-1, Cin).sum(0)
+        assert np.abs(db2.cpu().numpy() - cst[split:]).max() <= tol * np.abs(contrib_t).reshape(-1, Cin).sum(0).max()
+    finally:
+        L.call("gct2_set_workspace", None, 0)
 
 
 def test_mfma_and_direct_paths_agree(gpu):
@@ -354,10 +403,10 @@ def test_dense_head_train_fused(gpu, dt, M):
     pred = torch.zeros(M, Cout, device=gpu); dxb = torch.full((M, ld), 5.0, dtype=TDT[dt], device=gpu)
     dw = torch.zeros(Cin, Cout, device=gpu); db = torch.zeros(Cout, device=gpu)
     loss = torch.zeros(1, device=gpu); part = torch.zeros(1024, device=gpu)
-    scale = torch.tensor([8.0], device=gpu)
+    scale = torch.tensor([8.0], device=gpu); dbx = torch.zeros(Cmask, device=gpu)
     lib().call("gct2_dense_head_train", dt, xb.data_ptr(), ld, wd.data_ptr(), bd.data_ptr(), td.data_ptr(), pred.data_ptr(),
                dxb.data_ptr(), ld, dw.data_ptr(), db.data_ptr(), loss.data_ptr(), part.data_ptr(), M, Cin, Cout, Cmask,
-               scale.data_ptr(), stream())
+               scale.data_ptr(), dbx.data_ptr(), stream())
     torch.cuda.synchronize()
     pr = x @ w + b
     d = pr - tgt
@@ -367,6 +416,7 @@ def test_dense_head_train_fused(gpu, dt, M):
     assert rel_l2(dxb[:, :Cmask].double().cpu().numpy(), ((dp @ w.T) * (x > 0))[:, :Cmask]) <= TOL_OUT[dt]
     assert float((dxb[:, Cmask:].float() - 5).abs().max()) == 0
     assert rel_l2(dw.cpu().numpy(), x.T @ dp) <= 2e-5 and rel_l2(db.cpu().numpy(), dp.sum(0)) <= 2e-5
+    assert rel_l2(dbx.cpu().numpy(), dxb[:, :Cmask].double().cpu().numpy().sum(0)) <= 1e-5     # column sums of the stored rows
 
 
 def test_noise_mse(gpu):
@@ -391,6 +441,23 @@ def test_noise_mse(gpu):
     d = pred.astype(np.float64) - tgt
     assert abs(float(loss[0]) - np.mean(d * d)) <= 1e-6 * np.mean(d * d)
     assert rel_l2(dp.cpu().numpy(), 2 * d / n) <= 1e-6
+
+
+def test_noise_with_inkernel_rng_is_bit_identical(gpu):
+    """gct2_noise_image_rng == gct2_rng_normal + gct2_noise_image on the same stream positions (and returns the draws)."""
+    B, HW, C, steps, off = 3, 50, 3, 200, 12345
+    n = B * HW * C
+    x = torch.rand(B, HW, C, device=gpu) * 2 - 1
+    t = torch.tensor([1, 77, 200], dtype=torch.int32, device=gpu)
+    eps = torch.zeros(n, device=gpu)
+    lib().call("gct2_rng_normal", 99, 2, off, eps.data_ptr(), n, stream())
+    a = torch.zeros(B * HW, 8, dtype=torch.bfloat16, device=gpu); bb = torch.zeros_like(a)
+    lib().call("gct2_noise_image", BF16, x.data_ptr(), t.data_ptr(), eps.data_ptr(), a.data_ptr() + 2 * 4, 8, B, HW, C, steps, stream())
+    eps2 = torch.zeros(n, device=gpu)
+    lib().call("gct2_noise_image_rng", BF16, x.data_ptr(), t.data_ptr(), 99, 2, off, eps2.data_ptr(), bb.data_ptr() + 2 * 4, 8, B, HW, C,
+               steps, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a, bb) and torch.equal(eps, eps2) and float(a[:, 4:7].float().abs().max()) > 0
 
 
 def test_rng_streams(gpu):
