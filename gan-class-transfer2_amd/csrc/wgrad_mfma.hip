@@ -11,11 +11,13 @@
 // address, out-of-range offset = zero fill) into two LDS buffers, split over r across gridDim.z with fp32
 // atomics into the (pre-zeroed / running) gradient arena.
 #include "gct2_common.h"
+#include <algorithm>
 
 namespace {
 
 constexpr unsigned OOB = 0x80000000u;
 int g_wgrad_variant = 0, g_wgrad_ablate = 0;     // tuning / timing hooks (gct2_debug_tapgemm_variant)
+int g_wgrad_target = 256, g_wgrad_slab_max = 24;  // big-tile work-group target and largest split count reduced through slabs
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -177,6 +179,147 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
   }
 }
 
+// ---- 256 x 256 output tile: 8 waves (2 along gc x 4 along cs), each 128 x 64 (8 x 4 MFMA tiles, 128 accumulator
+// registers).  A 64-row step moves 64 KiB for 8.4 MFLOP = 128 FLOP per L2->LDS byte, twice the 128 x 128 tile: the
+// measured bound of the small tile is the ~20 TB/s L2->LDS path.  Two 64-KiB LDS buffers, one
+// work-group per CU.  Images per buffer: [big gc 0..127 | big gc 128..255 | small cs 0..127 | small cs 128..255].
+template <typename T>
+__global__ __launch_bounds__(512, 2) void wgrad256_kernel(WgradParams p) {
+  constexpr int IMG = 64 * 256;
+  __shared__ __attribute__((aligned(16))) char lds0[4 * IMG];
+  __shared__ __attribute__((aligned(16))) char lds1[4 * IMG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wm = wave >> 2;
+  const int Hs = p.Hs, Ws = p.Ws, Cb = p.Cb, Cs = p.Cs;
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  const int R = p.B * Hs * Ws;
+  const int GC = 16 * Cb;
+  const int tiles_n = (Cs + 255) / 256;
+  const int tiles = ((GC + 255) / 256) * tiles_n;
+  int tile, split;
+  if (p.rsplit >= 8) {            // a whole r-split on one XCD (ids with equal id % 8 share an L2)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % tiles;
+    split = (j / tiles) * 8 + xcd;
+    if (split >= p.rsplit) return;
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
+  const int gc0 = (tile / tiles_n) * 256, cs0 = (tile % tiles_n) * 256;
+  const int steps_total = (R + 63) / 64;
+  const int steps_per = (steps_total + p.rsplit - 1) / p.rsplit;
+  const int step_lo = split * steps_per;
+  const int step_hi = min(steps_total, step_lo + steps_per);
+  if (step_lo >= step_hi) return;
+
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.big), rs_s = make_rsrc(p.small);
+  // piece q = wave + 8 i (i < 2) of every image = rows 4q .. 4q+3; lane -> row 4q + (lane>>4), physical chunk lane&15
+  const int row0 = 4 * wave + (lane >> 4);                       // rows row0 and row0 + 32
+  const int lc = ((((lane & 15) >> 1) ^ timg_swz(row0)) << 1) | (lane & 1);   // same for row0 + 32
+  int kh[2], kw[2], cb[2];
+  bool gc_ok[2], cs_ok[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {                                  // image g of each operand
+    const int gc = gc0 + 128 * g + lc * 8;
+    gc_ok[g] = gc < GC;
+    const int tap = gc_ok[g] ? gc / Cb : 0;
+    cb[g] = gc_ok[g] ? gc - tap * Cb : 0;
+    kh[g] = tap >> 2; kw[g] = tap & 3;
+    cs_ok[g] = (cs0 + 128 * g + lc * 8) < Cs;
+  }
+  const int ldb2 = p.ldbig * 2, lds2 = p.ldsmall * 2;
+  const int adv_w = 64 % Ws, q1 = 64 / Ws, adv_h = q1 % Hs, adv_b = q1 / Hs;
+  int rb[2], rh[2], rw[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int r = step_lo * 64 + row0 + 32 * i;
+    rw[i] = r % Ws; const int t = r / Ws; rh[i] = t % Hs; rb[i] = t / Hs;
+  }
+  auto issue = [&](int step, char* base) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int r = step * 64 + row0 + 32 * i;
+      const bool r_ok = r < R;
+      char* piece = base + (wave + 8 * i) * 1024;
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        const int h = 2 * rh[i] + kh[g] - 1, w = 2 * rw[i] + kw[g] - 1;
+        const bool okb = gc_ok[g] && r_ok && (unsigned)h < (unsigned)Hb && (unsigned)w < (unsigned)Wb;
+        dma16(rs_b, piece + g * IMG, okb ? (unsigned)(((rb[i] * Hb + h) * Wb + w) * ldb2 + cb[g] * 2) : OOB);
+        dma16(rs_s, piece + (2 + g) * IMG, (cs_ok[g] && r_ok) ? (unsigned)(r * lds2 + (cs0 + 128 * g + lc * 8) * 2) : OOB);
+      }
+      rw[i] += adv_w; rh[i] += adv_h; rb[i] += adv_b;
+      if (rw[i] >= Ws) { rw[i] -= Ws; rh[i]++; }
+      if (rh[i] >= Hs) { rh[i] -= Hs; rb[i]++; }
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const char* base) {
+    const char* bimg = base + wm * IMG;                           // this wave's 128 gc rows = one whole big image
+    const char* simg = base + (2 + (wn >> 1)) * IMG;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      u32x4_t sf[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) sf[j] = timg_frag(simg, (wn & 1) * 64 + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const u32x4_t bf = timg_frag(bimg, i * 16, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(bf, sf[j], acc[i][j]);
+      }
+    }
+  };
+
+  const bool no_dma = p.ablate & 1, no_mfma = p.ablate & 2;
+  issue(step_lo, lds0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int step = step_lo; step < step_hi; step += 2) {
+    if (step + 1 < step_hi && !no_dma) issue(step + 1, lds1);
+    if (!no_mfma) compute(lds0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (step + 1 >= step_hi) break;
+    if (step + 2 < step_hi && !no_dma) issue(step + 2, lds0);
+    if (!no_mfma) compute(lds1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (p.ablate & 4) {
+    if (acc[0][0][0] == 12345.678f) p.dw[0] = acc[7][3][3] + acc[1][2][0];
+    return;
+  }
+  float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
+  const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = gc0 + wm * 128 + i * 16 + 4 * (lane >> 4) + r;
+      if (row >= GC) continue;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int col = cs0 + wn * 64 + j * 16 + (lane & 15);
+        if (col >= Cs) continue;
+        float* q = out + (size_t)row * Cs + col;
+        if (mode == 2) *q = acc[i][j][r];
+        else if (mode == 1) *q += acc[i][j][r];
+        else atomicAdd(q, acc[i][j][r]);
+      }
+    }
+  }
+}
+
 // dw[e] += sum_s slab[s][e], 4 elements per thread, slabs added in index order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n4, int nsplit) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,11 +342,18 @@ bool wgrad_mfma_supported(int dtype, const WgradParams& p) {
 
 int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
   const int R = p.B * p.Hs * p.Ws;
-  const int tiles = ((16 * p.Cb + 127) / 128) * ((p.Cs + 127) / 128);
+  // 256 x 256 tile (one work-group per CU) whenever the 128 x 128 tiling would have to split the reduction anyway
+  // (fewer than 512 tiles): measured -10..-22 % on U0/U1/U2/D1/D2 (profiles/r01_wgrad_variants.txt)
+  const int tiles128 = ((16 * p.Cb + 127) / 128) * ((p.Cs + 127) / 128);
+  const int tiles256 = ((16 * p.Cb + 255) / 256) * ((p.Cs + 255) / 256);
+  const int blocks256 = tiles256 * std::max(1, std::min((g_wgrad_target + tiles256 - 1) / tiles256, ((R + 63) / 64) / 4));
+  // ... and only if the big tiling still yields ~one work-group per CU (the 2x2 / 4x4 bottleneck levels have too few pixels)
+  const bool big_tile = g_wgrad_variant == 2 || (g_wgrad_variant == 0 && tiles128 < 512 && blocks256 >= 192);
+  const int tiles = big_tile ? ((16 * p.Cb + 255) / 256) * ((p.Cs + 255) / 256) : ((16 * p.Cb + 127) / 128) * ((p.Cs + 127) / 128);
   const int steps_total = (R + 63) / 64;
-  // aim at ~768 workgroups (3 per CU) but keep >= 4 steps of 64 rows per split; one owner per tile once the tiles
-  // alone give every CU a work-group
-  int rsplit = tiles >= 512 ? 1 : (768 + tiles - 1) / tiles;
+  // aim at ~768 workgroups (3 per CU; 512 for the big tile) but keep >= 4 steps of 64 rows per split; one owner per tile
+  // once the tiles alone give every CU a work-group
+  int rsplit = big_tile ? (g_wgrad_target + tiles - 1) / tiles : (tiles >= 512 ? 1 : (768 + tiles - 1) / tiles);
   rsplit = max(1, min(rsplit, steps_total / 4));
   const int per = (steps_total + rsplit - 1) / rsplit;
   rsplit = (steps_total + per - 1) / per;            // every split non-empty (each one owns a slab)
@@ -215,12 +365,15 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
   float* ws = gct2_workspace(&ws_bytes);
   // measured (scripts/bench_wgrad.py): slabs beat atomics up to ~24 splits; beyond that (UpShuffle_0: 16 tiles x 48
   // splits) the many 1-MiB slabs cost more than the atomics they replace
-  if (rsplit > 1 && rsplit <= 24 && ws && n % 4 == 0 && (uintptr_t)p.dw % 16 == 0 && n * sizeof(float) * rsplit <= ws_bytes &&
+  if (rsplit > 1 && rsplit <= (big_tile ? 64 : g_wgrad_slab_max) && ws && n % 4 == 0 && (uintptr_t)p.dw % 16 == 0 && n * sizeof(float) * rsplit <= ws_bytes &&
       g_wgrad_variant != 7)
     p.ws = ws;
   dim3 grid(rsplit >= 8 ? tiles * 8 * ((rsplit + 7) / 8) : tiles * rsplit);
   const bool one_buf = g_wgrad_variant == 1;
-  if (dtype == GCT2_BF16) {
+  if (big_tile) {
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256_kernel<__bf16>, grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(wgrad256_kernel<_Float16>, grid, dim3(512), 0, s, p);
+  } else if (dtype == GCT2_BF16) {
     if (one_buf) hipLaunchKernelGGL((wgrad_kernel<__bf16, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<__bf16, 2>), grid, dim3(256), 0, s, p);
   } else {
@@ -231,4 +384,9 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
   return gct2_check_launch("wgrad_mfma");
 }
 
-void wgrad_set_variant(int v) { g_wgrad_variant = v & 0xff; g_wgrad_ablate = (v >> 8) & 7; }
+void wgrad_set_variant(int v) {
+  g_wgrad_variant = v & 0xf; g_wgrad_ablate = (v >> 8) & 7;
+  if (v & 0x10) g_wgrad_target = 512;          // experiment bits
+  if (v & 0x20) g_wgrad_slab_max = 64;
+  if (v == 0) { g_wgrad_target = 256; g_wgrad_slab_max = 24; }
+}

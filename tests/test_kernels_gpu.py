@@ -193,6 +193,31 @@ def test_wgrad_reduction_modes_agree(gpu, shape):
     assert np.array_equal(res[1], res[2])          # slab path is bitwise reproducible
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(4, 32, 32, 64, 128), (1, 12, 20, 72, 136), (2, 8, 8, 256, 512)])
+def test_wgrad_tile_variants(gpu, variant, shape):
+    """weight-gradient tile variants: 1 = 128x128 single buffer, 2 = 256x256 (8 waves, 128x64 wave tiles), 3 = 128x128 double buffer."""
+    B, H, W, Cin, Cout = shape
+    dt = BF16
+    L = lib()
+    L.load().gct2_debug_tapgemm_variant(variant << 16)
+    try:
+        rng = np.random.default_rng(16)
+        x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+        dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+        dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+        xd, dzd, dztd = dev(x, dt, gpu), dev(dz, dt, gpu), dev(dzt, dt, gpu)
+        dw = torch.zeros(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)
+        dwt = torch.zeros(4, 4, Cout, Cin, dtype=torch.float32, device=gpu)
+        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, stream())
+        L.call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), Cin, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, stream())
+        torch.cuda.synchronize()
+        assert rel_l2(dw.cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
+        assert rel_l2(dwt.cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
+    finally:
+        L.load().gct2_debug_tapgemm_variant(0)
+
+
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
 @pytest.mark.parametrize("shape", WGRAD_SHAPES)
 def test_convT4s2_wgrad(gpu, dt, shape):
