@@ -31,6 +31,7 @@ SIGNATURES = {
     "gct2_device_check": [],
     "gct2_debug_force_direct": [_i],
     "gct2_set_workspace": [_vp, _sz],
+    "gct2_set_wgrad_workspace": [_vp, _sz],
     "gct2_debug_tapgemm_variant": [_i],
     "gct2_conv4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_conv4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],

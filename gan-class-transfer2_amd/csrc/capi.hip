@@ -38,10 +38,16 @@ static thread_local char g_err[512] = "";
 static int g_force_direct = 0;   // test hook: route every conv through the direct kernels
 static float* g_ws = nullptr;    // caller-owned split-K scratch (gct2_set_workspace)
 static size_t g_ws_bytes = 0;
+static float* g_wws = nullptr;   // optional second scratch for the weight-gradient kernels (gct2_set_wgrad_workspace)
+static size_t g_wws_bytes = 0;
 
 float* gct2_workspace(size_t* bytes) {
   *bytes = g_ws_bytes;
   return g_ws;
+}
+float* gct2_wgrad_workspace(size_t* bytes) {
+  if (g_wws) { *bytes = g_wws_bytes; return g_wws; }
+  return gct2_workspace(bytes);
 }
 
 int gct2_fail(int code, const char* fmt, ...) {
@@ -101,7 +107,7 @@ int run_wgrad(int dtype, const WgradParams& p, void* stream) {
 
 extern "C" {
 
-int gct2_abi_version(void) { return 3; }
+int gct2_abi_version(void) { return 4; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
 void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant(v >> 16); }
@@ -110,6 +116,13 @@ int gct2_set_workspace(void* ws, size_t bytes) {
   if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "set_workspace: pointer must be 16-byte aligned");
   g_ws = ws ? reinterpret_cast<float*>(ws) : nullptr;
   g_ws_bytes = ws ? bytes : 0;
+  return GCT2_OK;
+}
+
+int gct2_set_wgrad_workspace(void* ws, size_t bytes) {
+  if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "set_wgrad_workspace: pointer must be 16-byte aligned");
+  g_wws = ws ? reinterpret_cast<float*>(ws) : nullptr;
+  g_wws_bytes = ws ? bytes : 0;
   return GCT2_OK;
 }
 

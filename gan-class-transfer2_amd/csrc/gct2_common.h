@@ -109,7 +109,7 @@ struct TapGemmParams {
   int m_tiles, n_tiles, xcd_chunk;   // launch geometry (filled by the launcher): see xcd_tile()
   int ablate;                        // timing-only ablation bits (gct2_debug_tapgemm_variant >> 8)
   float* db; int db_split; float* db2;   // EPI_MASK: bias-gradient targets (column sums of the masked result), may be null
-  float* dbws;                           // 64 x N replica rows in the workspace that take the bias-gradient atomics, or null
+  float* dbws;                           // partial bias-gradient rows [m_tiles*phases | finalize rows][N] in the workspace, or null (atomics)
 };
 
 // XCD-aware work-group -> tile map.  The dispatcher deals consecutive work-group ids round-robin over the 8
@@ -126,6 +126,8 @@ __device__ __forceinline__ bool xcd_tile(int id, int m_tiles, int inner, int chu
 
 // caller-registered scratch (gct2_set_workspace); null when absent
 float* gct2_workspace(size_t* bytes);
+// scratch of the weight-gradient kernels: gct2_set_wgrad_workspace's if registered, else the one above
+float* gct2_wgrad_workspace(size_t* bytes);
 
 // wgrad: dw[tap][cb][cs] += sum_r big[pix_big(r,tap)][cb] * small[r][cs], r over the SMALL grid.
 struct WgradParams {

@@ -21,7 +21,6 @@
 #include "gct2_common.h"
 #include <algorithm>
 
-int pw_colsum(int dtype, const void* dz, int ld, float* db, size_t M, int C, float sign, hipStream_t s);   // pointwise.hip
 
 namespace {
 
@@ -60,17 +59,20 @@ __device__ __forceinline__ float* db_target(const TapGemmParams& p, int n) {
 // NBUF = 2: 4 waves (256 threads), 2 work-groups per CU cover each other's DMA latency, vmcnt(0) per step.
 // NBUF = 3: 8 waves (512 threads, 256 x 128 tile), 1 work-group per CU, the DMA of step t+2 stays in flight
 //           across the barrier that publishes step t+1 (counted vmcnt + raw s_barrier).
-template <typename T, int FORM, int BM, int BN, int EPI, int NBUF>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void tapgemm_kernel(TapGemmParams p) {
-  constexpr int NWV = (BM / 64) * (BN / 64);       // waves, each a 64 x 64 sub-tile
+// WM = 64 : every wave owns a 64 (m) x 64 (n) sub-tile;  WM = 128: 128 (m) x 64 (n), used by the 256 x 256 tile
+//           (8 waves; 96 LDS bytes per MFMA instead of 128, half the L2->LDS bytes per flop of the 128 x 128 tile).
+template <typename T, int FORM, int BM, int BN, int EPI, int NBUF, int WM = 64>
+__global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64) ? 4 : (WM == 64 ? 2 : 1)) void tapgemm_kernel(TapGemmParams p) {
+  constexpr int NWV = (BM / WM) * (BN / 64);       // waves, each a WM x 64 sub-tile
+  constexpr int MF = WM / 16;                      // 16-pixel fragments per wave
   static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
-  static_assert(FORM == FORM_CONVT || BN == 128, "T image is 128 columns wide");
+  static_assert(FORM == FORM_CONVT || BN % 128 == 0, "T images are 128 columns wide");
   constexpr int WAVES_N = BN / 64;
   constexpr int NA = BM / 8 / NWV;                 // 1-KiB pieces per wave, activation tile (8 rows each)
-  constexpr int NW = ((FORM == FORM_CONV) ? 16 : BN / 8) / NWV;
+  constexpr int NW = ((FORM == FORM_CONV) ? 16 * (BN / 128) : BN / 8) / NWV;
   constexpr int NDMA = NA + NW;                    // DMA instructions per wave per step
   constexpr int A_BYTES = BM * 128;
-  constexpr int W_BYTES = (FORM == FORM_CONV) ? 64 * 256 : BN * 128;
+  constexpr int W_BYTES = (FORM == FORM_CONV) ? 64 * 256 * (BN / 128) : BN * 128;   // FORM_CONV: BN/128 T images side by side
   constexpr int NTAPS = (FORM == FORM_CONV) ? 16 : 4;
 
   // DISTINCT LDS objects: lets hipcc prove that the DMA into one buffer does not alias the ds_reads of another,
@@ -128,11 +130,13 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
 #pragma unroll
   for (int i = 0; i < NW; i++) {
     if (FORM == FORM_CONV) {                       // T image: piece = 4 k-rows x 16 chunks
-      const int k = 4 * (wave + NWV * i) + (lane >> 4);
+      const int q = wave + NWV * i;                // pieces 0..15 fill image 0 (columns n0..n0+127), 16..31 image 1
+      const int k = 4 * (q & 15) + (lane >> 4);
       const int lc = ((((lane & 15) >> 1) ^ timg_swz(k)) << 1) | (lane & 1);
+      const int nn = n0 + (q >> 4) * 128 + lc * 8;
       w_k[i] = k;
-      w_nok[i] = (n0 + lc * 8) < N;
-      w_off[i] = (unsigned)((k * N + n0 + lc * 8) * 2);
+      w_nok[i] = nn < N;
+      w_off[i] = (unsigned)((k * N + nn) * 2);
     } else {                                       // N image: piece = 8 n-rows x 8 chunks
       const int n = 8 * (wave + NWV * i) + (lane >> 3);
       w_k[i] = a_lchunk * 8;                       // first k of this lane's chunk
@@ -171,11 +175,11 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
     }
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[4][MF];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MF; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // split-K: this workgroup reduces iterations [it_lo, it_hi) only and leaves an fp32 partial slab
   const int it_per = (niter + p.ksplit - 1) / p.ksplit;
@@ -184,17 +188,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
     const char* w_img = a_img + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
-      u32x4_t wf[4], af[4];
+      u32x4_t wf[4], af[MF];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        wf[i] = (FORM == FORM_CONV) ? timg_frag(w_img, wn * 64 + i * 16, kk, lane)
+      for (int i = 0; i < 4; i++)
+        wf[i] = (FORM == FORM_CONV) ? timg_frag(w_img + (wn >> 1) * (64 * 256), (wn & 1) * 64 + i * 16, kk, lane)
                                     : nimg_frag(w_img, wn * 64 + i * 16, kk, lane);
-        af[i] = nimg_frag(a_img, wm * 64 + i * 16, kk, lane);
-      }
+#pragma unroll
+      for (int j = 0; j < MF; j++) af[j] = nimg_frag(a_img, wm * WM + j * 16, kk, lane);
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
+        for (int j = 0; j < MF; j++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
     }
   };
   if constexpr (NBUF == 1) {
@@ -261,8 +265,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
 #pragma unroll
   for (int i = 0; i < 4; i++) bsum[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int m = m0 + wm * 64 + j * 16 + (elane & 15);
+  for (int j = 0; j < MF; j++) {
+    const int m = m0 + wm * WM + j * 16 + (elane & 15);
     if (m >= M) continue;
     size_t opix;
     if (FORM == FORM_CONV) opix = (size_t)m;
@@ -310,28 +314,73 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
     __builtin_amdgcn_sched_barrier(0);   // one 16-pixel column of the tile at a time: bounds the epilogue's live registers
   }
   if (EPI == EPI_MASK && (p.db || p.db2) && p.ksplit == 1) {
-    // column sums over the wave's 64 pixels: butterfly over the 16 lanes that share (lane>>4), then one atomic per channel
+    // column sums over the wave's WM pixels: butterfly over the 16 lanes that share (lane>>4); then the waves of one
+    // tile column meet in LDS (free after the K loop's last barrier) and the work-group stores ONE partial row,
+    // dbws[m_tile * PH + phase][n0 .. n0+BN), summed in a fixed order by dbpart_reduce_kernel: no atomics, no zeroing,
+    // bit-reproducible.  Without a workspace the sums go straight to db with atomics.
+    float* red = reinterpret_cast<float*>(lds0);
+    constexpr int WAVES_M = NWV / WAVES_N;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         float t = bsum[i][r];
         t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-        const int n = n0 + wn * 64 + i * 16 + 4 * (elane >> 4) + r;
-        if ((elane & 15) == 0 && n < N) {
-          // every work-group of the launch adds to the same N addresses: spread the adds over 64 replica rows in the
-          // workspace (summed by a column-sum kernel afterwards) - direct atomics cost +450 us/step of pure contention
-          float* q = p.dbws ? p.dbws + (size_t)(blockIdx.x & 63) * N + n : db_target(p, n);
-          if (q) atomicAdd(q, t);
+        const int c = wn * 64 + i * 16 + 4 * (elane >> 4) + r;
+        if ((elane & 15) == 0) {
+          if (p.dbws) red[wm * BN + c] = t;
+          else if (n0 + c < N) {
+            float* q = db_target(p, n0 + c);
+            if (q) atomicAdd(q, t);
+          }
         }
       }
+    }
+    if (p.dbws) {
+      __syncthreads();
+      if (tid < BN && n0 + tid < N) {
+        float t = red[tid];
+#pragma unroll
+        for (int k = 1; k < WAVES_M; k++) t += red[k * BN + tid];
+        p.dbws[(size_t)(m_tile * PH + phase) * N + n0 + tid] = t;
+      }
+    }
+  }
+}
+
+// db[n] += sum over the partial rows part[rows][N] left by the GEMM epilogue / the split-K finalize (fixed order).
+// Work-group = 32 columns x 128 row lanes; a wave holds 8 row lanes x 8 float4 column quads.
+__global__ __launch_bounds__(1024) void dbpart_reduce_kernel(const float* __restrict__ part, int rows, TapGemmParams p) {
+  const int N = p.N;
+  const int tid = threadIdx.x, cq = tid & 7, rl = tid >> 3;
+  const int n = blockIdx.x * 32 + cq * 4;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  if (n < N)
+    for (int r = rl; r < rows; r += 128) acc += *reinterpret_cast<const f32x4_t*>(part + (size_t)r * N + n);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    float t = acc[k];
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    acc[k] = t;
+  }
+  __shared__ f32x4_t red[16][8];
+  if ((tid & 63) < 8) red[tid >> 6][cq] = acc;
+  __syncthreads();
+  if (tid < 8 && n < N) {
+    f32x4_t t = red[0][tid];
+#pragma unroll
+    for (int k = 1; k < 16; k++) t += red[k][tid];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float* q = db_target(p, n + r);
+      if (q) *q += t[r];
     }
   }
 }
 
 // sums the split-K slabs and applies the epilogue the GEMM kernel skipped.  Work-group = 8 pixels x 128 channels,
 // thread = 4 channels of one pixel (split-K layers have few pixels: keep the grid wide), and the bias-gradient
-// column sums of the 8 pixels are reduced in LDS before the atomics.
+// column sums of the 8 pixels are reduced in LDS into one partial row for dbpart_reduce_kernel.
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, size_t npix) {
   const int N = p.N;
@@ -379,16 +428,19 @@ __global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, 
       f32x4_t t = red[0][tx];
 #pragma unroll
       for (int k = 1; k < 8; k++) t += red[k][tx];
+      if (p.dbws) *reinterpret_cast<f32x4_t*>(p.dbws + (size_t)blockIdx.x * N + n) = t;   // one partial row per work-group row
+      else {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float* q = db_target(p, n + r);
-        if (q) atomicAdd(q, t[r]);
+        for (int r = 0; r < 4; r++) {
+          float* q = db_target(p, n + r);
+          if (q) atomicAdd(q, t[r]);
+        }
       }
     }
   }
 }
 
-template <typename T, int FORM, int BM, int BN, int EPI, int NBUF>
+template <typename T, int FORM, int BM, int BN, int EPI, int NBUF, int WM = 64>
 int launch(TapGemmParams p, hipStream_t s) {
   const int M = p.B * p.Hs * p.Ws;
   constexpr int PH = FORM == FORM_CONVT ? 4 : 1;
@@ -401,10 +453,18 @@ int launch(TapGemmParams p, hipStream_t s) {
   p.ablate = g_tapgemm_ablate;
   size_t ws_bytes = 0;
   float* ws = gct2_workspace(&ws_bytes);
+  p.m_tiles = (M + BM - 1) / BM;
+  p.n_tiles = (p.N + BN - 1) / BN;
+  const bool want_db = EPI == EPI_MASK && (p.db || p.db2);
+  // fused bias gradient: partial rows at the tail of the workspace (one per (m-tile, phase), or per finalize work-group)
+  const size_t fin_rows = (npix + 7) / 8;
+  const size_t dbws_bytes = want_db ? std::max((size_t)p.m_tiles * PH, fin_rows) * p.N * sizeof(float) : 0;
+  const bool db_rows = want_db && ws && ws_bytes >= dbws_bytes + 16;
+  const size_t slab_room = db_rows ? ws_bytes - dbws_bytes - 16 : ws_bytes;
   if (ws && tiles < 192 && niter >= 4) {
     int want = (512 + tiles - 1) / tiles;
     const size_t slab = npix * p.N * sizeof(float);
-    want = (int)std::min<size_t>((size_t)want, ws_bytes / slab);
+    want = (int)std::min<size_t>((size_t)want, slab_room / slab);
     want = std::min(want, niter / 2);
     if (want >= 2) {
       const int per = (niter + want - 1) / want;
@@ -412,27 +472,17 @@ int launch(TapGemmParams p, hipStream_t s) {
       p.ws = ws;
     }
   }
-  p.m_tiles = (M + BM - 1) / BM;
-  p.n_tiles = (p.N + BN - 1) / BN;
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   dim3 grid(8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
-  auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF>;
-  // fused bias gradient without split-K: 64 replica rows at the tail of the workspace take the atomics
-  p.dbws = nullptr;
-  const size_t dbws_bytes = (size_t)64 * p.N * sizeof(float);
-  if (EPI == EPI_MASK && (p.db || p.db2) && p.ksplit == 1 && ws && ws_bytes >= dbws_bytes) {
-    p.dbws = ws + (ws_bytes - dbws_bytes) / sizeof(float) / 4 * 4;
-    (void)hipMemsetAsync(p.dbws, 0, dbws_bytes, s);
-  }
-  hipLaunchKernelGGL(kern, grid, dim3((BM / 64) * (BN / 64) * 64), 0, s, p);
+  auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF, WM>;
+  p.dbws = db_rows ? ws + (ws_bytes - dbws_bytes) / sizeof(float) / 4 * 4 : nullptr;
+  hipLaunchKernelGGL(kern, grid, dim3((BM / WM) * (BN / 64) * 64), 0, s, p);
   if (p.ksplit > 1) {
-    hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)((npix + 7) / 8), (p.N + 127) / 128), dim3(256), 0, s, p, npix);
+    hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)fin_rows, (p.N + 127) / 128), dim3(256), 0, s, p, npix);
   }
   if (p.dbws) {
-    if (p.db && p.db_split > 0)
-      if (int e = pw_colsum(GCT2_F32, p.dbws, p.N, p.db, 64, p.db_split, 1.f, s)) return e;
-    if (p.db2 && p.db_split < p.N)
-      if (int e = pw_colsum(GCT2_F32, p.dbws + p.db_split, p.N, p.db2, 64, p.N - p.db_split, 1.f, s)) return e;
+    const int rows = p.ksplit > 1 ? (int)fin_rows : p.m_tiles * PH;
+    hipLaunchKernelGGL(dbpart_reduce_kernel, dim3((p.N + 31) / 32), dim3(1024), 0, s, p.dbws, rows, p);
   }
   return gct2_check_launch("tapgemm_mfma");
 }
@@ -453,6 +503,15 @@ int dispatch(int form, int epi, const TapGemmParams& p, hipStream_t s) {
                                                       : launch<T, FORM_CONV, 256, 128, EPI_MASK, 1>(p, s);
     return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 128, EPI_BIAS_ACT, 1>(p, s)
                                : launch<T, FORM_CONVT, 256, 128, EPI_MASK, 1>(p, s);
+  }
+  // 256 x 256 tile, 8 waves of 128 x 64, two 64-KiB LDS buffers, one work-group per CU
+  const int tiles6 = ((M + 255) / 256) * ((p.N + 255) / 256) * (form == FORM_CONVT ? 4 : 1);
+  const bool auto6 = false && tiles6 >= 192;
+  if ((g_tapgemm_variant == 6 || auto6) && p.N >= 256) {
+    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 256, EPI_BIAS_ACT, 2, 128>(p, s)
+                                                      : launch<T, FORM_CONV, 256, 256, EPI_MASK, 2, 128>(p, s);
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 256, EPI_BIAS_ACT, 2, 128>(p, s)
+                               : launch<T, FORM_CONVT, 256, 256, EPI_MASK, 2, 128>(p, s);
   }
   if (g_tapgemm_variant == 1) {
     if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 1>(p, s)

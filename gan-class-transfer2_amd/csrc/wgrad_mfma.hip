@@ -362,7 +362,7 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
   p.ws = nullptr;
   const size_t n = (size_t)16 * p.Cb * p.Cs;
   size_t ws_bytes = 0;
-  float* ws = gct2_workspace(&ws_bytes);
+  float* ws = gct2_wgrad_workspace(&ws_bytes);
   // measured (scripts/bench_wgrad.py): slabs beat atomics up to ~24 splits; beyond that (UpShuffle_0: 16 tiles x 48
   // splits) the many 1-MiB slabs cost more than the atomics they replace
   if (rsplit > 1 && rsplit <= (big_tile ? 64 : g_wgrad_slab_max) && ws && n % 4 == 0 && (uintptr_t)p.dw % 16 == 0 && n * sizeof(float) * rsplit <= ws_bytes &&

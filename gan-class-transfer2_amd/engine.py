@@ -171,6 +171,14 @@ class UNetEngine:
         self.workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
         call("gct2_set_workspace", self.workspace.data_ptr() if workspace_mb else None,
              self.workspace.numel() * 4 if workspace_mb else 0)
+        # second stream + its own scratch: the weight-gradient kernels (and, single-GPU, the per-layer Adam launches) run
+        # beside the dgrad chain instead of between its links (backward())
+        self.overlap = True
+        self._side = torch.cuda.Stream(device=self.device)
+        self.wgrad_workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
+        call("gct2_set_wgrad_workspace", self.wgrad_workspace.data_ptr() if workspace_mb else None,
+             self.wgrad_workspace.numel() * 4 if workspace_mb else 0)
+        self.adam_merge_elems = 2 << 20    # inline Adam launches cover at least this many parameters
         self.ls_state = None
         if loss_scaling:
             self.ls_state = torch.zeros(4, dtype=torch.int32, device=self.device)  # 16-byte gct2_loss_scale_state
@@ -312,15 +320,42 @@ class UNetEngine:
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(layer)
 
-    def backward(self, b: _Buffers, head_done: bool = False) -> None:
+    def backward(self, b: _Buffers, head_done: bool = False, adam_inline: bool = False) -> None:
         """reverse pass (what tape.gradient does inside Keras fit, train.py:516); fills the g arena.
-        head_done: dR_0 and the Dense gradients were already produced by head_train."""
-        t, n, s, dt, A = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena
+        head_done: dR_0 and the Dense gradients were already produced by head_train.
+
+        Two streams: the dgrad chain (the only true dependency chain of the reverse pass) stays on the current stream;
+        every weight gradient is enqueued on the side stream behind an event of the dgrad launch that produced its dz, so
+        its work-groups fill the tails and the small bottleneck launches of the chain.  adam_inline (single GPU, no loss
+        scaling): a layer's Adam update follows on the side stream once its dgrad (the last reader of its weights) is
+        done.  The current stream joins the side stream before returning."""
+        t, n, dt, A = self.topo, self.topo.octaves, self.dtype, self.arena
+        main = torch.cuda.current_stream(self.device)
+        side = self._side if self.overlap else main
+        s, sw = main.cuda_stream, side.cuda_stream
         M = b.B * b.H * b.W
         if not head_done:
             call("gct2_dense_bwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), b.dpred.data_ptr(), b.dR[0].data_ptr(),
                  b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), s)
         self._ready("dense")
+        adam_lo = 0                                             # arena prefix [0, adam_lo) already updated
+
+        def side_waits_main() -> None:                          # side stream: everything enqueued on main so far is visible
+            if side is not main:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+
+        def adam_upto(layer: Optional[str], force: bool = False) -> None:
+            nonlocal adam_lo
+            if not adam_inline:
+                return
+            hi = A.total if layer is None else A.layer_ranges[layer][1]
+            if hi > adam_lo and (force or hi - adam_lo >= self.adam_merge_elems):
+                self.apply_adam(adam_lo, hi, stream=sw)
+                adam_lo = hi
+
+        prev: Optional[str] = "dense"                           # layers whose weights have no reader left on main
         for i in range(n):                                      # UpShuffle_i backward, outermost first
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
@@ -331,14 +366,18 @@ class UNetEngine:
             # bias gradients are column sums of pre-activation gradients: each dgrad launch adds the sums of the tensor
             # it writes (fused into its epilogue), so only U_0's bias needs the wgrad entry point's db when the head is unfused
             db_u = A.gptr(f"U{i}.b") if (i == 0 and not head_done) else None
-            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), s)
-            self._ready(f"U{i}")
+            side_waits_main()                                   # dz (and this layer's bias gradient) are complete
+            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), sw)
+            with torch.cuda.stream(side):
+                self._ready(f"U{i}")
+            adam_upto(prev)
             if i < n - 1:       # dx = dR_{i+1}: channels [0, Fu_{i+1}) belong to U_{i+1}, the rest to D_i
                 db, split, db2 = A.gptr(f"U{i + 1}.b"), t.fu(i + 1), A.gptr(f"D{i}.b")
             else:               # dx = gradient of D_{n-1}'s output
                 db, split, db2 = A.gptr(f"D{i}.b"), t.fd(i), None
             call("gct2_convT4s2_dgrad", dt, dz, lddz, A.wptr(f"U{i}.w"), x, ldx, dx, lddx, b.B, Hi, Wi, t.up_in(i),
                  t.fu(i), 0, db, split, db2, s)
+            prev = f"U{i}"
         for i in reversed(range(n)):                            # DownShuffle_i backward, innermost first
             H, W = b.hw[i]
             if i < n - 1:
@@ -346,11 +385,18 @@ class UNetEngine:
             else:
                 dz, lddz = b.dDlast.data_ptr(), t.fd(i)
             x, ldx = self._slice_ptr(b.R[i], t.fu(i)), b.ld[i]
-            call("gct2_conv4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), s)
-            self._ready(f"D{i}")
+            side_waits_main()
+            call("gct2_conv4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), sw)
+            with torch.cuda.stream(side):
+                self._ready(f"D{i}")
+            adam_upto(prev)
             if i > 0:                                           # the image itself needs no gradient
                 call("gct2_conv4s2_dgrad", dt, dz, lddz, A.wptr(f"D{i}.w"), x, ldx, self._slice_ptr(b.dR[i], t.fu(i)),
                      b.ld[i], b.B, H, W, t.cx(i), t.fd(i), 1, A.gptr(f"D{i - 1}.b"), t.cx(i), None, s)
+            prev = f"D{i}"
+        adam_upto(None, force=True)                             # D_0 has no dgrad: nothing on main reads the weights any more
+        if side is not main:
+            main.wait_stream(side)
 
     # ---- optimizer (train.py:50-65,75) -----------------------------------------------------------
     def learning_rate(self, k: Optional[int] = None) -> float:
@@ -365,10 +411,10 @@ class UNetEngine:
         tt = k + 1
         return self.learning_rate(k) * math.sqrt(1.0 - self.beta_2 ** tt) / (1.0 - self.beta_1 ** tt)
 
-    def apply_adam(self, lo: int = 0, hi: Optional[int] = None, grad_div: float = 1.0) -> None:
+    def apply_adam(self, lo: int = 0, hi: Optional[int] = None, grad_div: float = 1.0, stream: Optional[int] = None) -> None:
         """Keras Adam on arena range [lo, hi); does not advance `iterations` (see finish_step).
         grad_div > 1 folds the data-parallel mean (sum over ranks / world size) into the gradient read."""
-        A, s = self.arena, self._stream()
+        A, s = self.arena, (self._stream() if stream is None else stream)
         hi = A.total if hi is None else hi
         if self.ls_state is not None:      # device-resident inv_scale / found_inf of the loss-scale state
             inv_ptr, inf_ptr = self.ls_state.data_ptr() + 4, self.ls_state.data_ptr() + 12
@@ -417,10 +463,14 @@ class UNetEngine:
         fused = self.fused_head_ok()
         self.forward(b, head=not fused)
         loss = self.head_train(b, x) if fused else self.loss_and_dpred(b, x)
-        self.backward(b, head_done=fused)
+        # single GPU without loss scaling: Adam rides the side stream inside backward(); the loss-scaled step has to see
+        # every gradient (finite check) before any update
+        inline = apply and self.overlap and self.ls_state is None
+        self.backward(b, head_done=fused, adam_inline=inline)
         if apply:
-            self.check_finite()
-            self.apply_adam()
+            if not inline:
+                self.check_finite()
+                self.apply_adam()
             self.finish_step()
         return loss
 

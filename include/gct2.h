@@ -42,13 +42,19 @@ const char* gct2_last_error(void);          /* host string describing the last n
 int gct2_device_check(void);                /* GCT2_OK iff the current device is gfx950 */
 /* test hook: non-zero routes every convolution through the direct (non-MFMA) kernels */
 void gct2_debug_force_direct(int on);
-/* tuning hook: 0 = automatic tile choice, 2 = always the 4-wave / 2-buffer 128x128 tile, 3 = always the 8-wave /
- * 3-buffer 256x128 tile (same results; used by tests to cover both and by bench.py --variant for A/B timing) */
+/* tuning hook (same results for every value; tests cover each tile, bench.py --variant does A/B timing).
+ * bits 0-7: dgrad/forward tile, 0 = automatic, 1/2 = 128x128 with 1/2 LDS buffers, 3 = 256x128 8 waves 3 buffers,
+ * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles);  bits 8-9: timing-only ablation (results invalid);
+ * bits 16-19: weight-gradient tile, 0 = automatic, 1/3 = 128x128 with 1/2 buffers, 2 = 256x256, 7 = atomics. */
 void gct2_debug_tapgemm_variant(int v);
 /* optional caller-owned device scratch (16-byte aligned) for the split-K partial sums of layers whose output
  * is too small to fill the chip (the U-Net's bottleneck levels).  Process-wide; kernels that use it must be
  * enqueued on ONE stream at a time.  ws = NULL disables split-K (same results, slower small layers). */
 int gct2_set_workspace(void* ws, size_t bytes);
+/* optional second scratch used by the weight-gradient entry points only (their partial-tile slabs).  With it
+ * registered, *_wgrad calls may be enqueued on a second stream concurrently with the forward/dgrad entry points
+ * (the engine's backward pass does that); without it they share the scratch above and the one-stream rule holds. */
+int gct2_set_wgrad_workspace(void* ws, size_t bytes);
 
 /* ---- DownShuffle = Conv2D(f, 4, 2, 'same', relu)   train.py:158-169 ------------------------- */
 /* y[b,oh,ow,o] = act(bias[o] + sum_{kh,kw,i} x[b,2oh+kh-1,2ow+kw-1,i] * w[kh,kw,i,o])

@@ -12,6 +12,8 @@ B = 64
 LAYERS = {  # name: (kind, H, W, Cin, Cout)  kind: conv fwd / convT fwd / convT dgrad (conv-form) / conv dgrad (convT-form)
     "D1.fwd": ("conv_fwd", 64, 64, 128, 256), "D2.fwd": ("conv_fwd", 32, 32, 256, 512),
     "U2.fwd": ("convT_fwd", 16, 16, 1024, 256), "U1.fwd": ("convT_fwd", 32, 32, 512, 128), "U0.fwd": ("convT_fwd", 64, 64, 256, 64),
+    "D3.fwd": ("conv_fwd", 16, 16, 512, 512), "U3.fwd": ("convT_fwd", 8, 8, 1024, 512),
+    "U2.dgrad": ("convT_dgrad", 16, 16, 1024, 256), "D2.dgrad": ("conv_dgrad", 32, 32, 256, 512),
     "U1.dgrad": ("convT_dgrad", 32, 32, 512, 128), "U0.dgrad": ("convT_dgrad", 64, 64, 256, 64), "D1.dgrad": ("conv_dgrad", 64, 64, 128, 256),
 }
 def run(name, variant, iters=20):
@@ -32,12 +34,12 @@ def run(name, variant, iters=20):
     elif kind == "convT_dgrad":
         dz = torch.randn(B, 2 * H, 2 * W, Cout, device=dev).to(bf); w = (torch.randn(4, 4, Cout, Cin, device=dev) * .05).to(bf)
         act = torch.randn(B, H, W, Cin, device=dev).to(bf); dx = torch.empty_like(act)
-        f = lambda: L.call("gct2_convT4s2_dgrad", 1, dz.data_ptr(), Cout, w.data_ptr(), act.data_ptr(), Cin, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 0, s)
+        f = lambda: L.call("gct2_convT4s2_dgrad", 1, dz.data_ptr(), Cout, w.data_ptr(), act.data_ptr(), Cin, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 0, None, 0, None, s)
         flops = 2.0 * B * H * W * Cin * 16 * Cout
     else:
         dz = torch.randn(B, H // 2, W // 2, Cout, device=dev).to(bf); w = (torch.randn(4, 4, Cin, Cout, device=dev) * .05).to(bf)
         act = torch.randn(B, H, W, Cin, device=dev).to(bf); dx = torch.zeros_like(act)
-        f = lambda: L.call("gct2_conv4s2_dgrad", 1, dz.data_ptr(), Cout, w.data_ptr(), act.data_ptr(), Cin, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 1, s)
+        f = lambda: L.call("gct2_conv4s2_dgrad", 1, dz.data_ptr(), Cout, w.data_ptr(), act.data_ptr(), Cin, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 1, None, 0, None, s)
         flops = 2.0 * B * H * W * Cin * 4 * Cout
     for _ in range(3): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

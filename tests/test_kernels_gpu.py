@@ -283,10 +283,11 @@ def test_splitk_bottleneck_layers(gpu, dt):
         L.call("gct2_set_workspace", None, 0)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5])
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 12, 20, 72, 136), (3, 2, 2, 256, 64), (1, 32, 32, 128, 256)])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 12, 20, 72, 136), (3, 2, 2, 256, 64), (1, 32, 32, 128, 256), (1, 8, 12, 264, 328)])
 def test_tapgemm_tile_variants(gpu, variant, shape):
-    """both tile variants (4-wave/2-buffer 128x128 and 8-wave/3-buffer 256x128 with counted vmcnt) on every use."""
+    """every tile variant on every use: 1/2 = 128x128 (1/2 LDS buffers), 3 = 256x128 8-wave 3-buffer (counted vmcnt),
+    5 = 256x128 single buffer, 6 = 256x256 with 128x64 wave tiles (taken where N >= 256, else falls through to the default)."""
     B, H, W, Cin, Cout = shape
     dt = BF16
     L = lib()

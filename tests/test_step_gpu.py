@@ -185,6 +185,38 @@ def test_data_parallel_wrapper_single_rank_equals_plain_step(gpu):
         assert rel_l2(outs[1][k], outs[0][k]) <= 1e-6, k       # only fp32 atomics order may differ (UpShuffle_0-like splits)
 
 
+def test_data_parallel_exchange_streams_single_rank(gpu):
+    """the N>1 code path on one GPU: a 1-rank RCCL group with force_exchange runs the bucketed all-reduces on the
+    communication stream and the per-bucket Adam behind them; parameters must equal the plain engine step."""
+    import socket
+    import torch.distributed as dist
+    from gan_class_transfer2_amd.distributed import DataParallelStep
+    cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
+    params = O.init_params(cfg, seed=5)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=gpu)
+    try:
+        outs = []
+        for wrapped in (False, True):
+            eng = make_engine(cfg, 1, gpu)
+            eng.set_params(params)
+            stepper = DataParallelStep(eng, bucket_elems=100_000, force_exchange=True) if wrapped else eng
+            for step in range(3):
+                x, t_int, eps = O.synthetic_batch(cfg, seed=step)
+                stepper.train_step(torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32))
+            torch.cuda.synchronize()
+            if wrapped:
+                assert stepper.reducer.exchange and stepper.reducer.launched == len(stepper.reducer.buckets) >= 3
+            assert eng.iterations == 3
+            outs.append(eng.get_params())
+        for k in outs[0]:
+            assert rel_l2(outs[1][k], outs[0][k]) <= 1e-6, k
+    finally:
+        dist.destroy_process_group()
+
+
 def test_fp16_loss_scaling_step(gpu):
     """mixed_precision=True path (train.py:34,43-45,82-83): fp16 operands, dynamic loss scale, finite grads applied."""
     cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
