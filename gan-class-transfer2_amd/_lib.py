@@ -44,8 +44,8 @@ SIGNATURES = {
     "gct2_dense_head_train": [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gct2_rng_uniform_int": [_u64, _u64, _u64, _vp, _sz, _i, _i, _vp],
     "gct2_rng_normal": [_u64, _u64, _u64, _vp, _sz, _vp],
-    "gct2_noise_image": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "gct2_noise_image_rng": [_i, _vp, _vp, _u64, _u64, _u64, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gct2_noise_image": [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "gct2_noise_image_rng": [_i, _vp, _vp, _u64, _u64, _u64, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "gct2_mse_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
     "gct2_adam_keras_multi": [_vp, _vp, _vp, _vp, _vp, _i, _sz, _f, _f, _f, _f, _f, _vp, _vp, _i, _vp],
     "gct2_cast_from_f32": [_i, _vp, _vp, _sz, _vp],

@@ -19,8 +19,8 @@ bool rgb_wgrad_supported(int dtype, const WgradParams& p);
 int rgb_wgrad(int dtype, const WgradParams& p, hipStream_t s);
 int pw_rng_uniform_int(uint64_t, uint64_t, uint64_t, int32_t*, size_t, int, int, hipStream_t);
 int pw_rng_normal(uint64_t, uint64_t, uint64_t, float*, size_t, hipStream_t);
-int pw_noise(int, const float*, const int32_t*, const float*, void*, int, int, int, int, int, hipStream_t);
-int pw_noise_rng(int, const float*, const int32_t*, uint64_t, uint64_t, uint64_t, float*, void*, int, int, int, int, int, hipStream_t);
+int pw_noise(int, const float*, const int32_t*, const float*, void*, int, void*, int, int, int, int, int, hipStream_t);
+int pw_noise_rng(int, const float*, const int32_t*, uint64_t, uint64_t, uint64_t, float*, void*, int, void*, int, int, int, int, int, hipStream_t);
 int pw_dense_fwd(int, const void*, int, const float*, const float*, float*, int, int, int, hipStream_t);
 int pw_dense_bwd(int, const void*, int, const float*, const float*, void*, int, float*, float*, int, int, int, int, hipStream_t);
 int pw_mse(const float*, const float*, float*, float*, float*, size_t, const float*, hipStream_t);
@@ -107,7 +107,7 @@ int run_wgrad(int dtype, const WgradParams& p, void* stream) {
 
 extern "C" {
 
-int gct2_abi_version(void) { return 4; }
+int gct2_abi_version(void) { return 5; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
 void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant(v >> 16); }
@@ -234,18 +234,19 @@ int gct2_rng_normal(uint64_t seed, uint64_t stream_id, uint64_t offset, float* o
   return pw_rng_normal(seed, stream_id, offset, out, n, S(stream));
 }
 
-int gct2_noise_image(int dtype, const float* x, const int32_t* t_int, const float* eps, void* out, int ldout, int B, int HW, int C,
-                     int steps, void* stream) {
+int gct2_noise_image(int dtype, const float* x, const int32_t* t_int, const float* eps, void* out, int ldout, void* out2, int ldout2,
+                     int B, int HW, int C, int steps, void* stream) {
   if (!dtype_ok(dtype) || !x || !t_int || !eps || !out) return gct2_fail(GCT2_EINVAL, "noise_image: bad dtype or null pointer");
-  if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || steps <= 0) return gct2_fail(GCT2_EINVAL, "noise_image: bad shape");
-  return pw_noise(dtype, x, t_int, eps, out, ldout, B, HW, C, steps, S(stream));
+  if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || (out2 && ldout2 < C) || steps <= 0) return gct2_fail(GCT2_EINVAL, "noise_image: bad shape");
+  return pw_noise(dtype, x, t_int, eps, out, ldout, out2, ldout2, B, HW, C, steps, S(stream));
 }
 
 int gct2_noise_image_rng(int dtype, const float* x, const int32_t* t_int, uint64_t seed, uint64_t stream_id, uint64_t offset,
-                         float* eps_out, void* out, int ldout, int B, int HW, int C, int steps, void* stream) {
+                         float* eps_out, void* out, int ldout, void* out2, int ldout2, int B, int HW, int C, int steps, void* stream) {
   if (!dtype_ok(dtype) || !x || !t_int || !out) return gct2_fail(GCT2_EINVAL, "noise_image_rng: bad dtype or null pointer");
-  if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || steps <= 0) return gct2_fail(GCT2_EINVAL, "noise_image_rng: bad shape");
-  return pw_noise_rng(dtype, x, t_int, seed, stream_id, offset, eps_out, out, ldout, B, HW, C, steps, S(stream));
+  if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || (out2 && ldout2 < C) || steps <= 0)
+    return gct2_fail(GCT2_EINVAL, "noise_image_rng: bad shape");
+  return pw_noise_rng(dtype, x, t_int, seed, stream_id, offset, eps_out, out, ldout, out2, ldout2, B, HW, C, steps, S(stream));
 }
 
 int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n,

@@ -3,6 +3,7 @@
 // mixed-precision loss-scale state machine (train.py:82-83).  All are streaming kernels: 16-byte accesses
 // where the layout allows, grids capped at a few workgroups per CU with grid-stride loops.
 #include "gct2_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -56,8 +57,8 @@ __global__ void rng_normal_kernel(uint64_t seed, uint64_t stream_id, uint64_t of
 // noising with eps drawn on the fly from the same stream positions rng_normal_kernel would use: one thread per pixel
 template <typename T>
 __global__ void noise_rng_kernel(const float* __restrict__ x, const int32_t* __restrict__ t_int, uint64_t seed, uint64_t stream_id,
-                                 uint64_t offset, float* __restrict__ eps_out, T* __restrict__ out, int ldout, size_t npix, int HW,
-                                 int C, float inv_steps1) {
+                                 uint64_t offset, float* __restrict__ eps_out, T* __restrict__ out, int ldout,
+                                 T* __restrict__ out2, int ldout2, size_t npix, int HW, int C, float inv_steps1) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += stride) {
     const int b = (int)(pix / HW);
@@ -68,14 +69,17 @@ __global__ void noise_rng_kernel(const float* __restrict__ x, const int32_t* __r
       const size_t i = pix * C + c;
       const float e = philox_normal(seed, stream_id, offset + i);
       if (eps_out) eps_out[i] = e;
-      out[pix * ldout + c] = from_f32<T>(x[i] * sa + e * sb);
+      const T v = from_f32<T>(x[i] * sa + e * sb);
+      out[pix * ldout + c] = v;
+      if (out2) out2[pix * ldout2 + c] = v;
     }
   }
 }
 
 template <typename T>
 __global__ void noise_kernel(const float* __restrict__ x, const int32_t* __restrict__ t_int, const float* __restrict__ eps,
-                             T* __restrict__ out, int ldout, size_t npix, int HW, int C, float inv_steps1) {
+                             T* __restrict__ out, int ldout, T* __restrict__ out2, int ldout2, size_t npix, int HW, int C,
+                             float inv_steps1) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t total = npix * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -86,6 +90,7 @@ __global__ void noise_kernel(const float* __restrict__ x, const int32_t* __restr
     const float a = (1.f - t) * (1.f - t) * 0.25f;             // alpha_dash            train.py:93
     const float v = x[i] * sqrtf(a) + eps[i] * sqrtf(1.f - a); // train.py:231-234
     out[pix * ldout + c] = from_f32<T>(v);
+    if (out2) out2[pix * ldout2 + c] = from_f32<T>(v);
   }
 }
 
@@ -308,6 +313,228 @@ __global__ __launch_bounds__(256) void dense_head_train_kernel(const T* __restri
   if (tid == 0) partials[blockIdx.x] = lws[0] + lws[1] + lws[2] + lws[3];
 }
 
+// ---- the same fused head on the matrix cores ------------------------------------------------------------------------------
+// One wave = 16 pixels per trip, operands straight from global memory in MFMA fragment layout (no LDS staging):
+//   pred[o][pix]  = sum_c W[c][o] x[pix][c]         A = W^T (the fp32 kernel as a three-term 16-bit sum, rows o < Cout), B = x rows
+//   g[c][pix]     = sum_o W[c][o] d[pix][o]         A = W rows in the permuted order below, B = d = pred - target (hi + lo)
+// so the 16-bit operands carry the fp32 kernel and the fp32 residual as multi-term sums (forward ~fp32; backward ~2^-17, far
+// below the 16-bit rounding of the stored gradient).
+// Output row rho = 4g + r of backward MFMA ct is channel 32 (ct>>1) + 8 g + 4 (ct&1) + r: exactly the channels whose x values
+// this lane already holds as its forward B fragments, so the ReLU mask and the 16-byte gradient store need no shuffle.
+// dW / db / db_dx / loss are accumulated per lane and leave as one partial row per work-group (HEAD_ROW floats) for
+// dense_head_finish_kernel: no atomics, fixed summation order.
+constexpr int HEAD_ROW = 288;       // [0,216) dW (c*Cout+o) | [216,219) db | 219 loss | [224,288) db of the layer below
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dense_head_mfma_kernel(const T* __restrict__ x, int ld, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, const float* __restrict__ target,
+                                                                 float* __restrict__ pred_out, T* __restrict__ dx, int lddx,
+                                                                 float* __restrict__ part, int M, int Cin, int Cout,
+                                                                 const float* __restrict__ loss_scale_ptr) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, q = lane & 15;
+  const float gscale = (loss_scale_ptr ? *loss_scale_ptr : 1.f) * 2.0f / ((float)M * (float)Cout);
+  auto split = [](float v, T& hi, T& lo) { hi = from_f32<T>(v); lo = from_f32<T>(v - to_f32(hi)); };
+  auto pk = [](T a, T b) { return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16); };
+  // forward A operands: row o = q, reduction slots = channels 32 kk + 8 g + j
+  u32x4_t a_f[3][3];                                            // three-term split: pred keeps fp32 accuracy
+#pragma unroll
+  for (int kk = 0; kk < 3; kk++) {
+    T hi[8], mid[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int c = 32 * kk + 8 * g + j;
+      const float v = (q < Cout && c < Cin && (kk < 2 || g == 0)) ? w[c * Cout + q] : 0.f;
+      split(v, hi[j], mid[j]);
+      const float rest = (v - to_f32(hi[j])) - to_f32(mid[j]);
+      lo[j] = from_f32<T>(rest);
+    }
+    a_f[kk][0] = u32x4_t{pk(hi[0], hi[1]), pk(hi[2], hi[3]), pk(hi[4], hi[5]), pk(hi[6], hi[7])};
+    a_f[kk][1] = u32x4_t{pk(mid[0], mid[1]), pk(mid[2], mid[3]), pk(mid[4], mid[5]), pk(mid[6], mid[7])};
+    a_f[kk][2] = u32x4_t{pk(lo[0], lo[1]), pk(lo[2], lo[3]), pk(lo[4], lo[5]), pk(lo[6], lo[7])};
+  }
+  // backward A operands (lanes g == 0 only): row rho = q -> channel ch; slots {Whi0..2, Whi0..2, 0, 0} and {Wlo0..2, 0...}
+  u32x4_t a_b[4][2];
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) {
+    const int ch = 32 * (ct >> 1) + 8 * (q >> 2) + 4 * (ct & 1) + (q & 3);
+    T hi[3], lo[3];
+#pragma unroll
+    for (int o = 0; o < 3; o++) split((g == 0 && o < Cout) ? w[ch * Cout + o] : 0.f, hi[o], lo[o]);
+    const T z = from_f32<T>(0.f);
+    a_b[ct][0] = u32x4_t{pk(hi[0], hi[1]), pk(hi[2], hi[0]), pk(hi[1], hi[2]), 0u};
+    a_b[ct][1] = u32x4_t{pk(lo[0], lo[1]), pk(lo[2], z), 0u, 0u};
+  }
+  float bv[3];
+#pragma unroll
+  for (int o = 0; o < 3; o++) bv[o] = (bias && o < Cout) ? bias[o] : 0.f;
+  const uint32_t tail_keep = Cin - 64;                         // valid channels in the third fragment (pad channels may hold anything)
+
+  float wacc[3][8][3];
+#pragma unroll
+  for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+      for (int o = 0; o < 3; o++) wacc[kk][j][o] = 0.f;
+  float bacc[2][8];
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) bacc[kk][j] = 0.f;
+  float dbacc[3] = {0.f, 0.f, 0.f}, lacc = 0.f;
+
+  const int ngroups = (M + 15) >> 4;
+  const int gstride = gridDim.x * 4;
+  auto load = [&](int grp, u32x4_t (&xf)[3]) {
+    const int p = grp * 16 + q;
+    xf[0] = xf[1] = xf[2] = u32x4_t{0u, 0u, 0u, 0u};
+    if (grp < ngroups && p < M) {
+      const T* row = x + (size_t)p * ld + 8 * g;
+      xf[0] = gload128(row);
+      xf[1] = gload128(row + 32);
+      if (g == 0) xf[2] = gload128(row + 64);
+    }
+  };
+  u32x4_t cur[3], nxt[3];
+  int grp = blockIdx.x * 4 + wave;
+  load(grp, cur);
+  for (; grp < ngroups; grp += gstride) {
+    load(grp + gstride, nxt);
+    const int p = grp * 16 + q;
+    const bool pv = p < M;
+    if (g == 0) {                                              // zero the pad channels >= Cin of the third fragment
+#pragma unroll
+      for (int j2 = 0; j2 < 4; j2++) {
+        const uint32_t keep = tail_keep >= 2u * j2 + 2u ? 0xffffffffu : (tail_keep == 2u * j2 + 1u ? 0xffffu : 0u);
+        cur[2][j2] &= keep;
+      }
+    }
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+      acc = mfma16<T>(a_f[kk][2], cur[kk], acc);            // smallest terms first
+      acc = mfma16<T>(a_f[kk][1], cur[kk], acc);
+      acc = mfma16<T>(a_f[kk][0], cur[kk], acc);
+    }
+    // lanes g == 0: acc[o] = pred[pixel q][o]
+    float d[3] = {0.f, 0.f, 0.f};
+    if (g == 0 && pv) {
+#pragma unroll
+      for (int o = 0; o < 3; o++) {
+        if (o < Cout) {
+          const float pr = acc[o] + bv[o];
+          d[o] = pr - target[(size_t)p * Cout + o];
+          if (pred_out) pred_out[(size_t)p * Cout + o] = pr;
+          lacc = fmaf(d[o], d[o], lacc);
+        }
+      }
+    }
+    T dh[3], dl[3];
+#pragma unroll
+    for (int o = 0; o < 3; o++) split(d[o], dh[o], dl[o]);
+    const u32x4_t bb = {pk(dh[0], dh[1]), pk(dh[2], dl[0]), pk(dl[1], dl[2]), 0u};   // zero in lanes g > 0 (d = 0 there)
+    float dp[3];
+#pragma unroll
+    for (int o = 0; o < 3; o++) {
+      dp[o] = __shfl(d[o] * gscale, q, 64);                    // every lane group gets the gradient of its pixel
+      if (g == 0) dbacc[o] += dp[o];
+    }
+    u32x4_t gout[2];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) {
+      f32x4_t gd = {0.f, 0.f, 0.f, 0.f};
+      gd = mfma16<T>(a_b[ct][0], bb, gd);
+      gd = mfma16<T>(a_b[ct][1], bb, gd);
+      const int kk = ct >> 1, h = ct & 1;
+      float gv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t xw = cur[kk][2 * h + (r >> 1)];
+        const float xv = (r & 1) ? unpack_hi<T>(xw) : unpack_lo<T>(xw);
+        gv[r] = xv > 0.f ? gd[r] * gscale : 0.f;
+        bacc[kk][4 * h + r] += gv[r];
+      }
+      gout[kk][2 * h] = pack2<T>(gv[0], gv[1]);
+      gout[kk][2 * h + 1] = pack2<T>(gv[2], gv[3]);
+    }
+    if (pv) {
+      T* drow = dx + (size_t)p * lddx + 8 * g;
+      *reinterpret_cast<u32x4_t*>(drow) = gout[0];
+      *reinterpret_cast<u32x4_t*>(drow + 32) = gout[1];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+      for (int j2 = 0; j2 < 4; j2++) {
+        const float x0 = unpack_lo<T>(cur[kk][j2]), x1 = unpack_hi<T>(cur[kk][j2]);
+#pragma unroll
+        for (int o = 0; o < 3; o++) {
+          wacc[kk][2 * j2][o] = fmaf(x0, dp[o], wacc[kk][2 * j2][o]);
+          wacc[kk][2 * j2 + 1][o] = fmaf(x1, dp[o], wacc[kk][2 * j2 + 1][o]);
+        }
+      }
+    cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
+  }
+
+  // ---- reductions: over the 16 pixel lanes (butterfly), then over the 4 waves (LDS), one partial row per work-group ----
+  __shared__ float red[4][HEAD_ROW];
+  for (int i = tid; i < 4 * HEAD_ROW; i += 256) (&red[0][0])[i] = 0.f;
+  __syncthreads();
+  auto bfly = [](float t) {
+    t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+    return t;
+  };
+#pragma unroll
+  for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+      for (int o = 0; o < 3; o++) {
+        const float t = bfly(wacc[kk][j][o]);
+        const int c = 32 * kk + 8 * g + j;
+        if (q == 0 && o < Cout && c < Cin && (kk < 2 || g == 0)) red[wave][c * Cout + o] = t;
+      }
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float t = bfly(bacc[kk][j]);
+      if (q == 0) red[wave][224 + 32 * kk + 8 * g + j] = t;
+    }
+#pragma unroll
+  for (int o = 0; o < 3; o++) {
+    const float t = bfly(dbacc[o]);
+    if (lane == 0) red[wave][216 + o] = t;
+  }
+  {
+    const float t = bfly(lacc);
+    if (lane == 0) red[wave][219] = t;
+  }
+  __syncthreads();
+  for (int i = tid; i < HEAD_ROW; i += 256) part[(size_t)blockIdx.x * HEAD_ROW + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+// sums the head's partial rows: column -> dW / db / loss / db of the layer below.  9 work-groups x (32 columns x 32 row lanes).
+__global__ __launch_bounds__(1024) void dense_head_finish_kernel(const float* __restrict__ part, int rows, float* __restrict__ dw,
+                                                                 float* __restrict__ db, float* __restrict__ loss,
+                                                                 float* __restrict__ db_dx, int ndw, int Cout, float inv_n) {
+  const int tid = threadIdx.x, cx = tid & 31, rl = tid >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double acc = 0.0;
+  for (int r = rl; r < rows; r += 32) acc += (double)part[(size_t)r * HEAD_ROW + c];
+  __shared__ double red[32][33];
+  red[rl][cx] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 32; k++) t += red[k][cx];
+    if (c < ndw) dw[c] += (float)t;
+    else if (c >= 216 && c < 216 + Cout) { if (db) db[c - 216] += (float)t; }
+    else if (c == 219) *loss = (float)(t * (double)inv_n);
+    else if (c >= 224 && db_dx) db_dx[c - 224] += (float)t;
+  }
+}
+
 // ---- bias gradient: db[c] += sum_m dz[m][c] --------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dz, int ld, float* __restrict__ db, size_t M, int C,
@@ -452,30 +679,32 @@ int pw_rng_normal(uint64_t seed, uint64_t stream_id, uint64_t offset, float* out
   return gct2_check_launch("rng_normal");
 }
 template <typename T>
-static int noise_t(const float* x, const int32_t* t, const float* eps, void* out, int ldout, int B, int HW, int C, int steps, hipStream_t s) {
+static int noise_t(const float* x, const int32_t* t, const float* eps, void* out, int ldout, void* out2, int ldout2, int B, int HW, int C,
+                   int steps, hipStream_t s) {
   const size_t npix = (size_t)B * HW;
-  hipLaunchKernelGGL(noise_kernel<T>, dim3(blocks_for(npix * C, 256)), dim3(256), 0, s, x, t, eps, reinterpret_cast<T*>(out), ldout, npix,
-                     HW, C, 1.0f / (float)(steps + 1));
+  hipLaunchKernelGGL(noise_kernel<T>, dim3(blocks_for(npix * C, 256)), dim3(256), 0, s, x, t, eps, reinterpret_cast<T*>(out), ldout,
+                     reinterpret_cast<T*>(out2), ldout2, npix, HW, C, 1.0f / (float)(steps + 1));
   return gct2_check_launch("noise_image");
 }
-int pw_noise(int dtype, const float* x, const int32_t* t, const float* eps, void* out, int ldout, int B, int HW, int C, int steps, hipStream_t s) {
-  if (dtype == GCT2_F32) return noise_t<float>(x, t, eps, out, ldout, B, HW, C, steps, s);
-  if (dtype == GCT2_BF16) return noise_t<__bf16>(x, t, eps, out, ldout, B, HW, C, steps, s);
-  return noise_t<_Float16>(x, t, eps, out, ldout, B, HW, C, steps, s);
+int pw_noise(int dtype, const float* x, const int32_t* t, const float* eps, void* out, int ldout, void* out2, int ldout2, int B, int HW,
+             int C, int steps, hipStream_t s) {
+  if (dtype == GCT2_F32) return noise_t<float>(x, t, eps, out, ldout, out2, ldout2, B, HW, C, steps, s);
+  if (dtype == GCT2_BF16) return noise_t<__bf16>(x, t, eps, out, ldout, out2, ldout2, B, HW, C, steps, s);
+  return noise_t<_Float16>(x, t, eps, out, ldout, out2, ldout2, B, HW, C, steps, s);
 }
 template <typename T>
 static int noise_rng_t(const float* x, const int32_t* t, uint64_t seed, uint64_t sid, uint64_t off, float* eps_out, void* out, int ldout,
-                       int B, int HW, int C, int steps, hipStream_t s) {
+                       void* out2, int ldout2, int B, int HW, int C, int steps, hipStream_t s) {
   const size_t npix = (size_t)B * HW;
   hipLaunchKernelGGL(noise_rng_kernel<T>, dim3(blocks_for(npix, 256)), dim3(256), 0, s, x, t, seed, sid, off, eps_out,
-                     reinterpret_cast<T*>(out), ldout, npix, HW, C, 1.0f / (float)(steps + 1));
+                     reinterpret_cast<T*>(out), ldout, reinterpret_cast<T*>(out2), ldout2, npix, HW, C, 1.0f / (float)(steps + 1));
   return gct2_check_launch("noise_image_rng");
 }
 int pw_noise_rng(int dtype, const float* x, const int32_t* t, uint64_t seed, uint64_t sid, uint64_t off, float* eps_out, void* out,
-                 int ldout, int B, int HW, int C, int steps, hipStream_t s) {
-  if (dtype == GCT2_F32) return noise_rng_t<float>(x, t, seed, sid, off, eps_out, out, ldout, B, HW, C, steps, s);
-  if (dtype == GCT2_BF16) return noise_rng_t<__bf16>(x, t, seed, sid, off, eps_out, out, ldout, B, HW, C, steps, s);
-  return noise_rng_t<_Float16>(x, t, seed, sid, off, eps_out, out, ldout, B, HW, C, steps, s);
+                 int ldout, void* out2, int ldout2, int B, int HW, int C, int steps, hipStream_t s) {
+  if (dtype == GCT2_F32) return noise_rng_t<float>(x, t, seed, sid, off, eps_out, out, ldout, out2, ldout2, B, HW, C, steps, s);
+  if (dtype == GCT2_BF16) return noise_rng_t<__bf16>(x, t, seed, sid, off, eps_out, out, ldout, out2, ldout2, B, HW, C, steps, s);
+  return noise_rng_t<_Float16>(x, t, seed, sid, off, eps_out, out, ldout, out2, ldout2, B, HW, C, steps, s);
 }
 template <typename T>
 static int dense_fwd_t(const void* x, int ldx, const float* w, const float* b, float* y, int M, int Cin, int Cout, hipStream_t s) {
@@ -511,6 +740,20 @@ template <typename T>
 static int dense_head_train_t(const void* x, int ld, const float* w, const float* b, const float* target, float* pred, void* dx, int lddx,
                               float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask, const float* ls,
                               float* db_dx, hipStream_t s) {
+  // matrix-core version: the reference head (64 masked U_0 channels + 3 image channels -> 3 outputs) with a registered workspace
+  size_t ws_bytes = 0;
+  float* ws = gct2_workspace(&ws_bytes);
+  if (Cmask == 64 && Cin >= 64 && Cin <= 72 && ld >= 72 && Cout <= 3) {
+    const int ngroups = (M + 15) / 16;
+    const int grid = std::min(512, (ngroups + 3) / 4);
+    if (ws && ws_bytes >= (size_t)grid * HEAD_ROW * sizeof(float)) {
+      hipLaunchKernelGGL(dense_head_mfma_kernel<T>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const T*>(x), ld, w, b, target, pred,
+                         reinterpret_cast<T*>(dx), lddx, ws, M, Cin, Cout, ls);
+      hipLaunchKernelGGL(dense_head_finish_kernel, dim3(HEAD_ROW / 32), dim3(1024), 0, s, ws, grid, dw, db, loss, db_dx, Cin * Cout, Cout,
+                         1.0f / ((float)M * (float)Cout));
+      return gct2_check_launch("dense_head_train");
+    }
+  }
   constexpr int PIX = 256;
   const size_t lds = (size_t)PIX * ld * 2 + (size_t)PIX * Cmask * 2 + PIX * 16 + (size_t)ld * 16;
   const int ntiles = (M + PIX - 1) / PIX;

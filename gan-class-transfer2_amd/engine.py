@@ -210,6 +210,9 @@ class UNetEngine:
         z = lambda *shape, dtype=dt: torch.zeros(*shape, dtype=dtype, device=self.device)
         b.R = [z(B, b.hw[i][0], b.hw[i][1], b.ld[i]) for i in range(n)]
         b.dR = [z(B, b.hw[i][0], b.hw[i][1], b.ld[i]) for i in range(n)]
+        # packed copy of the network input (3 channels + a zero slot): DownShuffle_0 and its weight gradient gather 4x4
+        # windows from it instead of striding through R_0's 144-byte rows
+        b.img = z(B, H, W, 4)
         b.Dlast = z(B, b.hw[n][0], b.hw[n][1], t.fd(n - 1))
         b.dDlast = z(B, b.hw[n][0], b.hw[n][1], t.fd(n - 1))
         b.pred = z(B, H, W, 3, dtype=torch.float32)
@@ -255,19 +258,21 @@ class UNetEngine:
         s, t = self._stream(), self.topo
         call("gct2_rng_uniform_int", self.rng_seed, 1, self.rng_offset_t, b.t_int.data_ptr(), b.B, 1, self.steps, s)
         call("gct2_noise_image_rng", self.dtype, x.data_ptr(), b.t_int.data_ptr(), self.rng_seed, 2, self.rng_offset_eps,
-             b.eps.data_ptr() if keep_eps else None, self._slice_ptr(b.R[0], t.fu(0)), b.ld[0], b.B, b.H * b.W, 3, self.steps, s)
+             b.eps.data_ptr() if keep_eps else None, self._slice_ptr(b.R[0], t.fu(0)), b.ld[0], b.img.data_ptr(), 4,
+             b.B, b.H * b.W, 3, self.steps, s)
         self.rng_offset_t += b.B
         self.rng_offset_eps += b.eps.numel()
 
     def noise_into_r0(self, b: _Buffers, x: torch.Tensor) -> None:
         t = self.topo
         call("gct2_noise_image", self.dtype, x.data_ptr(), b.t_int.data_ptr(), b.eps.data_ptr(),
-             self._slice_ptr(b.R[0], t.fu(0)), b.ld[0], b.B, b.H * b.W, 3, self.steps, self._stream())
+             self._slice_ptr(b.R[0], t.fu(0)), b.ld[0], b.img.data_ptr(), 4, b.B, b.H * b.W, 3, self.steps, self._stream())
 
     def load_input_into_r0(self, b: _Buffers, noised: torch.Tensor) -> None:
         """Denoiser.call on an externally prepared image (sampler / inference path)."""
         t = self.topo
         b.R[0][..., t.fu(0):t.fu(0) + 3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
+        b.img[..., :3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
 
     def forward(self, b: _Buffers, head: bool = True) -> torch.Tensor:
         """Denoiser.call (train.py:206-215): R_0's image slice must already hold the network input.
@@ -279,8 +284,8 @@ class UNetEngine:
                 y, ldy = self._slice_ptr(b.R[i + 1], t.fu(i + 1)), b.ld[i + 1]
             else:
                 y, ldy = b.Dlast.data_ptr(), t.fd(i)
-            call("gct2_conv4s2_fwd", dt, self._slice_ptr(b.R[i], t.fu(i)), b.ld[i], A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"),
-                 y, ldy, b.B, H, W, t.cx(i), t.fd(i), 1, s)
+            x, ldx = (b.img.data_ptr(), 4) if i == 0 else (self._slice_ptr(b.R[i], t.fu(i)), b.ld[i])
+            call("gct2_conv4s2_fwd", dt, x, ldx, A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"), y, ldy, b.B, H, W, t.cx(i), t.fd(i), 1, s)
         for i in reversed(range(n)):                            # UpShuffle_i    (train.py:188)
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
@@ -385,8 +390,9 @@ class UNetEngine:
             else:
                 dz, lddz = b.dDlast.data_ptr(), t.fd(i)
             x, ldx = self._slice_ptr(b.R[i], t.fu(i)), b.ld[i]
+            xw, ldxw = (b.img.data_ptr(), 4) if i == 0 else (x, ldx)
             side_waits_main()
-            call("gct2_conv4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), sw)
+            call("gct2_conv4s2_wgrad", dt, xw, ldxw, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), sw)
             with torch.cuda.stream(side):
                 self._ready(f"D{i}")
             adam_upto(prev)

@@ -133,16 +133,18 @@ int gct2_rng_normal(uint64_t seed, uint64_t stream_id, uint64_t offset, float* o
                     void* stream);
 
 /* noised = x*sqrt(a_b) + eps*sqrt(1-a_b), a_b = 0.25*(1 - t_b/(steps+1))^2  (train.py:85-93,229-234)
- * x, eps: fp32 [B, HW, C] contiguous; t_int: int32[B]; out: view [B*HW, C] of `dtype` with ldout. */
+ * x, eps: fp32 [B, HW, C] contiguous; t_int: int32[B]; out: view [B*HW, C] of `dtype` with ldout.
+ * out2 (may be NULL): a second view [B*HW, C] with ldout2 that receives the same values - the engine keeps a packed
+ * copy of the image (ld 4) for DownShuffle_0 beside the slice of the concat buffer that Dense(3) reads. */
 int gct2_noise_image(int dtype, const float* x, const int32_t* t_int, const float* eps, void* out,
-                     int ldout, int B, int HW, int C, int steps, void* stream);
+                     int ldout, void* out2, int ldout2, int B, int HW, int C, int steps, void* stream);
 
 /* the same with eps drawn inside the kernel from the positions [offset, offset + B*HW*C) of the gct2_rng_normal stream
  * (seed, stream_id): bit-identical to gct2_rng_normal followed by gct2_noise_image, without the eps round trip through HBM.
  * eps_out (may be NULL) receives the draws. */
 int gct2_noise_image_rng(int dtype, const float* x, const int32_t* t_int, uint64_t seed, uint64_t stream_id,
-                         uint64_t offset, float* eps_out, void* out, int ldout, int B, int HW, int C, int steps,
-                         void* stream);
+                         uint64_t offset, float* eps_out, void* out, int ldout, void* out2, int ldout2, int B, int HW,
+                         int C, int steps, void* stream);
 
 /* loss = mean((target - pred)^2) in fp32 (train.py:272); dpred = loss_scale * 2 (pred-target)/n.
  * `loss` (1 float) is overwritten; `partials` is caller scratch of >= 1024 floats.

@@ -413,16 +413,23 @@ def test_dense_fwd_bwd(gpu, dt):
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
-@pytest.mark.parametrize("M", [1000, 256 * 5])
-def test_dense_head_train_fused(gpu, dt, M):
-    """fused Dense(3) + MSE + both gradients == the three separate kernels' definitions (ragged last tile at M=1000)."""
+@pytest.mark.parametrize("M", [1000, 256 * 5, 16 * 4 * 512 + 7])
+@pytest.mark.parametrize("with_ws", [False, True])
+def test_dense_head_train_fused(gpu, dt, M, with_ws):
+    """fused Dense(3) + MSE + both gradients == the three separate kernels' definitions (ragged last tile at M=1000).
+    with_ws: a registered workspace selects the matrix-core version (partial rows, no atomics); without it the LDS-tile
+    version runs.  The largest M gives every wave of the 512-work-group grid more than one trip."""
     Cin, Cout, ld, Cmask = 67, 3, 72, 64
+    ws = torch.full((1 << 20,), float("nan"), device=gpu) if with_ws else None
+    lib().call("gct2_set_workspace", ws.data_ptr() if with_ws else None, ws.numel() * 4 if with_ws else 0)
     rng = np.random.default_rng(12)
     x = rnd(np.maximum(rng.standard_normal((M, Cin)), 0), dt)
     w = rng.standard_normal((Cin, Cout)).astype(np.float32).astype(np.float64)
     b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
     tgt = rng.uniform(-1, 1, (M, Cout)).astype(np.float32).astype(np.float64)
     xb = torch.zeros(M, ld, dtype=TDT[dt], device=gpu)
+    if with_ws:
+        xb[:, Cin:] = float("nan")                                  # pad channels must not leak into anything
     xb[:, :Cin] = dev(x, dt, gpu)
     t32 = lambda a: torch.tensor(a, dtype=torch.float32, device=gpu)
     wd, bd, td = t32(w), t32(b), t32(tgt)
@@ -430,10 +437,13 @@ def test_dense_head_train_fused(gpu, dt, M):
     dw = torch.zeros(Cin, Cout, device=gpu); db = torch.zeros(Cout, device=gpu)
     loss = torch.zeros(1, device=gpu); part = torch.zeros(1024, device=gpu)
     scale = torch.tensor([8.0], device=gpu); dbx = torch.zeros(Cmask, device=gpu)
-    lib().call("gct2_dense_head_train", dt, xb.data_ptr(), ld, wd.data_ptr(), bd.data_ptr(), td.data_ptr(), pred.data_ptr(),
-               dxb.data_ptr(), ld, dw.data_ptr(), db.data_ptr(), loss.data_ptr(), part.data_ptr(), M, Cin, Cout, Cmask,
-               scale.data_ptr(), dbx.data_ptr(), stream())
-    torch.cuda.synchronize()
+    try:
+        lib().call("gct2_dense_head_train", dt, xb.data_ptr(), ld, wd.data_ptr(), bd.data_ptr(), td.data_ptr(), pred.data_ptr(),
+                   dxb.data_ptr(), ld, dw.data_ptr(), db.data_ptr(), loss.data_ptr(), part.data_ptr(), M, Cin, Cout, Cmask,
+                   scale.data_ptr(), dbx.data_ptr(), stream())
+        torch.cuda.synchronize()
+    finally:
+        lib().call("gct2_set_workspace", None, 0)
     pr = x @ w + b
     d = pr - tgt
     dp = 8.0 * 2 * d / d.size
@@ -442,7 +452,10 @@ def test_dense_head_train_fused(gpu, dt, M):
     assert rel_l2(dxb[:, :Cmask].double().cpu().numpy(), ((dp @ w.T) * (x > 0))[:, :Cmask]) <= TOL_OUT[dt]
     assert float((dxb[:, Cmask:].float() - 5).abs().max()) == 0
     assert rel_l2(dw.cpu().numpy(), x.T @ dp) <= 2e-5 and rel_l2(db.cpu().numpy(), dp.sum(0)) <= 2e-5
-    assert rel_l2(dbx.cpu().numpy(), dxb[:, :Cmask].double().cpu().numpy().sum(0)) <= 1e-5     # column sums of the stored rows
+    if with_ws:     # column sums of the fp32 gradient rows before they are rounded for the store
+        assert rel_l2(dbx.cpu().numpy(), ((dp @ w.T) * (x > 0))[:, :Cmask].sum(0)) <= 2e-5
+    else:           # column sums of the stored rows
+        assert rel_l2(dbx.cpu().numpy(), dxb[:, :Cmask].double().cpu().numpy().sum(0)) <= 1e-5
 
 
 def test_noise_mse(gpu):
@@ -454,9 +467,12 @@ def test_noise_mse(gpu):
     ref = O.noise_image(x.astype(np.float64).reshape(B, HW, 1, C), t, eps.astype(np.float64).reshape(B, HW, 1, C), steps).reshape(B * HW, C)
     xd, ed, td = torch.tensor(x, device=gpu), torch.tensor(eps, device=gpu), torch.tensor(t, device=gpu)
     out = torch.zeros(B * HW, 8, dtype=torch.float32, device=gpu)
-    lib().call("gct2_noise_image", F32, xd.data_ptr(), td.data_ptr(), ed.data_ptr(), out.data_ptr() + 4 * 2, 8, B, HW, C, steps, stream())
+    out2 = torch.zeros(B * HW, 4, dtype=torch.float32, device=gpu)     # the packed copy (ld 4)
+    lib().call("gct2_noise_image", F32, xd.data_ptr(), td.data_ptr(), ed.data_ptr(), out.data_ptr() + 4 * 2, 8, out2.data_ptr(), 4,
+               B, HW, C, steps, stream())
     torch.cuda.synchronize()
     assert rel_l2(out[:, 2:5].cpu().numpy(), ref) <= 1e-6
+    assert torch.equal(out2[:, :3], out[:, 2:5]) and float(out2[:, 3].abs().max()) == 0
     # MSE + gradient
     n = 100003
     pred, tgt = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
@@ -478,12 +494,15 @@ def test_noise_with_inkernel_rng_is_bit_identical(gpu):
     eps = torch.zeros(n, device=gpu)
     lib().call("gct2_rng_normal", 99, 2, off, eps.data_ptr(), n, stream())
     a = torch.zeros(B * HW, 8, dtype=torch.bfloat16, device=gpu); bb = torch.zeros_like(a)
-    lib().call("gct2_noise_image", BF16, x.data_ptr(), t.data_ptr(), eps.data_ptr(), a.data_ptr() + 2 * 4, 8, B, HW, C, steps, stream())
+    lib().call("gct2_noise_image", BF16, x.data_ptr(), t.data_ptr(), eps.data_ptr(), a.data_ptr() + 2 * 4, 8, None, 0, B, HW, C, steps,
+               stream())
     eps2 = torch.zeros(n, device=gpu)
-    lib().call("gct2_noise_image_rng", BF16, x.data_ptr(), t.data_ptr(), 99, 2, off, eps2.data_ptr(), bb.data_ptr() + 2 * 4, 8, B, HW, C,
-               steps, stream())
+    packed = torch.zeros(B * HW, 4, dtype=torch.bfloat16, device=gpu)
+    lib().call("gct2_noise_image_rng", BF16, x.data_ptr(), t.data_ptr(), 99, 2, off, eps2.data_ptr(), bb.data_ptr() + 2 * 4, 8,
+               packed.data_ptr(), 4, B, HW, C, steps, stream())
     torch.cuda.synchronize()
     assert torch.equal(a, bb) and torch.equal(eps, eps2) and float(a[:, 4:7].float().abs().max()) > 0
+    assert torch.equal(packed[:, :3], bb[:, 4:7]) and float(packed[:, 3].float().abs().max()) == 0
 
 
 def test_rng_streams(gpu):
