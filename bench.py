@@ -56,7 +56,7 @@ def f_train_per_image(topo, H, W):
 
 
 class KernelTimer:
-    """HIP events on the stream the kernels are launched on (torch's current stream), per kernel family."""
+    """HIP events on the stream each kernel is launched on, per kernel family."""
 
     FAMILY = {
         "gct2_conv4s2_fwd": "conv_form", "gct2_convT4s2_dgrad": "conv_form",
@@ -65,7 +65,10 @@ class KernelTimer:
     }
 
     def __init__(self):
-        self.events = []      # (family, start, end)
+        self.events = []      # (family, start, end) of the steps inside the timed region (two streams: in-situ durations)
+        self.isolated = []    # the same from the serial-stream steps run after the timed region (one kernel at a time)
+        self.sink = self.events
+        self.streams = {}     # raw stream handle -> torch stream object
         self.enabled = False
 
     def install(self, engine_module, lib_module):
@@ -80,17 +83,23 @@ class KernelTimer:
                 fam = None
             if fam is None:
                 return orig(name, *args)
+            # events go on the stream the kernel is launched on (the last argument): the weight gradients run on the engine's
+            # side stream, concurrently with the dgrad chain - their durations are the in-situ ones, like rocprofv3's
+            h = int(args[-1] or 0)
+            st = timer.streams.get(h)
+            if st is None:
+                st = timer.streams[h] = torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
+            s.record(st)
             orig(name, *args)
-            e.record()
-            timer.events.append((fam, s, e))
+            e.record(st)
+            timer.sink.append((fam, s, e))
 
         engine_module.call = timed_call
 
-    def summary(self):
+    def summary(self, events):
         tot, cnt = {}, {}
-        for fam, s, e in self.events:
+        for fam, s, e in events:
             tot[fam] = tot.get(fam, 0.0) + s.elapsed_time(e) * 1e-3
             cnt[fam] = cnt.get(fam, 0) + 1
         return tot, cnt
@@ -143,6 +152,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="tapgemm tile variant hook (0 auto, 2, 3): A/B timing only")
+    ap.add_argument("--serial-streams", action="store_true",
+                    help="run the weight gradients and Adam on the main stream (no overlap): per-kernel profiling runs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +180,7 @@ def main():
         _lib.load().gct2_debug_tapgemm_variant(args.variant)
     topo = g.Topology(128, 512, 6)                      # reference defaults, train.py:18-21
     eng = g.UNetEngine(topo, dtype, dev, rng_seed=rank, loss_scaling=(args.dtype == "f16"))
+    eng.overlap = not args.serial_streams
     dp = DataParallelStep(eng)
     dp.broadcast_parameters(0)
 
@@ -200,6 +212,17 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    # roofline leg: the same step with ONE stream, so that every MFMA launch has the chip to itself and its HIP-event duration
+    # is the kernel's own (with two streams a launch shares the CUs with whatever the other stream is running)
+    iso_steps = 0
+    if not args.no_kernel_events:
+        overlap0, eng.overlap = eng.overlap, False
+        timer.sink, timer.enabled = timer.isolated, True
+        for _ in range(4):
+            dp.train_step(x)
+            iso_steps += 1
+        barrier()
+        timer.enabled, eng.overlap = False, overlap0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -220,18 +243,20 @@ def main():
             "flops_per_image": f_img,
             "step_roofline_frac": round(imgs / world * f_img / MFMA_PEAK, 5),
         }
-        if timer.events:
-            tot, cnt = timer.summary()
+        if timer.isolated:
             fl = layer_flops(topo, B, S, S)
-            fams = {}
-            for fam in tot:
-                fams[fam] = {"launches_per_step": cnt[fam] // ev_steps, "ms_per_step": round(tot[fam] / ev_steps * 1e3, 4),
-                             "tflops": round(fl[fam] * ev_steps / tot[fam] / 1e12, 2)}
+
+            def families(events, nsteps):
+                tot, cnt = timer.summary(events)
+                return tot, cnt, {fam: {"launches_per_step": cnt[fam] // nsteps, "ms_per_step": round(tot[fam] / nsteps * 1e3, 4),
+                                        "tflops": round(fl[fam] * nsteps / tot[fam] / 1e12, 2)} for fam in tot}
+
+            tot, cnt, fams = families(timer.isolated, iso_steps)
             dom = max(tot, key=tot.get)
-            achieved = fl[dom] * ev_steps / tot[dom] / 1e12
-            # achieved = algorithmic FLOPs of ALL launches of the dominant family in the timed region / their summed HIP-event
-            # time (= average FLOPs per launch / average launch duration).  traffic = HBM bytes per launch from the committed
-            # PMC passes of this same command (profiles/r01_traffic.json; scripts/collect_traffic.py), only for the default config.
+            achieved = fl[dom] * iso_steps / tot[dom] / 1e12
+            # achieved = algorithmic FLOPs of ALL launches of the dominant family in the serial-stream steps / their summed
+            # HIP-event time (= average FLOPs per launch / average launch duration).  traffic = HBM bytes per launch from the
+            # committed PMC passes (profiles/r01_traffic.json; scripts/collect_traffic.py), only for the default config.
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tpath) and (S, B, args.dtype, world) == (128, 64, "bf16", 1):
@@ -240,9 +265,12 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_PEAK, 5),
                                "traffic": None if traffic is None else round(traffic),
-                               "flops_per_launch": fl[dom] / (cnt[dom] // ev_steps), "event_steps": ev_steps,
-                               "avg_launch_us": round(tot[dom] / cnt[dom] * 1e6, 2)}
+                               "flops_per_launch": fl[dom] / (cnt[dom] // iso_steps), "event_steps": iso_steps,
+                               "avg_launch_us": round(tot[dom] / cnt[dom] * 1e6, 2),
+                               "mode": "one stream (4 extra steps after the timed region): isolated launch durations"}
             out["kernels"] = fams
+            if timer.events:   # the same launches inside the timed region, where two streams share the chip
+                out["kernels_two_streams"] = families(timer.events, ev_steps)[2]
         if world == 1 and not args.no_cpu_baseline:
             kw = dict(pixel_size=128, max_size=512)
             v3, s3, n3 = cpu_baseline(dict(octaves=6, **kw), S, 4, 3, 1)
