@@ -54,22 +54,43 @@ __global__ void rng_normal_kernel(uint64_t seed, uint64_t stream_id, uint64_t of
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = philox_normal(seed, stream_id, offset + i);
 }
 
-// noising with eps drawn on the fly from the same stream positions rng_normal_kernel would use: one thread per pixel
+// noising with eps drawn on the fly from the same stream positions rng_normal_kernel would use.  One thread per Philox
+// counter = 4 consecutive elements of the flattened [pixel][channel] image: one Philox call, two logs and two sin/cos pairs
+// make four normals (philox_normal spends a whole call per element); values are bit-identical to it.
 template <typename T>
 __global__ void noise_rng_kernel(const float* __restrict__ x, const int32_t* __restrict__ t_int, uint64_t seed, uint64_t stream_id,
                                  uint64_t offset, float* __restrict__ eps_out, T* __restrict__ out, int ldout,
-                                 T* __restrict__ out2, int ldout2, size_t npix, int HW, int C, float inv_steps1) {
+                                 T* __restrict__ out2, int ldout2, size_t n, int HW, int C, float inv_steps1) {
+  const uint64_t c0 = offset >> 2;
+  const size_t ncounters = (size_t)(((offset + n + 3) >> 2) - c0);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += stride) {
-    const int b = (int)(pix / HW);
-    const float t = (float)t_int[b] * inv_steps1;
-    const float a = (1.f - t) * (1.f - t) * 0.25f;
-    const float sa = sqrtf(a), sb = sqrtf(1.f - a);
-    for (int c = 0; c < C; c++) {
-      const size_t i = pix * C + c;
-      const float e = philox_normal(seed, stream_id, offset + i);
-      if (eps_out) eps_out[i] = e;
-      const T v = from_f32<T>(x[i] * sa + e * sb);
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < ncounters; t += stride) {
+    const uint64_t ctr = c0 + t;
+    uint32_t r[4];
+    philox4x32_10(seed, stream_id, ctr, r);
+    float nrm[4];
+#pragma unroll
+    for (int pair = 0; pair < 2; pair++) {
+      const float u1 = ((float)(r[2 * pair] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u2 = ((float)(r[2 * pair + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float rad = sqrtf(-2.0f * logf(u1));
+      const float ang = 6.283185307179586f * u2;
+      nrm[2 * pair] = rad * cosf(ang);
+      nrm[2 * pair + 1] = rad * sinf(ang);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint64_t e = 4 * ctr + k;
+      if (e < offset || e >= offset + n) continue;
+      const size_t i = (size_t)(e - offset);
+      const size_t pix = i / C;
+      const int c = (int)(i - pix * C);
+      const int b = (int)(pix / HW);
+      const float tt = (float)t_int[b] * inv_steps1;
+      const float a = (1.f - tt) * (1.f - tt) * 0.25f;
+      const float sa = sqrtf(a), sb = sqrtf(1.f - a);
+      if (eps_out) eps_out[i] = nrm[k];
+      const T v = from_f32<T>(x[i] * sa + nrm[k] * sb);
       out[pix * ldout + c] = v;
       if (out2) out2[pix * ldout2 + c] = v;
     }
@@ -696,8 +717,8 @@ template <typename T>
 static int noise_rng_t(const float* x, const int32_t* t, uint64_t seed, uint64_t sid, uint64_t off, float* eps_out, void* out, int ldout,
                        void* out2, int ldout2, int B, int HW, int C, int steps, hipStream_t s) {
   const size_t npix = (size_t)B * HW;
-  hipLaunchKernelGGL(noise_rng_kernel<T>, dim3(blocks_for(npix, 256)), dim3(256), 0, s, x, t, seed, sid, off, eps_out,
-                     reinterpret_cast<T*>(out), ldout, reinterpret_cast<T*>(out2), ldout2, npix, HW, C, 1.0f / (float)(steps + 1));
+  hipLaunchKernelGGL(noise_rng_kernel<T>, dim3(blocks_for(npix * C / 4 + 2, 256)), dim3(256), 0, s, x, t, seed, sid, off, eps_out,
+                     reinterpret_cast<T*>(out), ldout, reinterpret_cast<T*>(out2), ldout2, npix * C, HW, C, 1.0f / (float)(steps + 1));
   return gct2_check_launch("noise_image_rng");
 }
 int pw_noise_rng(int dtype, const float* x, const int32_t* t, uint64_t seed, uint64_t sid, uint64_t off, float* eps_out, void* out,

@@ -13,6 +13,7 @@ LAYERS = {  # name: (kind, H, W, Cin, Cout)  kind: conv fwd / convT fwd / convT 
     "D1.fwd": ("conv_fwd", 64, 64, 128, 256), "D2.fwd": ("conv_fwd", 32, 32, 256, 512),
     "U2.fwd": ("convT_fwd", 16, 16, 1024, 256), "U1.fwd": ("convT_fwd", 32, 32, 512, 128), "U0.fwd": ("convT_fwd", 64, 64, 256, 64),
     "D3.fwd": ("conv_fwd", 16, 16, 512, 512), "U3.fwd": ("convT_fwd", 8, 8, 1024, 512),
+    "U3.dgrad": ("convT_dgrad", 8, 8, 1024, 512), "D3.dgrad": ("conv_dgrad", 16, 16, 512, 512),
     "U2.dgrad": ("convT_dgrad", 16, 16, 1024, 256), "D2.dgrad": ("conv_dgrad", 32, 32, 256, 512),
     "U1.dgrad": ("convT_dgrad", 32, 32, 512, 128), "U0.dgrad": ("convT_dgrad", 64, 64, 256, 64), "D1.dgrad": ("conv_dgrad", 64, 64, 128, 256),
 }
