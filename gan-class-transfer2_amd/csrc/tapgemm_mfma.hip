@@ -478,7 +478,7 @@ int launch(TapGemmParams p, hipStream_t s) {
     int want = (512 + tiles - 1) / tiles;
     const size_t slab = npix * p.N * sizeof(float);
     want = (int)std::min<size_t>((size_t)want, slab_room / slab);
-    want = std::min(want, niter / 2);
+    want = std::min(want, niter / 8);   // >= 8 K-steps per work-group: shorter slices are all prologue + slab traffic (2x2 levels: 43 -> 24 us)
     if (want >= 2) {
       const int per = (niter + want - 1) / want;
       p.ksplit = (niter + per - 1) / per;

@@ -9,6 +9,12 @@ dev = torch.device("cuda", 0)
 ws = torch.empty(64 << 18, dtype=torch.float32, device=dev)
 L.call("gct2_set_workspace", ws.data_ptr(), ws.numel() * 4)
 B = 64
+SMALL = {
+    "D3.fwd": ("conv_fwd", 16, 16, 512, 512), "D4.fwd": ("conv_fwd", 8, 8, 512, 512), "D5.fwd": ("conv_fwd", 4, 4, 512, 512),
+    "U5.fwd": ("convT_fwd", 2, 2, 512, 512), "U4.fwd": ("convT_fwd", 4, 4, 1024, 512), "U3.fwd": ("convT_fwd", 8, 8, 1024, 512),
+    "U3.dgrad": ("convT_dgrad", 8, 8, 1024, 512), "U4.dgrad": ("convT_dgrad", 4, 4, 1024, 512), "U5.dgrad": ("convT_dgrad", 2, 2, 512, 512),
+    "D5.dgrad": ("conv_dgrad", 4, 4, 512, 512), "D4.dgrad": ("conv_dgrad", 8, 8, 512, 512), "D3.dgrad": ("conv_dgrad", 16, 16, 512, 512),
+}
 LAYERS = {  # name: (kind, H, W, Cin, Cout)  kind: conv fwd / convT fwd / convT dgrad (conv-form) / conv dgrad (convT-form)
     "D1.fwd": ("conv_fwd", 64, 64, 128, 256), "D2.fwd": ("conv_fwd", 32, 32, 256, 512),
     "U2.fwd": ("convT_fwd", 16, 16, 1024, 256), "U1.fwd": ("convT_fwd", 32, 32, 512, 128), "U0.fwd": ("convT_fwd", 64, 64, 256, 64),
@@ -49,6 +55,8 @@ def run(name, variant, iters=20):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     return us, flops / us / 1e6
+if os.environ.get("LAYERSET") == "small":
+    LAYERS = SMALL
 variants = [int(v) for v in sys.argv[1:]] or [2, 3, 2 + 256, 2 + 512, 3 + 256, 3 + 512]
 print("layer      " + "".join(f"{'v%d/a%d' % (v & 255, v >> 8):>16s}" for v in variants))
 for name in LAYERS:
