@@ -41,7 +41,7 @@ SIGNATURES = {
     "gct2_convT4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gct2_dense_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gct2_dense_bwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
-    "gct2_dense_head_train": [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gct2_dense_head_train": [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "gct2_rng_uniform_int": [_u64, _u64, _u64, _vp, _sz, _i, _i, _vp],
     "gct2_rng_normal": [_u64, _u64, _u64, _vp, _sz, _vp],
     "gct2_noise_image": [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

@@ -25,7 +25,7 @@ int pw_dense_fwd(int, const void*, int, const float*, const float*, float*, int,
 int pw_dense_bwd(int, const void*, int, const float*, const float*, void*, int, float*, float*, int, int, int, int, hipStream_t);
 int pw_mse(const float*, const float*, float*, float*, float*, size_t, const float*, hipStream_t);
 int pw_dense_head_train(int, const void*, int, const float*, const float*, const float*, float*, void*, int, float*, float*, float*, float*,
-                        int, int, int, int, const float*, float*, hipStream_t);
+                        int, int, int, int, const float*, float*, const void*, int, hipStream_t);
 int pw_colsum(int, const void*, int, float*, size_t, int, float, hipStream_t);
 int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const float*, const int32_t*, int, hipStream_t);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
@@ -107,7 +107,7 @@ int run_wgrad(int dtype, const WgradParams& p, void* stream) {
 
 extern "C" {
 
-int gct2_abi_version(void) { return 5; }
+int gct2_abi_version(void) { return 6; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
 void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant(v >> 16); }
@@ -212,17 +212,19 @@ int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const floa
 
 int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, const float* b, const float* target, float* pred, void* dx,
                           int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
-                          const float* loss_scale_ptr, float* db_dx, void* stream) {
+                          const float* loss_scale_ptr, float* db_dx, const void* x2, int ldx2, void* stream) {
   if ((dtype != GCT2_BF16 && dtype != GCT2_F16) || !x || !w || !target || !dx || !dw || !loss || !partials)
     return gct2_fail(GCT2_EINVAL, "dense_head_train: 16-bit dtypes only / null pointer (use dense_fwd + mse_fwd_bwd + dense_bwd)");
-  if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout > 4 || ldx < Cin || ldx % 8 || lddx % 8 || Cmask % 8 || Cmask <= 0 || Cmask > Cin ||
+  if (x2 && (ldx2 < Cin - Cmask || ldx2 % 4 || (uintptr_t)x2 % 8 || Cin - Cmask > 4))
+    return gct2_fail(GCT2_EINVAL, "dense_head_train: x2 holds at most 4 channels per pixel in 8-byte aligned rows (ldx2 multiple of 4)");
+  if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout > 4 || ldx < (x2 ? Cmask : Cin) || ldx % 8 || lddx % 8 || Cmask % 8 || Cmask <= 0 || Cmask > Cin ||
       lddx < Cmask || (Cin + 1) * Cout > 256)
     return gct2_fail(GCT2_EINVAL, "dense_head_train: bad shape (need ldx, lddx, Cmask multiples of 8, (Cin+1)*Cout <= 256)");
   if ((uintptr_t)x % 16 || (uintptr_t)dx % 16) return gct2_fail(GCT2_EINVAL, "dense_head_train: views must be 16-byte aligned");
   if ((size_t)256 * ldx * 2 + (size_t)256 * Cmask * 2 + 256 * 16 + (size_t)ldx * 16 > 160 * 1024)
     return gct2_fail(GCT2_EINVAL, "dense_head_train: ldx=%d too large for the LDS tile", ldx);
   return pw_dense_head_train(dtype, x, ldx, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, loss_scale_ptr,
-                             db_dx, S(stream));
+                             db_dx, x2, ldx2, S(stream));
 }
 
 int gct2_rng_uniform_int(uint64_t seed, uint64_t stream_id, uint64_t offset, int32_t* out, size_t n, int lo, int hi, void* stream) {
@@ -244,7 +246,7 @@ int gct2_noise_image(int dtype, const float* x, const int32_t* t_int, const floa
 int gct2_noise_image_rng(int dtype, const float* x, const int32_t* t_int, uint64_t seed, uint64_t stream_id, uint64_t offset,
                          float* eps_out, void* out, int ldout, void* out2, int ldout2, int B, int HW, int C, int steps, void* stream) {
   if (!dtype_ok(dtype) || !x || !t_int || !out) return gct2_fail(GCT2_EINVAL, "noise_image_rng: bad dtype or null pointer");
-  if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || (out2 && ldout2 < C) || steps <= 0)
+  if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || (out2 && ldout2 < C) || steps <= 0 || (size_t)B * HW * C >= ((size_t)1 << 31))
     return gct2_fail(GCT2_EINVAL, "noise_image_rng: bad shape");
   return pw_noise_rng(dtype, x, t_int, seed, stream_id, offset, eps_out, out, ldout, out2, ldout2, B, HW, C, steps, S(stream));
 }

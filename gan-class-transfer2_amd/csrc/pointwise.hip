@@ -38,16 +38,24 @@ __global__ void rng_uniform_int_kernel(uint64_t seed, uint64_t stream_id, uint64
   out[i] = lo + (int32_t)__umulhi(r[e & 3], range);
 }
 
+// Box-Muller on the hardware transcendental units: v_log_f32 (log2), v_sin_f32 / v_cos_f32 (argument in revolutions, so
+// u2 goes in as is).  Absolute error ~1e-6 on a unit normal - a noise source, not a parity quantity (TF's own stream
+// cannot be reproduced) - and ~5x fewer instructions than libm's logf / sinf / cosf.
+__device__ __forceinline__ void box_muller(uint32_t r0, uint32_t r1, float& zc, float& zs) {
+  const float u1 = ((float)(r0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(r1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float rad = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // -2 ln u1 = -2 ln2 log2 u1
+  zc = rad * __builtin_amdgcn_cosf(u2);
+  zs = rad * __builtin_amdgcn_sinf(u2);
+}
 // element e uses counter e>>2; lanes (0,1) of the counter feed elements 4c,4c+1, lanes (2,3) feed 4c+2,4c+3
 __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t stream_id, uint64_t e) {
   uint32_t r[4];
   philox4x32_10(seed, stream_id, e >> 2, r);
   const int pair = (int)((e >> 1) & 1);
-  const float u1 = ((float)(r[2 * pair] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  const float u2 = ((float)(r[2 * pair + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  const float rad = sqrtf(-2.0f * logf(u1));
-  const float ang = 6.283185307179586f * u2;
-  return (e & 1) ? rad * sinf(ang) : rad * cosf(ang);
+  float zc, zs;
+  box_muller(r[2 * pair], r[2 * pair + 1], zc, zs);
+  return (e & 1) ? zs : zc;
 }
 __global__ void rng_normal_kernel(uint64_t seed, uint64_t stream_id, uint64_t offset, float* out, size_t n) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -69,30 +77,36 @@ __global__ void noise_rng_kernel(const float* __restrict__ x, const int32_t* __r
     uint32_t r[4];
     philox4x32_10(seed, stream_id, ctr, r);
     float nrm[4];
-#pragma unroll
-    for (int pair = 0; pair < 2; pair++) {
-      const float u1 = ((float)(r[2 * pair] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const float u2 = ((float)(r[2 * pair + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const float rad = sqrtf(-2.0f * logf(u1));
-      const float ang = 6.283185307179586f * u2;
-      nrm[2 * pair] = rad * cosf(ang);
-      nrm[2 * pair + 1] = rad * sinf(ang);
-    }
+    box_muller(r[0], r[1], nrm[0], nrm[1]);
+    box_muller(r[2], r[3], nrm[2], nrm[3]);
+    // elements 4 ctr .. 4 ctr + 3 of the flattened image: (pixel, channel, batch) advance incrementally (one division per thread)
+    const uint64_t e0 = 4 * ctr;
+    const uint64_t first = e0 < offset ? offset : e0;
+    if (first >= offset + n) continue;
+    const uint32_t i0 = (uint32_t)(first - offset);
+    uint32_t pix = i0 / (uint32_t)C, c = i0 - pix * (uint32_t)C;
+    uint32_t b = pix / (uint32_t)HW, rem = pix - b * (uint32_t)HW;
+    float sa = 0.f, sb = 0.f;
+    bool have = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const uint64_t e = 4 * ctr + k;
-      if (e < offset || e >= offset + n) continue;
+      const uint64_t e = e0 + k;
+      if (e < first || e >= offset + n) continue;
+      if (!have) {
+        const float tt = (float)t_int[b] * inv_steps1;
+        const float a = (1.f - tt) * (1.f - tt) * 0.25f;
+        sa = sqrtf(a); sb = sqrtf(1.f - a);
+        have = true;
+      }
       const size_t i = (size_t)(e - offset);
-      const size_t pix = i / C;
-      const int c = (int)(i - pix * C);
-      const int b = (int)(pix / HW);
-      const float tt = (float)t_int[b] * inv_steps1;
-      const float a = (1.f - tt) * (1.f - tt) * 0.25f;
-      const float sa = sqrtf(a), sb = sqrtf(1.f - a);
       if (eps_out) eps_out[i] = nrm[k];
       const T v = from_f32<T>(x[i] * sa + nrm[k] * sb);
-      out[pix * ldout + c] = v;
-      if (out2) out2[pix * ldout2 + c] = v;
+      out[(size_t)pix * ldout + c] = v;
+      if (out2) out2[(size_t)pix * ldout2 + c] = v;
+      if (++c == (uint32_t)C) {
+        c = 0; ++pix;
+        if (++rem == (uint32_t)HW) { rem = 0; ++b; have = false; }
+      }
     }
   }
 }
@@ -350,7 +364,8 @@ __global__ __launch_bounds__(256, 2) void dense_head_mfma_kernel(const T* __rest
                                                                  const float* __restrict__ bias, const float* __restrict__ target,
                                                                  float* __restrict__ pred_out, T* __restrict__ dx, int lddx,
                                                                  float* __restrict__ part, int M, int Cin, int Cout,
-                                                                 const float* __restrict__ loss_scale_ptr) {
+                                                                 const float* __restrict__ loss_scale_ptr,
+                                                                 const T* __restrict__ x2, int ldx2) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, q = lane & 15;
   const float gscale = (loss_scale_ptr ? *loss_scale_ptr : 1.f) * 2.0f / ((float)M * (float)Cout);
@@ -413,7 +428,12 @@ __global__ __launch_bounds__(256, 2) void dense_head_mfma_kernel(const T* __rest
       const T* row = x + (size_t)p * ld + 8 * g;
       xf[0] = gload128(row);
       xf[1] = gload128(row + 32);
-      if (g == 0) xf[2] = gload128(row + 64);
+      if (g == 0) {
+        if (x2) {   // channels 64.. live in a packed side buffer (<= 4 of them, 8-byte aligned rows)
+          const u32x2_t v2 = *reinterpret_cast<const u32x2_t*>(x2 + (size_t)p * ldx2);
+          xf[2] = u32x4_t{v2[0], v2[1], 0u, 0u};
+        } else xf[2] = gload128(row + 64);
+      }
     }
   };
   u32x4_t cur[3], nxt[3];
@@ -760,21 +780,23 @@ int pw_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float*
 template <typename T>
 static int dense_head_train_t(const void* x, int ld, const float* w, const float* b, const float* target, float* pred, void* dx, int lddx,
                               float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask, const float* ls,
-                              float* db_dx, hipStream_t s) {
+                              float* db_dx, const void* x2, int ldx2, hipStream_t s) {
   // matrix-core version: the reference head (64 masked U_0 channels + 3 image channels -> 3 outputs) with a registered workspace
   size_t ws_bytes = 0;
   float* ws = gct2_workspace(&ws_bytes);
-  if (Cmask == 64 && Cin >= 64 && Cin <= 72 && ld >= 72 && Cout <= 3) {
+  if (Cmask == 64 && Cin >= 64 && Cin <= (x2 ? 68 : 72) && (x2 || ld >= 72) && Cout <= 3) {
     const int ngroups = (M + 15) / 16;
     const int grid = std::min(512, (ngroups + 3) / 4);
     if (ws && ws_bytes >= (size_t)grid * HEAD_ROW * sizeof(float)) {
       hipLaunchKernelGGL(dense_head_mfma_kernel<T>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const T*>(x), ld, w, b, target, pred,
-                         reinterpret_cast<T*>(dx), lddx, ws, M, Cin, Cout, ls);
+                         reinterpret_cast<T*>(dx), lddx, ws, M, Cin, Cout, ls, reinterpret_cast<const T*>(x2), ldx2);
       hipLaunchKernelGGL(dense_head_finish_kernel, dim3(HEAD_ROW / 32), dim3(1024), 0, s, ws, grid, dw, db, loss, db_dx, Cin * Cout, Cout,
                          1.0f / ((float)M * (float)Cout));
       return gct2_check_launch("dense_head_train");
     }
   }
+  if (x2) return gct2_fail(GCT2_EINVAL, "dense_head_train: a split input (x2) needs the matrix-core version: Cmask = 64, Cin <= 68, "
+                                        "Cout <= 3 and a registered workspace");
   constexpr int PIX = 256;
   const size_t lds = (size_t)PIX * ld * 2 + (size_t)PIX * Cmask * 2 + PIX * 16 + (size_t)ld * 16;
   const int ntiles = (M + PIX - 1) / PIX;
@@ -792,9 +814,10 @@ static int dense_head_train_t(const void* x, int ld, const float* w, const float
 }
 int pw_dense_head_train(int dtype, const void* x, int ld, const float* w, const float* b, const float* target, float* pred, void* dx,
                         int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
-                        const float* ls, float* db_dx, hipStream_t s) {
-  if (dtype == GCT2_BF16) return dense_head_train_t<__bf16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, s);
-  return dense_head_train_t<_Float16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, s);
+                        const float* ls, float* db_dx, const void* x2, int ldx2, hipStream_t s) {
+  if (dtype == GCT2_BF16)
+    return dense_head_train_t<__bf16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, x2, ldx2, s);
+  return dense_head_train_t<_Float16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, x2, ldx2, s);
 }
 int pw_mse(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n, const float* ls, hipStream_t s) {
   const int nb = blocks_for(n, 1024) > 1024 ? 1024 : blocks_for(n, 1024);

@@ -255,18 +255,26 @@ class UNetEngine:
     def sample_and_noise_into_r0(self, b: _Buffers, x: torch.Tensor, keep_eps: bool = False) -> None:
         """train.py:224-234 in two launches: t_int, then noising with eps drawn inside the kernel (same stream positions
         as sample_noise + noise_into_r0, bit-identical result, no eps round trip through HBM)."""
-        s, t = self._stream(), self.topo
+        s = self._stream()
+        out, ldout, out2, ldout2 = self._noise_targets(b)
         call("gct2_rng_uniform_int", self.rng_seed, 1, self.rng_offset_t, b.t_int.data_ptr(), b.B, 1, self.steps, s)
         call("gct2_noise_image_rng", self.dtype, x.data_ptr(), b.t_int.data_ptr(), self.rng_seed, 2, self.rng_offset_eps,
-             b.eps.data_ptr() if keep_eps else None, self._slice_ptr(b.R[0], t.fu(0)), b.ld[0], b.img.data_ptr(), 4,
-             b.B, b.H * b.W, 3, self.steps, s)
+             b.eps.data_ptr() if keep_eps else None, out, ldout, out2, ldout2, b.B, b.H * b.W, 3, self.steps, s)
         self.rng_offset_t += b.B
         self.rng_offset_eps += b.eps.numel()
 
+    def _noise_targets(self, b: _Buffers) -> Tuple[int, int, Optional[int], int]:
+        """where the noised image goes: always the packed copy `img` (DownShuffle_0 reads it, and so does the fused head
+        through its x2 argument); the image slice of R_0 only when the unfused Dense kernels will read R_0 as one
+        67-channel view (its 6-byte writes into 144-byte rows cost more than the rest of the noising)."""
+        if self.fused_head_ok():
+            return b.img.data_ptr(), 4, None, 0
+        return self._slice_ptr(b.R[0], self.topo.fu(0)), b.ld[0], b.img.data_ptr(), 4
+
     def noise_into_r0(self, b: _Buffers, x: torch.Tensor) -> None:
-        t = self.topo
-        call("gct2_noise_image", self.dtype, x.data_ptr(), b.t_int.data_ptr(), b.eps.data_ptr(),
-             self._slice_ptr(b.R[0], t.fu(0)), b.ld[0], b.img.data_ptr(), 4, b.B, b.H * b.W, 3, self.steps, self._stream())
+        out, ldout, out2, ldout2 = self._noise_targets(b)
+        call("gct2_noise_image", self.dtype, x.data_ptr(), b.t_int.data_ptr(), b.eps.data_ptr(), out, ldout, out2, ldout2,
+             b.B, b.H * b.W, 3, self.steps, self._stream())
 
     def load_input_into_r0(self, b: _Buffers, noised: torch.Tensor) -> None:
         """Denoiser.call on an externally prepared image (sampler / inference path)."""
@@ -309,7 +317,9 @@ class UNetEngine:
         return b.loss
 
     def fused_head_ok(self) -> bool:
-        return self.use_fused_head and self.dtype != F32 and self.topo.fu(0) % 8 == 0
+        """the matrix-core head with the split input (R_0's UpShuffle_0 channels + the packed image): the reference topology
+        (Fu_0 = 64) in a 16-bit mode with a workspace; anything else runs dense_fwd + mse_fwd_bwd + dense_bwd."""
+        return self.use_fused_head and self.dtype != F32 and self.topo.fu(0) == 64 and self.workspace is not None
 
     def head_train(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
         """Dense(3) + fp32 MSE + both of their gradients in one pass over R_0 (gct2_dense_head_train)."""
@@ -318,7 +328,7 @@ class UNetEngine:
         call("gct2_dense_head_train", self.dtype, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"),
              target.data_ptr(), b.pred.data_ptr(), b.dR[0].data_ptr(), b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"),
              b.loss.data_ptr(), b.partials.data_ptr(), b.B * b.H * b.W, t.fu(0) + 3, 3, t.fu(0), ls_ptr, A.gptr("U0.b"),
-             self._stream())
+             b.img.data_ptr(), 4, self._stream())
         return b.loss
 
     def _ready(self, layer: str) -> None:

@@ -117,12 +117,15 @@ int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const floa
  *   pred = x w + b;  loss = mean((pred - target)^2);  dpred = loss_scale * 2 (pred - target) / (M Cout);
  *   dx[m, i < Cmask] = (x > 0) * dpred w^T;  dw += x^T dpred;  db += sum dpred.
  * target: fp32 [M,Cout]; pred: fp32 [M,Cout] or NULL; loss: 1 float; partials: >= 1024 floats scratch.
+ * x2 (may be NULL): the input channels [Cmask, Cin) come from this second view (ldx2 elements per pixel, at most 4
+ * channels, 8-byte aligned rows) instead of x - the concat [UpShuffle_0 output, image] is then never assembled at all
+ * (the image lives in its packed copy only).  Needs Cmask = 64, Cout <= 3 and a registered workspace.
  * Replaces train.py:198-202 + 262-272 and their autodiff inside Keras fit (train.py:516). */
 int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, const float* b,
                           const float* target, float* pred, void* dx, int lddx, float* dw, float* db,
                           float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
                           const float* loss_scale_ptr, float* db_dx /* += column sums of dx, or NULL */,
-                          void* stream);
+                          const void* x2, int ldx2, void* stream);
 
 /* ---- Trainer.call pieces   train.py:223-272 -------------------------------------------------- */
 /* t_int[b] ~ U{1..steps} (train.py:224-226) and eps ~ N(0,1) (train.py:227) from a counter-based

@@ -414,11 +414,13 @@ def test_dense_fwd_bwd(gpu, dt):
 
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("M", [1000, 256 * 5, 16 * 4 * 512 + 7])
-@pytest.mark.parametrize("with_ws", [False, True])
+@pytest.mark.parametrize("with_ws", [False, True, "split"])
 def test_dense_head_train_fused(gpu, dt, M, with_ws):
     """fused Dense(3) + MSE + both gradients == the three separate kernels' definitions (ragged last tile at M=1000).
     with_ws: a registered workspace selects the matrix-core version (partial rows, no atomics); without it the LDS-tile
-    version runs.  The largest M gives every wave of the 512-work-group grid more than one trip."""
+    version runs.  The largest M gives every wave of the 512-work-group grid more than one trip.
+    "split": the image channels [64, 67) come from a packed second view (x2, ld 4); R_0's own slice holds NaN."""
+    split, with_ws = with_ws == "split", bool(with_ws)
     Cin, Cout, ld, Cmask = 67, 3, 72, 64
     ws = torch.full((1 << 20,), float("nan"), device=gpu) if with_ws else None
     lib().call("gct2_set_workspace", ws.data_ptr() if with_ws else None, ws.numel() * 4 if with_ws else 0)
@@ -431,6 +433,10 @@ def test_dense_head_train_fused(gpu, dt, M, with_ws):
     if with_ws:
         xb[:, Cin:] = float("nan")                                  # pad channels must not leak into anything
     xb[:, :Cin] = dev(x, dt, gpu)
+    x2 = torch.zeros(M, 4, dtype=TDT[dt], device=gpu)
+    if split:
+        x2[:, :3] = xb[:, Cmask:Cin]
+        xb[:, Cmask:] = float("nan")
     t32 = lambda a: torch.tensor(a, dtype=torch.float32, device=gpu)
     wd, bd, td = t32(w), t32(b), t32(tgt)
     pred = torch.zeros(M, Cout, device=gpu); dxb = torch.full((M, ld), 5.0, dtype=TDT[dt], device=gpu)
@@ -440,7 +446,7 @@ def test_dense_head_train_fused(gpu, dt, M, with_ws):
     try:
         lib().call("gct2_dense_head_train", dt, xb.data_ptr(), ld, wd.data_ptr(), bd.data_ptr(), td.data_ptr(), pred.data_ptr(),
                    dxb.data_ptr(), ld, dw.data_ptr(), db.data_ptr(), loss.data_ptr(), part.data_ptr(), M, Cin, Cout, Cmask,
-                   scale.data_ptr(), dbx.data_ptr(), stream())
+                   scale.data_ptr(), dbx.data_ptr(), x2.data_ptr() if split else None, 4 if split else 0, stream())
         torch.cuda.synchronize()
     finally:
         lib().call("gct2_set_workspace", None, 0)
