@@ -9,7 +9,7 @@ FAMILY = [("wgrad_kernel", "wgrad"), ("tapgemm_kernelIDF16bLi0E", "conv_form"), 
           ("tapgemm_kernel<", None)]
 
 def family(name):
-    if "wgrad_kernel" in name and "rgb" not in name:
+    if re.search(r"wgrad(256)?_kernel", name) and "rgb" not in name:
         return "wgrad"
     m = re.search(r"tapgemm_kernelI\w+?Li(\d)E", name)
     if m:
