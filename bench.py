@@ -273,7 +273,7 @@ def main():
                 out["kernels_two_streams"] = families(timer.events, ev_steps)[2]
         if world == 1 and not args.no_cpu_baseline:
             kw = dict(pixel_size=128, max_size=512)
-            v3, s3, n3 = cpu_baseline(dict(octaves=6, **kw), S, 4, 3, 1)
+            v3, s3, n3 = cpu_baseline(dict(octaves=6, **kw), S, 4, 100, 1, budget_s=12.0)   # ~12 s of CPU work
             v1, s1, n1 = cpu_baseline(dict(octaves=5, **kw), 32, 8, 10, 2)
             out["cpu_baseline"] = {"value": round(v3, 3), "unit": "images/sec", "cores": host_cores(), "kind": "port",
                                    "sample": f"oracle/torch_cross.py (PyTorch CPU fp32 restatement of train.py; TensorFlow unavailable), "
