@@ -27,6 +27,9 @@ int pw_mse(const float*, const float*, float*, float*, float*, size_t, const flo
 int pw_dense_head_train(int, const void*, int, const float*, const float*, const float*, float*, void*, int, float*, float*, float*, float*,
                         int, int, int, int, const float*, float*, const void*, int, hipStream_t);
 int pw_colsum(int, const void*, int, float*, size_t, int, float, hipStream_t);
+int pw_diffusion_mix(int, const float*, const float*, float, float*, void*, int, void*, int, size_t, int, hipStream_t);
+int pw_diffusion_update(const float*, const float*, float, float*, float*, size_t, hipStream_t);
+int pw_noise_edits(const float*, const float*, int, float*, int, int, int, hipStream_t);
 int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const float*, const int32_t*, int, hipStream_t);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
 int pw_ls_init(gct2_loss_scale_state*, float, hipStream_t);
@@ -107,7 +110,7 @@ int run_wgrad(int dtype, const WgradParams& p, void* stream) {
 
 extern "C" {
 
-int gct2_abi_version(void) { return 6; }
+int gct2_abi_version(void) { return 7; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
 void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant(v >> 16); }
@@ -249,6 +252,27 @@ int gct2_noise_image_rng(int dtype, const float* x, const int32_t* t_int, uint64
   if (B <= 0 || HW <= 0 || C <= 0 || ldout < C || (out2 && ldout2 < C) || steps <= 0 || (size_t)B * HW * C >= ((size_t)1 << 31))
     return gct2_fail(GCT2_EINVAL, "noise_image_rng: bad shape");
   return pw_noise_rng(dtype, x, t_int, seed, stream_id, offset, eps_out, out, ldout, out2, ldout2, B, HW, C, steps, S(stream));
+}
+
+int gct2_diffusion_mix(int dtype, const float* x_theta, const float* eps_theta, float alpha, float* fake, void* out, int ldout, void* out2,
+                       int ldout2, size_t npix, int C, void* stream) {
+  if (!dtype_ok(dtype) || !x_theta || !eps_theta || !fake || !out) return gct2_fail(GCT2_EINVAL, "diffusion_mix: bad dtype or null pointer");
+  if (npix == 0 || C <= 0 || ldout < C || (out2 && ldout2 < C) || !(alpha >= 0.f && alpha <= 1.f))
+    return gct2_fail(GCT2_EINVAL, "diffusion_mix: bad shape or alpha outside [0, 1]");
+  return pw_diffusion_mix(dtype, x_theta, eps_theta, alpha, fake, out, ldout, out2, ldout2, npix, C, S(stream));
+}
+
+int gct2_diffusion_update(const float* pred, const float* fake, float alpha, float* x_theta, float* eps_theta, size_t n, void* stream) {
+  if (!pred || !fake || !x_theta || !eps_theta || n == 0) return gct2_fail(GCT2_EINVAL, "diffusion_update: null pointer or n == 0");
+  if (!(alpha >= 0.f && alpha < 1.f)) return gct2_fail(GCT2_EINVAL, "diffusion_update: alpha must be in [0, 1)");
+  return pw_diffusion_update(pred, fake, alpha, x_theta, eps_theta, n, S(stream));
+}
+
+int gct2_noise_edits(const float* eps, const float* dictionary, int K, float* out, int H, int W, int C, void* stream) {
+  if (!eps || !dictionary || !out) return gct2_fail(GCT2_EINVAL, "noise_edits: null pointer");
+  if (H <= 0 || W <= 0 || C <= 0 || K <= 0 || (H & 3) || (W & 3))
+    return gct2_fail(GCT2_EINVAL, "noise_edits: H=%d W=%d must be positive multiples of 4 (avg_pool2d(4, 4, 'SAME') without padding)", H, W);
+  return pw_noise_edits(eps, dictionary, K, out, H, W, C, S(stream));
 }
 
 int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n,

@@ -576,6 +576,65 @@ __global__ __launch_bounds__(1024) void dense_head_finish_kernel(const float* __
   }
 }
 
+// ---- log_sample (train.py:323-496): the sampler's pointwise steps, fp32 state ------------------------------------------------
+// fake = sqrt(a) x_theta + sqrt(1-a) eps_theta (train.py:372-375, 441-444); also stored in the compute dtype where the network
+// reads its input (packed image and/or the image slice of R_0)
+template <typename T>
+__global__ void diffusion_mix_kernel(const float* __restrict__ x, const float* __restrict__ e, float sa, float sb,
+                                     float* __restrict__ fake, T* __restrict__ out, int ldout, T* __restrict__ out2, int ldout2,
+                                     size_t n, int C) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float f = sa * x[i] + sb * e[i];
+    fake[i] = f;
+    const size_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    out[pix * ldout + c] = from_f32<T>(f);
+    if (out2) out2[pix * ldout2 + c] = from_f32<T>(f);
+  }
+}
+// predict_x branch (train.py:394-398, 463-467): x_theta = prediction; eps_theta = (fake - sqrt(a) x_theta) / sqrt(1-a)
+__global__ void diffusion_update_kernel(const float* __restrict__ pred, const float* __restrict__ fake, float sa, float sb,
+                                        float* __restrict__ x, float* __restrict__ e, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float p = pred[i];
+    x[i] = p;
+    e[i] = (fake[i] - sa * p) / sb;
+  }
+}
+// the four noise variants of train.py:416-431 from one eps image [H,W,C]: out[0] = eps, out[1] = nearest-upsample x4 of the
+// 4x4 average pool, out[2] = rolled by one pixel along H and W, out[3] = per-pixel nearest entry of dictionary [H,W,K,C]
+__global__ void noise_edits_kernel(const float* __restrict__ eps, const float* __restrict__ dict, int K, float* __restrict__ out,
+                                   int H, int W, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * W) return;
+  const int h = idx / W, w = idx - h * W;
+  const size_t img = (size_t)H * W * C;
+  const float* px = eps + (size_t)idx * C;
+  const int hs = (h + H - 1) % H, wsft = (w + W - 1) % W;     // tf.roll(x, 1, axis): out[i] = in[i - 1]
+  const int h0 = h & ~3, w0 = w & ~3;
+  for (int c = 0; c < C; c++) {
+    out[(size_t)idx * C + c] = px[c];
+    float a = 0.f;
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) a += eps[((size_t)(h0 + i) * W + (w0 + j)) * C + c];
+    out[img + (size_t)idx * C + c] = a * (1.0f / 16.0f);
+    out[2 * img + (size_t)idx * C + c] = eps[((size_t)hs * W + wsft) * C + c];
+  }
+  int best = 0;
+  float bestd = 0.f;
+  for (int k = 0; k < K; k++) {
+    float d = 0.f;
+    for (int c = 0; c < C; c++) {
+      const float t = px[c] - dict[((size_t)idx * K + k) * C + c];
+      d += t * t;
+    }
+    if (k == 0 || d < bestd) { bestd = d; best = k; }          // first minimum, like tf.argmin
+  }
+  for (int c = 0; c < C; c++) out[3 * img + (size_t)idx * C + c] = dict[((size_t)idx * K + best) * C + c];
+}
+
 // ---- bias gradient: db[c] += sum_m dz[m][c] --------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dz, int ld, float* __restrict__ db, size_t M, int C,
@@ -818,6 +877,28 @@ int pw_dense_head_train(int dtype, const void* x, int ld, const float* w, const 
   if (dtype == GCT2_BF16)
     return dense_head_train_t<__bf16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, x2, ldx2, s);
   return dense_head_train_t<_Float16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, x2, ldx2, s);
+}
+template <typename T>
+static int diffusion_mix_t(const float* x, const float* e, float a, float* fake, void* out, int ldout, void* out2, int ldout2, size_t npix,
+                           int C, hipStream_t s) {
+  const size_t n = npix * C;
+  hipLaunchKernelGGL(diffusion_mix_kernel<T>, dim3(blocks_for(n, 256)), dim3(256), 0, s, x, e, sqrtf(a), sqrtf(1.f - a), fake,
+                     reinterpret_cast<T*>(out), ldout, reinterpret_cast<T*>(out2), ldout2, n, C);
+  return gct2_check_launch("diffusion_mix");
+}
+int pw_diffusion_mix(int dtype, const float* x, const float* e, float a, float* fake, void* out, int ldout, void* out2, int ldout2,
+                     size_t npix, int C, hipStream_t s) {
+  if (dtype == GCT2_F32) return diffusion_mix_t<float>(x, e, a, fake, out, ldout, out2, ldout2, npix, C, s);
+  if (dtype == GCT2_BF16) return diffusion_mix_t<__bf16>(x, e, a, fake, out, ldout, out2, ldout2, npix, C, s);
+  return diffusion_mix_t<_Float16>(x, e, a, fake, out, ldout, out2, ldout2, npix, C, s);
+}
+int pw_diffusion_update(const float* pred, const float* fake, float a, float* x, float* e, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(diffusion_update_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pred, fake, sqrtf(a), sqrtf(1.f - a), x, e, n);
+  return gct2_check_launch("diffusion_update");
+}
+int pw_noise_edits(const float* eps, const float* dict, int K, float* out, int H, int W, int C, hipStream_t s) {
+  hipLaunchKernelGGL(noise_edits_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, eps, dict, K, out, H, W, C);
+  return gct2_check_launch("noise_edits");
 }
 int pw_mse(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n, const float* ls, hipStream_t s) {
   const int nb = blocks_for(n, 1024) > 1024 ? 1024 : blocks_for(n, 1024);

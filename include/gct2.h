@@ -149,6 +149,21 @@ int gct2_noise_image_rng(int dtype, const float* x, const int32_t* t_int, uint64
                          uint64_t offset, float* eps_out, void* out, int ldout, void* out2, int ldout2, int B, int HW,
                          int C, int steps, void* stream);
 
+/* ---- log_sample, the reference's sampler (train.py:323-496, predict_x branch): pointwise steps, fp32 state ---- */
+/* fake = sqrt(alpha) x_theta + sqrt(1-alpha) eps_theta  (train.py:372-375, 441-444), alpha = alpha_dash(t) from the caller.
+ * x_theta, eps_theta, fake: fp32 [npix*C]; the network input is also stored in `dtype` into the view out [npix, C] (ldout) and,
+ * if non-NULL, out2 (ldout2) - the packed image and the image slice of the concat buffer. */
+int gct2_diffusion_mix(int dtype, const float* x_theta, const float* eps_theta, float alpha, float* fake,
+                       void* out, int ldout, void* out2, int ldout2, size_t npix, int C, void* stream);
+/* x_theta = pred;  eps_theta = (fake - sqrt(alpha) pred) / sqrt(1-alpha)   (train.py:394-398, 463-467); fp32 [n] each. */
+int gct2_diffusion_update(const float* pred, const float* fake, float alpha, float* x_theta, float* eps_theta,
+                          size_t n, void* stream);
+/* the four inputs of the reverse pass built from one inverted noise image eps [H,W,C] (train.py:416-431): out [4,H,W,C] =
+ * eps | nearest-upsample x4 of avg_pool2d(eps, 4, 4) | tf.roll by 1 along H and W | per-pixel nearest of the K entries of
+ * dictionary [H,W,K,C] (squared distance, first minimum).  H, W multiples of 4. */
+int gct2_noise_edits(const float* eps, const float* dictionary, int K, float* out, int H, int W, int C,
+                     void* stream);
+
 /* loss = mean((target - pred)^2) in fp32 (train.py:272); dpred = loss_scale * 2 (pred-target)/n.
  * `loss` (1 float) is overwritten; `partials` is caller scratch of >= 1024 floats.
  * loss_scale_ptr: device pointer to the current loss scale (fp16 mode) or NULL for 1. */

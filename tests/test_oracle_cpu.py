@@ -131,3 +131,62 @@ def test_oracle_trainer_two_steps_decrease_nothing_weird():
     x, t, e = O.synthetic_batch(cfg, 4)
     l0 = tr.train_step(x, t, e)[0]; l1 = tr.train_step(x, t, e)[0]
     assert tr.iterations == 2 and np.isfinite(l0) and np.isfinite(l1) and l1 < l0     # same batch twice: loss must drop
+
+
+# ---- the sampler restatement (oracle/sampler_oracle.py; train.py:323-496) ------------------------------------------------
+def test_noise_edits_against_definition_loops():
+    from oracle import sampler_oracle as S
+    rng = np.random.default_rng(3)
+    H, W, K = 8, 12, 8
+    eps, dic = rng.standard_normal((1, H, W, 3)), rng.standard_normal((H, W, K, 3))
+    out = S.noise_edits(eps, dic)
+    assert out.shape == (4, H, W, 3) and np.array_equal(out[0], eps[0])
+    for h in range(H):
+        for w in range(W):
+            blk = eps[0, h // 4 * 4:h // 4 * 4 + 4, w // 4 * 4:w // 4 * 4 + 4]
+            assert np.allclose(out[1, h, w], blk.mean((0, 1)), atol=1e-14)                 # avg_pool 4x4 + nearest upsample
+            assert np.array_equal(out[2, h, w], eps[0, (h - 1) % H, (w - 1) % W])           # tf.roll by 1 on both axes
+            d = ((eps[0, h, w][None] - dic[h, w]) ** 2).sum(-1)
+            assert np.array_equal(out[3, h, w], dic[h, w, int(np.argmin(d))])               # per-pixel codebook
+
+
+def test_sampler_identities_and_golden():
+    """(1) call pattern and recurrences of train.py:323-496 checked on an instrumented stand-in denoiser; (2) the committed
+    fixture is reproduced bit for bit."""
+    import importlib.util
+    from oracle import sampler_oracle as S
+    rng = np.random.default_rng(5)
+    img, ex = rng.uniform(-1, 1, (1, 8, 8, 3)), rng.standard_normal((1, 2, 8, 8, 3))
+    dic = rng.standard_normal((8, 8, 8, 3))
+    calls = []
+
+    def den(x):
+        calls.append(x.copy())
+        return 0.5 * x + 0.1
+
+    res = S.log_sample(den, img, ex, dic, steps=5, test_step=2)
+    a = lambda t: float(O.alpha_dash(t, 5))
+    assert len(calls) == 1 + 5 + 5 and [c.shape[0] for c in calls] == [1] * 6 + [6] * 5   # train.py:332, 377, 446
+    assert np.allclose(calls[0], img * a(2) ** 0.5 + ex[0, :1] * (1 - a(2)) ** 0.5, atol=1e-15)
+    assert np.allclose(calls[1], (a(1) ** 0.5 + (1 - a(1)) ** 0.5) * img, atol=1e-15)      # eps_theta starts as the image (train.py:367)
+    # the predict_x update keeps sqrt(a) x_theta + sqrt(1-a) eps_theta == fake: the next input follows from the previous pair
+    x1 = den(calls[1]); calls.pop()
+    e1 = (calls[1] - a(1) ** 0.5 * x1) / (1 - a(1)) ** 0.5
+    assert np.allclose(calls[2], a(2) ** 0.5 * x1 + (1 - a(2)) ** 0.5 * e1, atol=1e-14)
+    assert np.allclose(calls[6][:2], (a(5) ** 0.5 + (1 - a(5)) ** 0.5) * ex[0], atol=1e-14)        # the two random noises lead the batch of six
+    assert res["fake"].shape == (6, 8, 8, 3) and set(res) >= {"denoised", "example_loss", "step_1", "step_0.25", "step_0.5", "step_0.75"}
+    spec = importlib.util.spec_from_file_location("mgs", os.path.join(os.path.dirname(GOLDEN), "make_golden_sampler.py"))
+    mgs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mgs)
+    z = np.load(os.path.join(os.path.dirname(GOLDEN), "tiny_sampler.npz"))
+    cfg, params, image, example, dictionary = mgs.inputs()
+    assert all(np.array_equal(params[k], z["param/" + k]) for k in params) and np.array_equal(image, z["example_image"])
+    out = S.log_sample(S.unet_denoiser(params, cfg), image, example, dictionary, mgs.STEPS, mgs.TEST_STEP)
+    for k, v in out.items():
+        assert np.abs(np.asarray(v) - z["out/" + k]).max() < 1e-12, k
+    # the denoiser evaluations agree with the independent torch formulation
+    import torch as _t
+    pred_o = O.unet_forward(params, image, cfg)[0]
+    pred_t = T.unet_forward(params, image, cfg) if hasattr(T, "unet_forward") else None
+    if pred_t is not None:
+        assert np.abs(pred_o - np.asarray(pred_t)).max() < 1e-10
