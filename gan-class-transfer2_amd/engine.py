@@ -496,6 +496,42 @@ class UNetEngine:
         self.load_input_into_r0(b, noised)
         return self.forward(b)
 
+    # ---- state serialisation (the reference has none, train.py:499-503 only logs) ----------------
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """everything a run needs to continue bit-identically: fp32 parameters and Adam slots (one arena each, layout =
+        ParamArena.offsets), optimizer iterations, RNG stream positions, loss-scale state.  CPU tensors, safetensors-ready."""
+        torch.cuda.synchronize(self.device)
+        A = self.arena
+        sd = {"arena.p": A.p.cpu(), "arena.m": A.m.cpu(), "arena.v": A.v.cpu(),
+              "counters": torch.tensor([self.iterations, self.rng_seed, self.rng_offset_t, self.rng_offset_eps], dtype=torch.int64),
+              "topology": torch.tensor([self.topo.pixel_size, self.topo.max_size, self.topo.octaves, A.total], dtype=torch.int64)}
+        if self.ls_state is not None:
+            sd["loss_scale_state"] = self.ls_state.cpu()
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        A = self.arena
+        want = [self.topo.pixel_size, self.topo.max_size, self.topo.octaves, A.total]
+        if [int(v) for v in sd["topology"]] != want:
+            raise ValueError(f"checkpoint topology {[int(v) for v in sd['topology']]} != engine topology {want}")
+        if ("loss_scale_state" in sd) != (self.ls_state is not None):
+            raise ValueError("checkpoint and engine disagree on dynamic loss scaling (mixed_precision, train.py:34)")
+        for name in ("p", "m", "v"):
+            getattr(A, name).copy_(sd["arena." + name].to(self.device, torch.float32))
+        A.g.zero_()
+        self.iterations, self.rng_seed, self.rng_offset_t, self.rng_offset_eps = (int(v) for v in sd["counters"])
+        if self.ls_state is not None:
+            self.ls_state.copy_(sd["loss_scale_state"].to(self.device))
+        A.refresh_shadow(self._stream())
+
+    def save_checkpoint(self, path: str) -> None:
+        from safetensors.torch import save_file
+        save_file(self.state_dict(), path)
+
+    def load_checkpoint(self, path: str) -> None:
+        from safetensors.torch import load_file        # safetensors: loading executes nothing from the file
+        self.load_state_dict(load_file(path))
+
     def loss_scale(self) -> Tuple[float, int]:
         if self.ls_state is None:
             return 1.0, 0

@@ -246,3 +246,28 @@ def test_fp16_loss_scaling_step(gpu):
     p2 = eng.get_params()
     assert all(np.array_equal(p2[k], p1[k]) for k in p1)
     assert eng.loss_scale() == (2.0 ** 14, 0)
+
+
+def test_checkpoint_roundtrip_continues(gpu, tmp_path):
+    """state serialisation: 2 steps, save, load into a fresh engine, 1 more step on each -> the same loss
+    bit for bit (same parameters, same device RNG positions) and the same parameters / Adam slots afterwards."""
+    cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
+    params = O.init_params(cfg, seed=5)
+    x = torch.tensor(O.synthetic_batch(cfg, seed=0)[0], dtype=torch.float32, device=gpu)
+    a = make_engine(cfg, 1, gpu, rng_seed=11)
+    a.set_params(params)
+    for _ in range(2):
+        a.train_step(x)
+    path = str(tmp_path / "ckpt.safetensors")
+    a.save_checkpoint(path)
+    b = make_engine(cfg, 1, gpu, rng_seed=99)
+    b.load_checkpoint(path)
+    assert (b.iterations, b.rng_seed, b.rng_offset_t, b.rng_offset_eps) == (a.iterations, a.rng_seed, a.rng_offset_t, a.rng_offset_eps)
+    la, lb = a.train_step(x), b.train_step(x)
+    torch.cuda.synchronize()
+    assert float(la[0]) == float(lb[0])
+    for name in ("p", "m", "v"):     # equal up to the fp32 atomics order of the 3-channel layer's weight gradient / the unfused head
+        assert rel_l2(getattr(a.arena, name).cpu().numpy(), getattr(b.arena, name).cpu().numpy()) <= 1e-6, name
+    wrong = make_engine(O.OracleConfig(size=32, pixel_size=32, max_size=64, octaves=3, batch_size=4), 1, gpu)
+    with pytest.raises(ValueError):
+        wrong.load_checkpoint(path)
