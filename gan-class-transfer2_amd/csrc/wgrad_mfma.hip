@@ -18,6 +18,7 @@ namespace {
 constexpr unsigned OOB = 0x80000000u;
 int g_wgrad_variant = 0, g_wgrad_ablate = 0;     // tuning / timing hooks (gct2_debug_tapgemm_variant)
 int g_wgrad_target = 256, g_wgrad_slab_max = 24;  // big-tile work-group target and largest split count reduced through slabs
+int g_wgrad_pipe = 1;                             // big tile: 1 = four 32-row stages with a spanning pipeline (default), 0 = two 64-row buffers
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -320,6 +321,166 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(WgradParams p) {
   }
 }
 
+// ---- the same 256 x 256 tile with a spanning pipeline ----------------------------------------------------------------------
+// One work-group per CU has no second work-group to cover its DMA latency, and a loop that drains vmcnt to 0 at every
+// barrier exposes that latency every step (measured on wgrad256_kernel: MFMA-only 108 us, DMA-only 84 us, together 149 us).
+// Here a stage is 32 rows of r (4 images x 8 KiB = 32 KiB), FOUR stage buffers, the DMA of stage s+3 is issued while stage s
+// is multiplied and only stage s+1 is waited for (counted vmcnt, raw s_barrier): two stages stay in flight across every
+// barrier.  The DMA is inline asm so that hipcc's own vmcnt bookkeeping does not see it (it would drain it at the loop
+// head); every wait for it is written out below.
+#define GCT2_VMCNT_ONLY(n) ((((n) & 0xF) | 0x70 | 0xF00 | ((((n) >> 4) & 3) << 14)))
+__device__ __forceinline__ void dma16_hidden(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff) {
+  const unsigned lds_addr = (unsigned)(uintptr_t)(lds_void_t*)lds_piece;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
+               : "memory", "m0");
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
+  constexpr int IMG = 32 * 256;                                   // one T image of a stage: 32 r-rows x 128 columns
+  constexpr int NDMA = 4;                                         // DMA instructions per wave per stage (one piece of each image)
+  __shared__ __attribute__((aligned(16))) char lds0[4 * IMG];
+  __shared__ __attribute__((aligned(16))) char lds1[4 * IMG];
+  __shared__ __attribute__((aligned(16))) char lds2[4 * IMG];
+  __shared__ __attribute__((aligned(16))) char lds3[4 * IMG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wm = wave >> 2;
+  const int Hs = p.Hs, Ws = p.Ws, Cb = p.Cb, Cs = p.Cs;
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  const int R = p.B * Hs * Ws;
+  const int GC = 16 * Cb;
+  const int tiles_n = (Cs + 255) / 256;
+  const int tiles = ((GC + 255) / 256) * tiles_n;
+  int tile, split;
+  if (p.rsplit >= 8) {            // a whole r-split on one XCD (ids with equal id % 8 share an L2)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % tiles;
+    split = (j / tiles) * 8 + xcd;
+    if (split >= p.rsplit) return;
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
+  const int gc0 = (tile / tiles_n) * 256, cs0 = (tile % tiles_n) * 256;
+  const int steps_total = (R + 63) / 64;
+  const int steps_per = (steps_total + p.rsplit - 1) / p.rsplit;
+  const int step_lo = split * steps_per;
+  const int step_hi = min(steps_total, step_lo + steps_per);
+  if (step_lo >= step_hi) return;
+  const int st_lo = 2 * step_lo, st_hi = 2 * step_hi;             // 32-row stages (rows >= R are zero-filled)
+
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.big), rs_s = make_rsrc(p.small);
+  // piece q = wave of every image = rows 4q .. 4q+3; lane -> row 4q + (lane>>4), physical chunk lane&15
+  const int row0 = 4 * wave + (lane >> 4);
+  const int lc = ((((lane & 15) >> 1) ^ timg_swz(row0)) << 1) | (lane & 1);
+  int kh[2], kw[2], cb[2];
+  bool gc_ok[2], cs_ok[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const int gc = gc0 + 128 * g + lc * 8;
+    gc_ok[g] = gc < GC;
+    const int tap = gc_ok[g] ? gc / Cb : 0;
+    cb[g] = gc_ok[g] ? gc - tap * Cb : 0;
+    kh[g] = tap >> 2; kw[g] = tap & 3;
+    cs_ok[g] = (cs0 + 128 * g + lc * 8) < Cs;
+  }
+  const int ldb2 = p.ldbig * 2, lds2b = p.ldsmall * 2;
+  const int adv_w = 32 % Ws, q1 = 32 / Ws, adv_h = q1 % Hs, adv_b = q1 / Hs;
+  int rb, rh, rw;
+  {
+    const int r = st_lo * 32 + row0;
+    rw = r % Ws; const int t = r / Ws; rh = t % Hs; rb = t / Hs;
+  }
+  auto issue = [&](int st, char* base) {                          // stages are issued in increasing order: (rb, rh, rw) advance
+    const int r = st * 32 + row0;
+    const bool r_ok = r < R;
+    char* piece = base + wave * 1024;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const int h = 2 * rh + kh[g] - 1, w = 2 * rw + kw[g] - 1;
+      const bool okb = gc_ok[g] && r_ok && (unsigned)h < (unsigned)Hb && (unsigned)w < (unsigned)Wb;
+      dma16_hidden(rs_b, piece + g * IMG, okb ? (unsigned)(((rb * Hb + h) * Wb + w) * ldb2 + cb[g] * 2) : OOB);
+      dma16_hidden(rs_s, piece + (2 + g) * IMG, (cs_ok[g] && r_ok) ? (unsigned)(r * lds2b + (cs0 + 128 * g + lc * 8) * 2) : OOB);
+    }
+    rw += adv_w; rh += adv_h; rb += adv_b;
+    if (rw >= Ws) { rw -= Ws; rh++; }
+    if (rh >= Hs) { rh -= Hs; rb++; }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const char* base) {
+    const char* bimg = base + wm * IMG;
+    const char* simg = base + (2 + (wn >> 1)) * IMG;
+    u32x4_t sf[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sf[j] = timg_frag(simg, (wn & 1) * 64 + j * 16, 0, lane);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const u32x4_t bf = timg_frag(bimg, i * 16, 0, lane);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(bf, sf[j], acc[i][j]);
+    }
+  };
+
+  const bool no_dma = p.ablate & 1, no_mfma = p.ablate & 2;
+  // stage s: issue s+3, multiply s, wait until only the DMAs of the stages beyond s+1 are outstanding, barrier
+  auto stage = [&](int st, const char* cur, char* tgt) {
+    if (st + 3 < st_hi && !no_dma) issue(st + 3, tgt);
+    if (!no_mfma) compute(cur);
+    if (no_dma) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
+    else if (st + 3 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
+    else if (st + 2 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
+    else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
+    __builtin_amdgcn_s_barrier();
+  };
+  issue(st_lo, lds0);
+  if (st_lo + 1 < st_hi) issue(st_lo + 1, lds1);
+  if (st_lo + 2 < st_hi) issue(st_lo + 2, lds2);
+  if (st_lo + 2 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
+  else if (st_lo + 1 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
+  else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
+  __builtin_amdgcn_s_barrier();
+  for (int st = st_lo; st < st_hi; st += 4) {                     // four stages per trip: buffer roles are compile-time
+    stage(st, lds0, lds3);
+    if (st + 1 >= st_hi) break;
+    stage(st + 1, lds1, lds0);
+    if (st + 2 >= st_hi) break;
+    stage(st + 2, lds2, lds1);
+    if (st + 3 >= st_hi) break;
+    stage(st + 3, lds3, lds2);
+  }
+  if (p.ablate & 4) {
+    if (acc[0][0][0] == 12345.678f) p.dw[0] = acc[7][3][3] + acc[1][2][0];
+    return;
+  }
+  float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
+  const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = gc0 + wm * 128 + i * 16 + 4 * (lane >> 4) + r;
+      if (row >= GC) continue;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int col = cs0 + wn * 64 + j * 16 + (lane & 15);
+        if (col >= Cs) continue;
+        float* q = out + (size_t)row * Cs + col;
+        if (mode == 2) *q = acc[i][j][r];
+        else if (mode == 1) *q += acc[i][j][r];
+        else atomicAdd(q, acc[i][j][r]);
+      }
+    }
+  }
+}
+
 // dw[e] += sum_s slab[s][e], 4 elements per thread, slabs added in index order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n4, int nsplit) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,7 +531,10 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
     p.ws = ws;
   dim3 grid(rsplit >= 8 ? tiles * 8 * ((rsplit + 7) / 8) : tiles * rsplit);
   const bool one_buf = g_wgrad_variant == 1;
-  if (big_tile) {
+  if (big_tile && g_wgrad_pipe) {
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256p_kernel<__bf16>, grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(wgrad256p_kernel<_Float16>, grid, dim3(512), 0, s, p);
+  } else if (big_tile) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256_kernel<__bf16>, grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL(wgrad256_kernel<_Float16>, grid, dim3(512), 0, s, p);
   } else if (dtype == GCT2_BF16) {
@@ -386,6 +550,7 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
 
 void wgrad_set_variant(int v) {
   g_wgrad_variant = v & 0xf; g_wgrad_ablate = (v >> 8) & 7;
+  g_wgrad_pipe = (v & 0x40) ? 0 : 1;          // 0x40: the two-buffer big-tile kernel (A/B timing, parity tests)
   if (v & 0x10) g_wgrad_target = 512;          // experiment bits
   if (v & 0x20) g_wgrad_slab_max = 64;
   if (v == 0) { g_wgrad_target = 256; g_wgrad_slab_max = 24; }

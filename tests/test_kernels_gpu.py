@@ -193,10 +193,11 @@ def test_wgrad_reduction_modes_agree(gpu, shape):
     assert np.array_equal(res[1], res[2])          # slab path is bitwise reproducible
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 0x42])
 @pytest.mark.parametrize("shape", [(4, 32, 32, 64, 128), (1, 12, 20, 72, 136), (2, 8, 8, 256, 512)])
 def test_wgrad_tile_variants(gpu, variant, shape):
-    """weight-gradient tile variants: 1 = 128x128 single buffer, 2 = 256x256 (8 waves, 128x64 wave tiles), 3 = 128x128 double buffer."""
+    """weight-gradient tile variants: 1 = 128x128 single buffer, 2 = 256x256 (8 waves of 128x64) with the four-stage spanning
+    pipeline (counted vmcnt across raw barriers), 0x42 = 256x256 with two 64-row buffers, 3 = 128x128 double buffer."""
     B, H, W, Cin, Cout = shape
     dt = BF16
     L = lib()
