@@ -271,3 +271,58 @@ def test_checkpoint_roundtrip_continues(gpu, tmp_path):
     wrong = make_engine(O.OracleConfig(size=32, pixel_size=32, max_size=64, octaves=3, batch_size=4), 1, gpu)
     with pytest.raises(ValueError):
         wrong.load_checkpoint(path)
+
+
+def test_config3_full_size_properties(gpu):
+    """BASELINE config 3 (3x128x128, bs 64, reference topology, bf16) is too large for the CPU oracle in a test, so the
+    headline size is covered by properties the path must have at any size:
+    (a) the reverse pass is reproducible bit for bit - also a race check of the two-stream schedule (every gradient but the
+        3-channel layer's, whose kernel adds with fp32 atomics);
+    (b) one stream and two streams give the same bits;
+    (c) batch sharding (the data-parallel identity): the gradient of the full batch is the mean of the
+        gradients of its two halves, to within the bf16 rounding noise of the gradient chain;
+    (d) a few optimizer steps on one batch lower the loss."""
+    import gan_class_transfer2_amd as g
+    topo = g.Topology(128, 512, 6)
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randint(0, 256, (64, 128, 128, 3), generator=gen).float() / 128 - 1).to(gpu)
+    t_int = torch.randint(1, 201, (64,), generator=gen, dtype=torch.int32)
+    eps = torch.randn(64, 128, 128, 3, generator=gen)
+
+    def grads_of(eng, sl):
+        eng.arena.g.zero_()
+        loss = eng.train_step(x[sl].contiguous(), t_int[sl].contiguous(), eps[sl].contiguous(), apply=False)
+        torch.cuda.synchronize()
+        return float(loss[0]), eng.arena.g.clone()
+
+    eng = g.UNetEngine(topo, g.BF16, gpu)
+    full = slice(0, 64)
+    l1, g1 = grads_of(eng, full)
+    l2, g2 = grads_of(eng, full)
+    lo, hi = eng.arena.layer_ranges["D0"]
+    det = torch.ones(eng.arena.total, dtype=torch.bool, device=gpu)
+    det[lo:hi] = False
+    assert l1 == l2 and np.isfinite(l1) and l1 > 0
+    assert torch.equal(g1[det], g2[det])                                                    # (a)
+    assert rel_l2(g1[lo:hi].cpu().numpy(), g2[lo:hi].cpu().numpy()) <= 1e-5
+    eng.overlap = False
+    l3, g3 = grads_of(eng, full)
+    eng.overlap = True
+    assert l3 == l1 and torch.equal(g3[det], g1[det])                                       # (b)
+    la, ga = grads_of(eng, slice(0, 32))
+    lb, gb = grads_of(eng, slice(32, 64))
+    assert abs(0.5 * (la + lb) - l1) <= 1e-6 * l1
+    errs = {layer: rel_l2((0.5 * (ga[a:b] + gb[a:b])).cpu().numpy(), g1[a:b].cpu().numpy())
+            for layer, (a, b) in eng.arena.layer_ranges.items()}
+    print("shard-equivalence rel-L2 per layer:", {k: float("%.2e" % v) for k, v in errs.items()})
+    # In exact arithmetic the two sides are equal, and at small sizes they agree to 1e-7 (same kernels, same split-K
+    # partitions).  Here the half batches take other split-K partitions in the bottleneck layers, i.e. another fp32 summation
+    # order, which flips a few bf16 roundings of the activations (measured: 1e-4..8e-4 rel-L2 between the two forward
+    # passes); the bf16 gradient chain amplifies that to the per-cent level in the deepest layers - the same order as the
+    # distance of either side from an fp32 run (4e-2..1.4e-1, scripts/dbg_shard.py).  So the bound is the bf16 noise level.
+    whole = rel_l2((0.5 * (ga + gb)).cpu().numpy(), g1.cpu().numpy())
+    assert whole <= 3e-2 and max(errs.values()) <= 0.1, (whole, errs)                       # (c)
+    eng.arena.g.zero_()
+    losses = [float(eng.train_step(x, t_int, eps)[0]) for _ in range(4)]                    # (d)
+    torch.cuda.synchronize()
+    assert losses[-1] < losses[0] and all(np.isfinite(losses))
