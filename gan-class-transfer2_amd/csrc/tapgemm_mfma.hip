@@ -14,8 +14,8 @@
 // channels of one tap per step.  Staging is LDS-DMA (buffer_load_dwordx4 ... lds): every wave-instruction
 // deposits 1 KiB lane-linearly, so the XOR swizzle of the LDS images is applied to each lane's SOURCE address;
 // zero padding (image border, ragged M/K/N) is an out-of-range buffer offset, which the hardware turns into
-// zeros in LDS (probed: tests/hw_probe/probe_glds.hip).  Two LDS buffers: the DMA of step t+1 is issued before
-// the MFMAs of step t, one vmcnt(0)+barrier per step.
+// zeros in LDS (probed: tests/hw_probe/probe_glds.hip).  Tile / buffering variants: see dispatch() below (default: one or
+// two LDS buffers with the DMA of step t+1 issued before the MFMAs of step t, 2 work-groups per CU covering each other).
 // MFMA orientation: A operand = weights (rows = n), B operand = activations (cols = m), so every lane ends
 // with 4 consecutive output channels of one pixel -> 8-byte NHWC stores.
 #include "gct2_common.h"

@@ -6,10 +6,14 @@
 //   Conv2D          : big = layer input x (Cb = Cin),  small = dz (Cs = Cout)  -> dW (4,4,Cin,Cout)
 //   Conv2DTranspose : big = dz (Cb = Cout),            small = x  (Cs = Cin)   -> dW (4,4,Cout,Cin)
 // Both operands have the REDUCTION index r as their slow (row) index in memory, so both LDS tiles are
-// "T images" ([64 r][128 channels]) consumed through ds_read_tr16_b64.  128 x 128 output tile per
-// 256-thread workgroup, 64 rows of r per step, LDS-DMA staging (buffer_load ... lds; swizzle on the source
-// address, out-of-range offset = zero fill) into two LDS buffers, split over r across gridDim.z with fp32
-// atomics into the (pre-zeroed / running) gradient arena.
+// "T images" ([r][128 channels]) consumed through ds_read_tr16_b64.  LDS-DMA staging (buffer_load ... lds; swizzle on
+// the source address, out-of-range offset = zero fill).  Three kernels:
+//   wgrad256p_kernel : 256 x 256 tile, 8 waves of 128 x 64, four 32-row stages with a spanning pipeline (default where the
+//                      tile count still gives about one work-group per CU)
+//   wgrad256_kernel  : the same tile with two 64-row buffers (kept for A/B timing and as a parity cross-check)
+//   wgrad_kernel     : 128 x 128 tile, 4 waves, one or two 64-row buffers, 2-4 work-groups per CU (small layers)
+// The reduction over r is split across work-groups (XCD-aware 1-D grid); partial tiles go to workspace slabs summed in a
+// fixed order by wgrad_reduce_kernel (reproducible), to their single owner (read-add-write), or to fp32 atomics.
 #include "gct2_common.h"
 #include <algorithm>
 
@@ -485,8 +489,17 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n4, int nsplit) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  f32x4_t a = reinterpret_cast<const f32x4_t*>(ws)[i];
-  for (int s = 1; s < nsplit; s++) a += reinterpret_cast<const f32x4_t*>(ws)[(size_t)s * n4 + i];
+  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(ws) + i;
+  f32x4_t a = src[0];
+  int s = 1;
+  for (; s + 8 <= nsplit; s += 8) {          // 8 independent slab loads in flight, added in slab order
+    f32x4_t t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = src[(size_t)(s + u) * n4];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a += t[u];
+  }
+  for (; s < nsplit; s++) a += src[(size_t)s * n4];
   reinterpret_cast<f32x4_t*>(dw)[i] += a;
 }
 
