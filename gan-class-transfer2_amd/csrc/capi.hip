@@ -10,6 +10,7 @@ int tapgemm_mfma(int dtype, int form, int epi, const TapGemmParams& p, hipStream
 int tapgemm_direct(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
 void tapgemm_set_variant(int v);
 void wgrad_set_variant(int v);
+void halo_set_mode(int m);
 bool wgrad_mfma_supported(int dtype, const WgradParams& p);
 int wgrad_mfma(int dtype, WgradParams p, hipStream_t s);
 int wgrad_direct(int dtype, const WgradParams& p, hipStream_t s);
@@ -113,7 +114,7 @@ extern "C" {
 int gct2_abi_version(void) { return 7; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
-void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant(v >> 16); }
+void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant((v >> 16) & 0xff); halo_set_mode((v >> 24) & 3); }
 
 int gct2_set_workspace(void* ws, size_t bytes) {
   if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "set_workspace: pointer must be 16-byte aligned");

@@ -1,0 +1,220 @@
+// Halo-tile variant of the FORM_CONVT tap GEMM (Conv2DTranspose forward, train.py:148-153): ONE staged source patch serves
+// all 4 output-parity phases and all 4 taps of each.
+//
+// tapgemm_kernel<FORM_CONVT> stages a 256-pixel x 64-channel source tile per (phase, tap, k-chunk): 16 tile loads per k-chunk
+// for a 256-pixel patch, although the 16 (phase, tap) pairs only touch the 3 x 3 neighbourhood of every pixel.  For layers
+// with few output channels (UpShuffle_0: N = 64) those loads are the bound (measured: full 204 us, MFMA-only 144 us,
+// DMA-only 169 us).  Here a work-group owns a 16 x 16 patch of the SMALL grid: the 18 x 18 halo (324 pixel rows x 128 B) is
+// staged ONCE per 64-channel k-chunk and every (phase, tap) reads its A fragments from it at a shifted row offset; only the
+// weights (4 phases x 64 n x 64 k = 32 KiB) are staged per tap round.  L2->LDS traffic per k-chunk: 41 + 4 x 32 = 169 KiB
+// instead of 640 KiB.
+//
+// 8 waves: wave = (phase, half of the patch) -> 128 pixels x 64 channels (8 x 4 MFMA tiles, 128 accumulator registers).
+// A fragment = 16 pixels of one patch row = 16 CONSECUTIVE halo rows starting at an arbitrary row (the tap shift), so the halo
+// image uses a swizzle that is conflict-free for ds_read_b128 at EVERY start row: chunk ^ (4*bit1(row) + 2*bit2(row))
+// (exhaustive check over the lane groups of MI355X_MICROARCH.md, LDS table; the N-image swizzle needs aligned starts).
+// Needs Hs, Ws multiples of 16.  Epilogue: bias + ReLU (forward).
+#include "gct2_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr unsigned OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void lds_void_t;
+int g_halo_mode = 0;                 // 0 = automatic, 1 = never, 2 = whenever the shape allows (tests / A-B timing)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)OOB, 0x00020000);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
+}
+__device__ __forceinline__ int halo_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1); }
+
+constexpr int HP = 18;                        // halo pitch (pixels per halo row)
+constexpr int HPIECES = 41;                   // 1-KiB pieces (8 pixel rows each) covering the 324 halo pixels
+constexpr int HALO_BYTES = HPIECES * 1024;
+constexpr int WB_BYTES = 4 * 64 * 128;        // 4 phases x 64 n-rows x 128 B
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
+  __shared__ __attribute__((aligned(16))) char halo0[HALO_BYTES];
+  __shared__ __attribute__((aligned(16))) char halo1[HALO_BYTES];
+  __shared__ __attribute__((aligned(16))) char wb0[WB_BYTES];
+  __shared__ __attribute__((aligned(16))) char wb1[WB_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int phase = wave >> 1, mhalf = wave & 1;
+  const int ph = phase >> 1, pw = phase & 1;
+  const int g = lane >> 4, q = lane & 15;
+  const int Hs = p.Hs, Ws = p.Ws, K = p.K, N = p.N;
+  const int tx_n = Ws >> 4, ty_n = Hs >> 4;
+  int m_tile, n_tile;
+  if (!xcd_tile((int)blockIdx.x, p.m_tiles, p.n_tiles, p.xcd_chunk, m_tile, n_tile)) return;
+  const int tx = m_tile % tx_n, tq = m_tile / tx_n, ty = tq % ty_n, b = tq / ty_n;
+  const int sh0 = ty * 16, sw0 = tx * 16, n0 = n_tile * 64;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x), rs_w = make_rsrc(p.w);
+  const int ldx2 = p.ldx * 2;
+
+  // ---- per-lane DMA descriptors ------------------------------------------------------------------------------------
+  // halo: piece pi = wave + 8 i (i < 6, pi < 41) = halo rows 8 pi .. 8 pi + 7; lane -> row 8 pi + (lane>>3), physical chunk lane&7
+  unsigned h_off[6];
+  unsigned h_ok = 0;
+  int h_lchunk[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int pi = wave + 8 * i;
+    const int row = 8 * pi + (lane >> 3);
+    const int lchunk = (lane & 7) ^ halo_swz(row);
+    h_lchunk[i] = lchunk;
+    h_off[i] = 0;
+    if (pi < HPIECES && row < HP * HP) {
+      const int hy = row / HP, hx = row - hy * HP;
+      const int y = sh0 - 1 + hy, x = sw0 - 1 + hx;
+      if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) {
+        h_off[i] = (unsigned)(((b * Hs + y) * Ws + x) * ldx2 + lchunk * 16);
+        h_ok |= 1u << i;
+      }
+    }
+  }
+  // weights: piece (phase i, n-block wave): lane -> n = 8 wave + (lane>>3), physical chunk lane&7 (N-image swizzle)
+  const int w_n = 8 * wave + (lane >> 3);
+  const int w_lchunk = (lane & 7) ^ ((w_n >> 1) & 7);
+  const bool w_nok = (n0 + w_n) < N;
+  const unsigned w_off = (unsigned)(((n0 + w_n) * K + w_lchunk * 8) * 2);
+
+  const int nk = (K + 63) / 64;
+  const int nround = 4 * nk;                                   // (k-chunk, tap round (a, c))
+
+  auto issue_halo = [&](int kc, char* hbuf) {
+    const int c0 = kc * 64;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int pi = wave + 8 * i;
+      if (pi < HPIECES) {                                      // wave-uniform
+        const bool ok = ((h_ok >> i) & 1u) && (c0 + h_lchunk[i] * 8) < K;
+        dma16(rs_x, hbuf + pi * 1024, ok ? h_off[i] + (unsigned)(c0 * 2) : OOB);
+      }
+    }
+  };
+  auto issue_w = [&](int round, char* wbuf) {
+    const int kc = round >> 2, a = (round >> 1) & 1, c = round & 1;
+    const int c0 = kc * 64;
+    const bool kok = w_nok && (c0 + w_lchunk * 8) < K;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                              // phase i = (i>>1, i&1): kernel tap (1 - ph + 2a, 1 - pw + 2c)
+      const int tap16 = (1 - (i >> 1) + 2 * a) * 4 + (1 - (i & 1) + 2 * c);
+      dma16(rs_w, wbuf + i * 8192 + wave * 1024, kok ? w_off + (unsigned)((tap16 * N * K + c0) * 2) : OOB);
+    }
+  };
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int round, const char* hbuf, const char* wbuf) {
+    const int a = (round >> 1) & 1, c = round & 1;
+    // an opaque copy of the lane's pixel column: without it every fragment address of all 8 unrolled rounds is loop-invariant,
+    // gets hoisted out of the K loop and spills (128 address registers)
+    int ql = q;
+    asm volatile("" : "+v"(ql));
+    // source pixel of output (sh, sw), phase (ph, pw), tap (a, c) = (sh + ph - a, sw + pw - c); halo origin = (sh0-1, sw0-1)
+    const int row0 = (mhalf * 8 + ph - a + 1) * HP + (pw - c + 1) + ql;
+    const char* wimg = wbuf + phase * 8192;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      u32x4_t wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) wf[i] = nimg_frag(wimg, i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int row = row0 + j * HP;
+        const u32x4_t af = lds_read128(hbuf, row * 128 + (((4 * kk + g) ^ halo_swz(row)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i][j] = mfma16<T>(wf[i], af, acc[i][j]);
+      }
+    }
+  };
+
+  // ---- main loop: 8 rounds (two k-chunks) per trip so that every buffer role is a compile-time constant --------------
+  issue_halo(0, halo0);
+  issue_w(0, wb0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#define GCT2_HALO_ROUND(R, HCUR, WCUR, WNEXT, HNEXT)                                         \
+  {                                                                                          \
+    const int r_ = (R);                                                                      \
+    if (r_ + 1 < nround) {                                                                   \
+      issue_w(r_ + 1, WNEXT);                                                                \
+      if (((r_ + 1) & 3) == 0) issue_halo((r_ + 1) >> 2, HNEXT);                             \
+    }                                                                                        \
+    compute(r_, HCUR, WCUR);                                                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+    __syncthreads();                                                                         \
+    if (r_ + 1 >= nround) break;                                                             \
+  }
+  for (int r = 0; r < nround; r += 8) {
+    GCT2_HALO_ROUND(r + 0, halo0, wb0, wb1, halo1)
+    GCT2_HALO_ROUND(r + 1, halo0, wb1, wb0, halo1)
+    GCT2_HALO_ROUND(r + 2, halo0, wb0, wb1, halo1)
+    GCT2_HALO_ROUND(r + 3, halo0, wb1, wb0, halo1)
+    GCT2_HALO_ROUND(r + 4, halo1, wb0, wb1, halo0)
+    GCT2_HALO_ROUND(r + 5, halo1, wb1, wb0, halo0)
+    GCT2_HALO_ROUND(r + 6, halo1, wb0, wb1, halo0)
+    GCT2_HALO_ROUND(r + 7, halo1, wb1, wb0, halo0)
+  }
+#undef GCT2_HALO_ROUND
+
+  // ---- epilogue: lane holds out[pixel (row mhalf*8 + j, col q)][n = n0 + 16 i + 4 g + r], phase (ph, pw) --------------
+  T* __restrict__ yout = reinterpret_cast<T*>(p.y);
+  int elane = lane;
+  asm volatile("" : "+v"(elane));                              // keeps the output addresses out of the K loop
+  const int eq = elane & 15, eg = elane >> 4;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int sh = sh0 + mhalf * 8 + j, sw = sw0 + eq;
+    const size_t opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int n = n0 + i * 16 + 4 * eg;
+      if (n >= N) continue;
+      f32x4_t v = acc[i][j];
+      if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+      }
+      u32x2_t o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+      *reinterpret_cast<u32x2_t*>(yout + opix * p.ldy + n) = o;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+}  // namespace
+
+void halo_set_mode(int m) { g_halo_mode = m; }
+
+// the halo kernel takes the bias+ReLU forward of a transposed convolution whose SMALL grid tiles into 16 x 16 patches
+bool halo_convT_wanted(int epi, const TapGemmParams& p) {
+  if (g_halo_mode == 1 || epi != EPI_BIAS_ACT) return false;
+  if ((p.Hs & 15) || (p.Ws & 15) || p.accumulate) return false;
+  if (g_halo_mode == 2) return true;
+  // automatic: layers whose source-tile traffic dominates (few output channels per pixel) and that fill the chip
+  const int tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4) * ((p.N + 63) / 64);
+  return p.N <= 128 && tiles >= 512;          // measured: UpShuffle_0 (N = 64) 206 -> 153 us, UpShuffle_1 (N = 128) 141 -> 136 us
+}
+
+int halo_convT(int dtype, TapGemmParams p, hipStream_t s) {
+  p.m_tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4);
+  p.n_tiles = (p.N + 63) / 64;
+  p.xcd_chunk = (p.m_tiles + 7) / 8;
+  p.ksplit = 1;
+  dim3 grid(8 * p.xcd_chunk * p.n_tiles);
+  if (dtype == GCT2_BF16) hipLaunchKernelGGL(halo_convT_kernel<__bf16>, grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL(halo_convT_kernel<_Float16>, grid, dim3(512), 0, s, p);
+  return gct2_check_launch("halo_convT");
+}

@@ -57,8 +57,9 @@ def run(name, variant, iters=20):
     return us, flops / us / 1e6
 if os.environ.get("LAYERSET") == "small":
     LAYERS = SMALL
+# variant bits 24-25: halo kernel mode (1 = never, 2 = wherever the shape allows), e.g. 33554432 = halo forced
 variants = [int(v) for v in sys.argv[1:]] or [2, 3, 2 + 256, 2 + 512, 3 + 256, 3 + 512]
-print("layer      " + "".join(f"{'v%d/a%d' % (v & 255, v >> 8):>16s}" for v in variants))
+print("layer      " + "".join(f"{'v%d/a%d/h%d' % (v & 255, (v >> 8) & 3, v >> 24):>16s}" for v in variants))
 for name in LAYERS:
     print(f"{name:10s} " + "".join("%8.1fus %4.0fTF" % run(name, v) for v in variants))
 L.load().gct2_debug_tapgemm_variant(0)

@@ -586,3 +586,34 @@ def test_loss_scale_state_machine(gpu):
         assert float(raw[:1].view(torch.float32)[0]) == ref.scale and int(raw[2]) == ref.good_steps
         assert bool((p != p_before).any()) == applied          # update skipped on inf/nan
         assert bool(torch.isfinite(p).all())
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (1, 32, 16, 136, 72), (3, 16, 32, 256, 128), (1, 16, 16, 8, 8)])
+def test_convT_fwd_halo_kernel(gpu, dt, shape):
+    """halo-tile Conv2DTranspose forward (one staged 18x18 source patch for all phases and taps; shift-invariant LDS swizzle):
+    forced on (variant bits 24-25 = 2) and compared with the oracle; shapes cover ragged K and N, several patches per image
+    in both directions, several images, and the smallest channel counts."""
+    B, H, W, Cin, Cout = shape
+    L = lib()
+    rng = np.random.default_rng(31)
+    x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+    wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+    b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+    xd, wtd, bd = dev(x, dt, gpu), dev(wt, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
+    ref = np.maximum(O.convT4s2_fwd(x, wt, b), 0)
+    outs = []
+    for mode in (2, 1):          # halo forced / halo off: both against the oracle, and close to each other
+        L.load().gct2_debug_tapgemm_variant(mode << 24)
+        try:
+            ld = Cout + 8
+            yt = torch.full((B, 2 * H, 2 * W, ld), 7.0, dtype=TDT[dt], device=gpu)
+            L.call("gct2_convT4s2_fwd", dt, xd.data_ptr(), Cin, wtd.data_ptr(), bd.data_ptr(), yt.data_ptr() + 4 * yt.element_size(), ld,
+                   B, H, W, Cin, Cout, 1, stream())
+            torch.cuda.synchronize()
+        finally:
+            L.load().gct2_debug_tapgemm_variant(0)
+        assert rel_l2(yt[..., 4:4 + Cout].double().cpu().numpy(), ref) <= TOL_OUT[dt], mode
+        assert float((yt[..., :4].float() - 7).abs().max()) == 0 and float((yt[..., 4 + Cout:].float() - 7).abs().max()) == 0
+        outs.append(yt)
+    assert rel_l2(outs[0].double().cpu().numpy(), outs[1].double().cpu().numpy()) <= TOL_OUT[dt]
