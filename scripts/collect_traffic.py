@@ -9,8 +9,10 @@ FAMILY = [("wgrad_kernel", "wgrad"), ("tapgemm_kernelIDF16bLi0E", "conv_form"), 
           ("tapgemm_kernel<", None)]
 
 def family(name):
-    if re.search(r"wgrad(256)?_kernel", name) and "rgb" not in name:
+    if re.search(r"wgrad(256p?)?_kernel", name) and "rgb" not in name:
         return "wgrad"
+    if "halo_convT_kernel" in name:
+        return "convT_form"
     m = re.search(r"tapgemm_kernelI\w+?Li(\d)E", name)
     if m:
         return "conv_form" if m.group(1) == "0" else "convT_form"
