@@ -3,7 +3,8 @@
 The directory name carries a hyphen (project convention); import it as `gan_class_transfer2_amd`
 (the alias package next to it extends its __path__ here).
 """
-from . import _lib, build, engine, model, sampler # noqa: F401
+from . import _lib, build, data, engine, model, sampler # noqa: F401
+from .data import ImageDataset                    # noqa: F401
 from .sampler import log_sample, make_log_sample  # noqa: F401
 from ._lib import BF16, F16, F32, Gct2Error       # noqa: F401
 from .engine import Topology, UNetEngine          # noqa: F401

@@ -33,6 +33,7 @@ SIGNATURES = {
     "gct2_diffusion_mix": [_i, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _sz, _i, _vp],
     "gct2_diffusion_update": [_vp, _vp, _f, _vp, _vp, _sz, _vp],
     "gct2_noise_edits": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "gct2_image_prepare": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "gct2_set_workspace": [_vp, _sz],
     "gct2_set_wgrad_workspace": [_vp, _sz],
     "gct2_debug_tapgemm_variant": [_i],

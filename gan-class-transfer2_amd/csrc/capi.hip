@@ -31,6 +31,7 @@ int pw_colsum(int, const void*, int, float*, size_t, int, float, hipStream_t);
 int pw_diffusion_mix(int, const float*, const float*, float, float*, void*, int, void*, int, size_t, int, hipStream_t);
 int pw_diffusion_update(const float*, const float*, float, float*, float*, size_t, hipStream_t);
 int pw_noise_edits(const float*, const float*, int, float*, int, int, int, hipStream_t);
+int pw_image_prepare(const uint8_t*, const int64_t*, const int32_t*, float*, int, int, hipStream_t);
 int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const float*, const int32_t*, int, hipStream_t);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
 int pw_ls_init(gct2_loss_scale_state*, float, hipStream_t);
@@ -111,7 +112,7 @@ int run_wgrad(int dtype, const WgradParams& p, void* stream) {
 
 extern "C" {
 
-int gct2_abi_version(void) { return 7; }
+int gct2_abi_version(void) { return 8; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
 void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant((v >> 16) & 0xff); halo_set_mode((v >> 24) & 3); }
@@ -274,6 +275,11 @@ int gct2_noise_edits(const float* eps, const float* dictionary, int K, float* ou
   if (H <= 0 || W <= 0 || C <= 0 || K <= 0 || (H & 3) || (W & 3))
     return gct2_fail(GCT2_EINVAL, "noise_edits: H=%d W=%d must be positive multiples of 4 (avg_pool2d(4, 4, 'SAME') without padding)", H, W);
   return pw_noise_edits(eps, dictionary, K, out, H, W, C, S(stream));
+}
+
+int gct2_image_prepare(const uint8_t* src, const int64_t* offsets, const int32_t* dims, float* dst, int B, int size, void* stream) {
+  if (!src || !offsets || !dims || !dst || B <= 0 || size <= 0) return gct2_fail(GCT2_EINVAL, "image_prepare: null pointer or empty batch");
+  return pw_image_prepare(src, offsets, dims, dst, B, size, S(stream));
 }
 
 int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n,

@@ -635,6 +635,24 @@ __global__ void noise_edits_kernel(const float* __restrict__ eps, const float* _
   for (int c = 0; c < C; c++) out[3 * img + (size_t)idx * C + c] = dict[((size_t)idx * K + best) * C + c];
 }
 
+// ---- input contract (train.py:285-293): random crop, random left-right flip, u8 -> value/128 - 1, one launch per batch ------
+// src: concatenated decoded RGB images (u8, HWC); per image b: byte offset, original height/width, crop origin, flip flag
+__global__ void image_prepare_kernel(const uint8_t* __restrict__ src, const int64_t* __restrict__ offsets, const int32_t* __restrict__ dims,
+                                     float* __restrict__ dst, int B, int size) {
+  const size_t per = (size_t)size * size * 3;
+  const size_t total = per * B;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int b = (int)(i / per);
+    const int r = (int)(i - (size_t)b * per);
+    const int c = r % 3, xy = r / 3, x = xy % size, y = xy / size;
+    const int W0 = dims[5 * b + 1], oy = dims[5 * b + 2], ox = dims[5 * b + 3], flip = dims[5 * b + 4];
+    const int sx = ox + (flip ? size - 1 - x : x);
+    const uint8_t v = src[offsets[b] + ((size_t)(oy + y) * W0 + sx) * 3 + c];
+    dst[i] = (float)v * (1.0f / 128.0f) - 1.0f;                  // exact: v/128 has at most 8 significant bits
+  }
+}
+
 // ---- bias gradient: db[c] += sum_m dz[m][c] --------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dz, int ld, float* __restrict__ db, size_t M, int C,
@@ -899,6 +917,10 @@ int pw_diffusion_update(const float* pred, const float* fake, float a, float* x,
 int pw_noise_edits(const float* eps, const float* dict, int K, float* out, int H, int W, int C, hipStream_t s) {
   hipLaunchKernelGGL(noise_edits_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, eps, dict, K, out, H, W, C);
   return gct2_check_launch("noise_edits");
+}
+int pw_image_prepare(const uint8_t* src, const int64_t* offsets, const int32_t* dims, float* dst, int B, int size, hipStream_t s) {
+  hipLaunchKernelGGL(image_prepare_kernel, dim3(blocks_for((size_t)B * size * size * 3, 256)), dim3(256), 0, s, src, offsets, dims, dst, B, size);
+  return gct2_check_launch("image_prepare");
 }
 int pw_mse(const float* pred, const float* target, float* dpred, float* loss, float* partials, size_t n, const float* ls, hipStream_t s) {
   const int nb = blocks_for(n, 1024) > 1024 ? 1024 : blocks_for(n, 1024);

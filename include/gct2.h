@@ -165,6 +165,14 @@ int gct2_diffusion_update(const float* pred, const float* fake, float alpha, flo
 int gct2_noise_edits(const float* eps, const float* dictionary, int K, float* out, int H, int W, int C,
                      void* stream);
 
+/* ---- input contract, decode_file without the decoder (train.py:285-293) ------------------------------------------------ */
+/* dst[b,y,x,c] = src_b[oy+y, ox + (flip ? size-1-x : x), c] / 128 - 1: random_crop + random_flip_left_right + the cast of
+ * train.py:288-292 for a whole batch in one launch.  src: device buffer of decoded RGB images (u8, HWC) back to back;
+ * offsets[b]: byte offset of image b; dims[b] = {H0, W0, oy, ox, flip} (int32, the caller draws the crop origin and the flip and
+ * guarantees oy + size <= H0, ox + size <= W0); dst: fp32 [B, size, size, 3]. */
+int gct2_image_prepare(const uint8_t* src, const int64_t* offsets, const int32_t* dims, float* dst, int B, int size,
+                       void* stream);
+
 /* loss = mean((target - pred)^2) in fp32 (train.py:272); dpred = loss_scale * 2 (pred-target)/n.
  * `loss` (1 float) is overwritten; `partials` is caller scratch of >= 1024 floats.
  * loss_scale_ptr: device pointer to the current loss scale (fp16 mode) or NULL for 1. */

@@ -70,3 +70,11 @@ def log_sample(denoise: Callable[[np.ndarray], np.ndarray], example_image: np.nd
 
 def unet_denoiser(params, cfg: O.OracleConfig, operand_round: Optional[str] = None) -> Callable[[np.ndarray], np.ndarray]:
     return lambda x: O.unet_forward(params, x, cfg, operand_round)[0]
+
+
+def decode_contract(image_u8: np.ndarray, oy: int, ox: int, flip: bool, size: int) -> np.ndarray:
+    """train.py:288-292 after the decoder: crop [size, size, 3] at (oy, ox), optional left-right flip, value / 128 - 1."""
+    out = image_u8[oy:oy + size, ox:ox + size, :]
+    if flip:
+        out = out[:, ::-1, :]
+    return out.astype(np.float64) / 128 - 1
