@@ -1,4 +1,5 @@
-// Halo-tile variant of the FORM_CONVT tap GEMM (Conv2DTranspose forward, train.py:148-153): ONE staged source patch serves
+// Halo-tile variant of the FORM_CONVT tap GEMM (Conv2DTranspose forward, train.py:148-153, and the input gradient of
+// Conv2D, train.py:161-166): ONE staged source patch serves
 // all 4 output-parity phases and all 4 taps of each.
 //
 // tapgemm_kernel<FORM_CONVT> stages a 256-pixel x 64-channel source tile per (phase, tap, k-chunk): 16 tile loads per k-chunk
@@ -13,7 +14,7 @@
 // A fragment = 16 pixels of one patch row = 16 CONSECUTIVE halo rows starting at an arbitrary row (the tap shift), so the halo
 // image uses a swizzle that is conflict-free for ds_read_b128 at EVERY start row: chunk ^ (4*bit1(row) + 2*bit2(row))
 // (exhaustive check over the lane groups of MI355X_MICROARCH.md, LDS table; the N-image swizzle needs aligned starts).
-// Needs Hs, Ws multiples of 16.  Epilogue: bias + ReLU (forward).
+// Needs Hs, Ws multiples of 16.  Epilogues: bias + ReLU (forward) or mask / accumulate / bias-gradient rows (Conv2D dgrad).
 #include "gct2_common.h"
 #include <algorithm>
 
@@ -36,7 +37,7 @@ constexpr int HPIECES = 41;                   // 1-KiB pieces (8 pixel rows each
 constexpr int HALO_BYTES = HPIECES * 1024;
 constexpr int WB_BYTES = 4 * 64 * 128;        // 4 phases x 64 n-rows x 128 B
 
-template <typename T>
+template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   __shared__ __attribute__((aligned(16))) char halo0[HALO_BYTES];
   __shared__ __attribute__((aligned(16))) char halo1[HALO_BYTES];
@@ -169,10 +170,16 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #undef GCT2_HALO_ROUND
 
   // ---- epilogue: lane holds out[pixel (row mhalf*8 + j, col q)][n = n0 + 16 i + 4 g + r], phase (ph, pw) --------------
+  // EPI_BIAS_ACT: bias + ReLU (Conv2DTranspose forward).  EPI_MASK: ReLU mask of the tensor the gradient belongs to, optional
+  // accumulation into the skip slice, column sums for the fused bias gradient (Conv2D input gradient), as in tapgemm_kernel.
   T* __restrict__ yout = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ actp = reinterpret_cast<const T*>(p.act);
   int elane = lane;
   asm volatile("" : "+v"(elane));                              // keeps the output addresses out of the K loop
   const int eq = elane & 15, eg = elane >> 4;
+  f32x4_t bsum[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) bsum[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int sh = sh0 + mhalf * 8 + j, sw = sw0 + eq;
@@ -182,15 +189,61 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       const int n = n0 + i * 16 + 4 * eg;
       if (n >= N) continue;
       f32x4_t v = acc[i][j];
-      if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
-      if (p.relu) {
+      if (EPI == EPI_BIAS_ACT) {
+        if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+        if (p.relu) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+        }
+      } else {
+        if (actp) {
+          const u32x2_t a2 = *reinterpret_cast<const u32x2_t*>(actp + opix * p.ldact + n);
+          if (!(unpack_lo<T>(a2[0]) > 0.f)) v[0] = 0.f;
+          if (!(unpack_hi<T>(a2[0]) > 0.f)) v[1] = 0.f;
+          if (!(unpack_lo<T>(a2[1]) > 0.f)) v[2] = 0.f;
+          if (!(unpack_hi<T>(a2[1]) > 0.f)) v[3] = 0.f;
+        }
+        bsum[i] += v;
+        if (p.accumulate) {
+          const u32x2_t o2 = *reinterpret_cast<const u32x2_t*>(yout + opix * p.ldy + n);
+          v[0] += unpack_lo<T>(o2[0]); v[1] += unpack_hi<T>(o2[0]);
+          v[2] += unpack_lo<T>(o2[1]); v[3] += unpack_hi<T>(o2[1]);
+        }
       }
       u32x2_t o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
       *reinterpret_cast<u32x2_t*>(yout + opix * p.ldy + n) = o;
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if (EPI == EPI_MASK && (p.db || p.db2)) {
+    // all 8 waves cover the same 64 channels: butterfly over the 16 pixel lanes, meet in LDS (free after the last barrier of the
+    // K loop), ONE partial row per work-group for the ordered row reduction (no atomics); without a workspace: atomics
+    float* red = reinterpret_cast<float*>(wb0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float t = bsum[i][r];
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+        const int c = i * 16 + 4 * eg + r;
+        if (eq == 0) {
+          if (p.dbws) red[wave * 64 + c] = t;
+          else if (n0 + c < N) {
+            float* qd = (n0 + c) < p.db_split ? (p.db ? p.db + n0 + c : nullptr) : (p.db2 ? p.db2 + (n0 + c - p.db_split) : nullptr);
+            if (qd) atomicAdd(qd, t);
+          }
+        }
+      }
+    }
+    if (p.dbws) {
+      __syncthreads();
+      if (tid < 64 && n0 + tid < N) {
+        float t = red[tid];
+#pragma unroll
+        for (int k = 1; k < 8; k++) t += red[k * 64 + tid];
+        p.dbws[(size_t)m_tile * N + n0 + tid] = t;
+      }
+    }
   }
 }
 
@@ -198,23 +251,41 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 
 void halo_set_mode(int m) { g_halo_mode = m; }
 
-// the halo kernel takes the bias+ReLU forward of a transposed convolution whose SMALL grid tiles into 16 x 16 patches
+int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, hipStream_t s);   // tapgemm_mfma.hip
+
+// the halo kernel takes FORM_CONVT problems whose SMALL grid tiles into 16 x 16 patches: the Conv2DTranspose forward
+// (bias + ReLU) and the Conv2D input gradient (mask / accumulate / fused bias gradient)
 bool halo_convT_wanted(int epi, const TapGemmParams& p) {
-  if (g_halo_mode == 1 || epi != EPI_BIAS_ACT) return false;
-  if ((p.Hs & 15) || (p.Ws & 15) || p.accumulate) return false;
+  if (g_halo_mode == 1) return false;
+  if ((p.Hs & 15) || (p.Ws & 15)) return false;
   if (g_halo_mode == 2) return true;
   // automatic: layers whose source-tile traffic dominates (few output channels per pixel) and that fill the chip
   const int tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4) * ((p.N + 63) / 64);
   return p.N <= 128 && tiles >= 512;          // measured: UpShuffle_0 (N = 64) 206 -> 153 us, UpShuffle_1 (N = 128) 141 -> 136 us
 }
 
-int halo_convT(int dtype, TapGemmParams p, hipStream_t s) {
+int halo_convT(int dtype, int epi, TapGemmParams p, hipStream_t s) {
   p.m_tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4);
   p.n_tiles = (p.N + 63) / 64;
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   p.ksplit = 1;
+  p.dbws = nullptr;
+  if (epi == EPI_MASK && (p.db || p.db2)) {      // partial bias-gradient rows at the tail of the workspace, one per work-group row
+    size_t ws_bytes = 0;
+    float* ws = gct2_workspace(&ws_bytes);
+    const size_t need = (size_t)p.m_tiles * p.N * sizeof(float);
+    if (ws && ws_bytes >= need + 16) p.dbws = ws + (ws_bytes - need) / sizeof(float) / 4 * 4;
+  }
   dim3 grid(8 * p.xcd_chunk * p.n_tiles);
-  if (dtype == GCT2_BF16) hipLaunchKernelGGL(halo_convT_kernel<__bf16>, grid, dim3(512), 0, s, p);
-  else hipLaunchKernelGGL(halo_convT_kernel<_Float16>, grid, dim3(512), 0, s, p);
+  if (epi == EPI_BIAS_ACT) {
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_BIAS_ACT>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_BIAS_ACT>), grid, dim3(512), 0, s, p);
+  } else {
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_MASK>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_MASK>), grid, dim3(512), 0, s, p);
+  }
+  if (p.dbws) {
+    if (int e = tapgemm_dbpart_reduce(p.dbws, p.m_tiles, p, s)) return e;
+  }
   return gct2_check_launch("halo_convT");
 }

@@ -567,10 +567,16 @@ bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {
 void tapgemm_set_variant(int v) { g_tapgemm_variant = v & 0xff; g_tapgemm_ablate = (v >> 8) & 3; }
 
 bool halo_convT_wanted(int epi, const TapGemmParams& p);      // halo_mfma.hip
-int halo_convT(int dtype, TapGemmParams p, hipStream_t s);
+int halo_convT(int dtype, int epi, TapGemmParams p, hipStream_t s);
+
+// the ordered row reduction of the fused bias gradients, for the other translation units that leave partial rows
+int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(dbpart_reduce_kernel, dim3((p.N + 31) / 32), dim3(1024), 0, s, part, rows, p);
+  return gct2_check_launch("dbpart_reduce");
+}
 
 int tapgemm_mfma(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s) {
-  if (form == FORM_CONVT && g_tapgemm_variant == 0 && halo_convT_wanted(epi, p)) return halo_convT(dtype, p, s);
+  if (form == FORM_CONVT && g_tapgemm_variant == 0 && halo_convT_wanted(epi, p)) return halo_convT(dtype, epi, p, s);
   if (dtype == GCT2_BF16) return dispatch<__bf16>(form, epi, p, s);
   return dispatch<_Float16>(form, epi, p, s);
 }

@@ -617,3 +617,37 @@ def test_convT_fwd_halo_kernel(gpu, dt, shape):
         assert float((yt[..., :4].float() - 7).abs().max()) == 0 and float((yt[..., 4 + Cout:].float() - 7).abs().max()) == 0
         outs.append(yt)
     assert rel_l2(outs[0].double().cpu().numpy(), outs[1].double().cpu().numpy()) <= TOL_OUT[dt]
+
+
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 24), (1, 32, 64, 136, 64)])
+def test_conv_dgrad_halo_kernel(gpu, shape, use_ws):
+    """the halo-tile kernel as the Conv2D input gradient (mask, accumulation into a running buffer, fused bias gradients with the
+    split at db_split, partial rows with a workspace / atomics without): forced on and compared with the oracle."""
+    B, H, W, Cin, Cout = shape                     # dgrad output [B,H,W,Cin]; small grid H/2 x W/2 must tile into 16 x 16
+    dt = BF16
+    L = lib()
+    ws = torch.empty(8 << 18, dtype=torch.float32, device=gpu)
+    L.call("gct2_set_workspace", ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0)
+    L.load().gct2_debug_tapgemm_variant(2 << 24)
+    try:
+        rng = np.random.default_rng(41)
+        x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+        w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+        dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+        prev = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+        contrib = O.conv4s2_bwd(x, w, dz)[0] * (x > 0)
+        split = (Cin // 2) // 8 * 8
+        dxd, dzd, wd, xd = dev(prev, dt, gpu), dev(dz, dt, gpu), dev(w, dt, gpu), dev(x, dt, gpu)
+        db = torch.full((split,), 3.0, device=gpu); db2 = torch.full((Cin - split,), -1.0, device=gpu)
+        L.call("gct2_conv4s2_dgrad", dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin,
+               dxd.data_ptr(), Cin, B, H, W, Cin, Cout, 1, db.data_ptr(), split, db2.data_ptr(), stream())
+        torch.cuda.synchronize()
+        cs = contrib.reshape(-1, Cin).sum(0)
+        scale = np.abs(contrib).reshape(-1, Cin).sum(0).max()
+        assert np.abs(db.cpu().numpy() - 3.0 - cs[:split]).max() <= 2e-3 * scale
+        assert np.abs(db2.cpu().numpy() + 1.0 - cs[split:]).max() <= 2e-3 * scale
+        assert rel_l2(dxd.double().cpu().numpy(), contrib + prev) <= TOL_OUT[dt]
+    finally:
+        L.load().gct2_debug_tapgemm_variant(0)
+        L.call("gct2_set_workspace", None, 0)
