@@ -11,7 +11,7 @@ unchanged on CPU tensors with the gloo backend (tests/test_distributed_cpu.py).
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
