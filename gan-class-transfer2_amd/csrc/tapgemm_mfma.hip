@@ -507,10 +507,9 @@ int dispatch(int form, int epi, const TapGemmParams& p, hipStream_t s) {
   const int M = p.B * p.Hs * p.Ws;
   const bool big = g_tapgemm_variant == 3;   // measured r01: the 4-wave tile at 2 work-groups per CU is faster (profiles/)
   // automatic choice (per-layer A/B in scripts/bench_layer.py, profiles/r01_layer_variants.txt): the 256 x 128 single-
-  // buffer tile moves 25 % fewer L2->LDS bytes per FLOP and wins 5-14 % where it still yields >= 2 work-groups per CU,
-  // except for the Conv2D forward (bias epilogue), where the 128 x 128 double-buffered tile stays ahead.
+  // buffer tile moves 25 % fewer L2->LDS bytes per FLOP and wins 5-14 % where it still yields >= 2 work-groups per CU.
   const int tiles256 = ((M + 255) / 256) * ((p.N + 127) / 128) * (form == FORM_CONVT ? 4 : 1);
-  const bool auto5 = g_tapgemm_variant == 0 && tiles256 >= 512 && !(form == FORM_CONV && epi == EPI_BIAS_ACT);
+  const bool auto5 = g_tapgemm_variant == 0 && tiles256 >= 512;
   if ((g_tapgemm_variant == 5 || auto5) && p.N > 64) {   // 256 x 128 tile, 8 waves, one LDS buffer (48 KiB), 2 work-groups per CU
     if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 128, EPI_BIAS_ACT, 1>(p, s)
                                                       : launch<T, FORM_CONV, 256, 128, EPI_MASK, 1>(p, s);
