@@ -144,6 +144,18 @@ class _Buffers:
     pass
 
 
+# the library's scratch registrations are process-wide: remember which engine's tensors are registered, so that an engine
+# re-registers its own before it launches and un-registers them when it dies (no dangling pointers inside the library)
+_WS_OWNER: List[Optional[int]] = [None]
+
+
+def reset_workspace_registration() -> None:
+    """forget every scratch registration (library and bookkeeping); engines re-register on their next launch."""
+    call("gct2_set_workspace", None, 0)
+    call("gct2_set_wgrad_workspace", None, 0)
+    _WS_OWNER[0] = None
+
+
 class UNetEngine:
     """the planned (zero-copy concat) forward / backward / optimizer step of the Denoiser U-Net."""
 
@@ -169,15 +181,12 @@ class UNetEngine:
         self._bufs: Dict[Tuple[int, int, int], _Buffers] = {}
         # split-K scratch for the bottleneck layers (include/gct2.h gct2_set_workspace); caller-owned = this tensor
         self.workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
-        call("gct2_set_workspace", self.workspace.data_ptr() if workspace_mb else None,
-             self.workspace.numel() * 4 if workspace_mb else 0)
         # second stream + its own scratch: the weight-gradient kernels (and, single-GPU, the per-layer Adam launches) run
         # beside the dgrad chain instead of between its links (backward())
         self.overlap = True
         self._side = torch.cuda.Stream(device=self.device)
         self.wgrad_workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
-        call("gct2_set_wgrad_workspace", self.wgrad_workspace.data_ptr() if workspace_mb else None,
-             self.wgrad_workspace.numel() * 4 if workspace_mb else 0)
+        self._ensure_workspace()
         self.adam_merge_elems = 2 << 20    # inline Adam launches cover at least this many parameters
         self.ls_state = None
         if loss_scaling:
@@ -187,6 +196,22 @@ class UNetEngine:
         self.grad_ready_hook: Optional[Callable[[str], None]] = None
 
     # ------------------------------------------------------------------------------------------
+    def _ensure_workspace(self) -> None:
+        """(re-)register this engine's scratch tensors with the library unless they already are the registered ones."""
+        if _WS_OWNER[0] == id(self):
+            return
+        ws, wws = self.workspace, self.wgrad_workspace
+        call("gct2_set_workspace", ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0)
+        call("gct2_set_wgrad_workspace", wws.data_ptr() if wws is not None else None, wws.numel() * 4 if wws is not None else 0)
+        _WS_OWNER[0] = id(self)
+
+    def __del__(self):
+        try:
+            if _WS_OWNER[0] == id(self):
+                reset_workspace_registration()
+        except Exception:       # interpreter shutdown: the library may already be gone
+            pass
+
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
@@ -285,6 +310,7 @@ class UNetEngine:
     def forward(self, b: _Buffers, head: bool = True) -> torch.Tensor:
         """Denoiser.call (train.py:206-215): R_0's image slice must already hold the network input.
         head=False stops before Dense(3) (the train step runs the fused head kernel instead)."""
+        self._ensure_workspace()
         t, n, s, dt, A = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena
         for i in range(n):                                      # DownShuffle_i  (train.py:184)
             H, W = b.hw[i]
@@ -323,6 +349,7 @@ class UNetEngine:
 
     def head_train(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
         """Dense(3) + fp32 MSE + both of their gradients in one pass over R_0 (gct2_dense_head_train)."""
+        self._ensure_workspace()
         t, A = self.topo, self.arena
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
         call("gct2_dense_head_train", self.dtype, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"),
@@ -344,6 +371,7 @@ class UNetEngine:
         its work-groups fill the tails and the small bottleneck launches of the chain.  adam_inline (single GPU, no loss
         scaling): a layer's Adam update follows on the side stream once its dgrad (the last reader of its weights) is
         done.  The current stream joins the side stream before returning."""
+        self._ensure_workspace()
         t, n, dt, A = self.topo, self.topo.octaves, self.dtype, self.arena
         main = torch.cuda.current_stream(self.device)
         side = self._side if self.overlap else main

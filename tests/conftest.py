@@ -21,3 +21,15 @@ def gpu():
     g._lib.load()
     g._lib.call("gct2_device_check")
     return torch.device("cuda", 0)
+
+
+@pytest.fixture(autouse=True)
+def _clean_library_state(request):
+    """the library's scratch registrations and tuning hooks are process-wide: every GPU test starts from the defaults (no
+    scratch registered - engines register their own on first use - and automatic tile choice)."""
+    if "gpu" in request.fixturenames:
+        request.getfixturevalue("gpu")
+        import gan_class_transfer2_amd as g
+        g.engine.reset_workspace_registration()
+        g._lib.load().gct2_debug_tapgemm_variant(0)
+    yield
