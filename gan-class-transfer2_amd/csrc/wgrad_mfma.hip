@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(bf[i], sf[j], acc[i][j]);
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(sf[j], bf[i], acc[i][j]);
     }
   };
 
@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
     if (acc[0][0][0] == 12345.678f) p.dw[0] = acc[3][3][3] + acc[1][2][0];
     return;
   }
-  // lane holds dW[gc = .. + 4*(lane>>4) + r][cs = .. + (lane&15)]
+  // MFMA operand order A = small (cs), B = big (gc): lane holds dW[gc = .. + (lane&15)][cs = .. + 4*(lane>>4) + r], i.e. four
+  // consecutive columns of one row -> 16-byte stores (the other order costs four times the store instructions: -7..-24 %)
   //   rsplit == 1        : the tile has one owner -> plain read-add-write (no atomic unit, reproducible)
   //   slabs (p.ws)       : plain stores of the partial tile into slab[split]; wgrad_reduce_kernel adds the slabs in a fixed
   //                        order (reproducible, and plain stores run ~4x the chip-wide float-atomic rate)
@@ -167,18 +168,18 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
+    const int row = gc0 + wm * 64 + i * 16 + (lane & 15);
+    if (row >= GC) continue;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = gc0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
-      if (row >= GC) continue;
+    for (int j = 0; j < 4; j++) {
+      const int col = cs0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      if (col >= Cs) continue;                         // Cs is a multiple of 8: a 4-column group is inside or outside as a whole
+      float* q = out + (size_t)row * Cs + col;
+      if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
+      else if (mode == 1) *reinterpret_cast<f32x4_t*>(q) += acc[i][j];
+      else {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int col = cs0 + wn * 64 + j * 16 + (lane & 15);
-        if (col >= Cs) continue;
-        float* q = out + (size_t)row * Cs + col;
-        if (mode == 2) *q = acc[i][j][r];
-        else if (mode == 1) *q += acc[i][j][r];
-        else atomicAdd(q, acc[i][j][r]);
+        for (int r = 0; r < 4; r++) atomicAdd(q + r, acc[i][j][r]);
       }
     }
   }
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(WgradParams p) {
       for (int i = 0; i < 8; i++) {
         const u32x4_t bf = timg_frag(bimg, i * 16, kk, lane);
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(bf, sf[j], acc[i][j]);
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(sf[j], bf, acc[i][j]);
       }
     }
   };
@@ -308,18 +309,18 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(WgradParams p) {
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
+    const int row = gc0 + wm * 128 + i * 16 + (lane & 15);
+    if (row >= GC) continue;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = gc0 + wm * 128 + i * 16 + 4 * (lane >> 4) + r;
-      if (row >= GC) continue;
+    for (int j = 0; j < 4; j++) {
+      const int col = cs0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      if (col >= Cs) continue;
+      float* q = out + (size_t)row * Cs + col;
+      if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
+      else if (mode == 1) *reinterpret_cast<f32x4_t*>(q) += acc[i][j];
+      else {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int col = cs0 + wn * 64 + j * 16 + (lane & 15);
-        if (col >= Cs) continue;
-        float* q = out + (size_t)row * Cs + col;
-        if (mode == 2) *q = acc[i][j][r];
-        else if (mode == 1) *q += acc[i][j][r];
-        else atomicAdd(q, acc[i][j][r]);
+        for (int r = 0; r < 4; r++) atomicAdd(q + r, acc[i][j][r]);
       }
     }
   }
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
     for (int i = 0; i < 8; i++) {
       const u32x4_t bf = timg_frag(bimg, i * 16, 0, lane);
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(bf, sf[j], acc[i][j]);
+      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(sf[j], bf, acc[i][j]);
     }
   };
 
@@ -468,18 +469,18 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
+    const int row = gc0 + wm * 128 + i * 16 + (lane & 15);
+    if (row >= GC) continue;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = gc0 + wm * 128 + i * 16 + 4 * (lane >> 4) + r;
-      if (row >= GC) continue;
+    for (int j = 0; j < 4; j++) {
+      const int col = cs0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      if (col >= Cs) continue;
+      float* q = out + (size_t)row * Cs + col;
+      if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
+      else if (mode == 1) *reinterpret_cast<f32x4_t*>(q) += acc[i][j];
+      else {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int col = cs0 + wn * 64 + j * 16 + (lane & 15);
-        if (col >= Cs) continue;
-        float* q = out + (size_t)row * Cs + col;
-        if (mode == 2) *q = acc[i][j][r];
-        else if (mode == 1) *q += acc[i][j][r];
-        else atomicAdd(q, acc[i][j][r]);
+        for (int r = 0; r < 4; r++) atomicAdd(q + r, acc[i][j][r]);
       }
     }
   }
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 bool wgrad_mfma_supported(int dtype, const WgradParams& p) {
   if (dtype != GCT2_BF16 && dtype != GCT2_F16) return false;
   if (p.Cb % 8 || p.Cs % 8 || p.ldbig % 8 || p.ldsmall % 8) return false;
-  if ((uintptr_t)p.big % 16 || (uintptr_t)p.small % 16) return false;
+  if ((uintptr_t)p.big % 16 || (uintptr_t)p.small % 16 || (uintptr_t)p.dw % 16) return false;    // 16-byte loads and stores
   const size_t big_bytes = (size_t)p.B * p.Hs * p.Ws * 4 * p.ldbig * 2, small_bytes = (size_t)p.B * p.Hs * p.Ws * p.ldsmall * 2;
   if (big_bytes >= 0x7ff00000u || small_bytes >= 0x7ff00000u) return false;     // 31-bit buffer offsets
   return true;
