@@ -31,6 +31,12 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_pie
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
 }
 __device__ __forceinline__ int halo_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1); }
+// Weight image: fragment i of a wave holds the output channels 32 (i>>1) + 8 g + 4 (i&1) + r in its lane group g, so that the
+// fragments 2k and 2k+1 together give every lane EIGHT consecutive channels of its pixel -> 16-byte stores / mask loads in the
+// epilogue.  Row (= channel) of lane q in fragment i, and the swizzle that keeps those gathered rows conflict-free for
+// ds_read_b128 (exhaustive search over XOR-linear swizzles against the lane groups of MI355X_MICROARCH.md, LDS table):
+__device__ __forceinline__ int w_row(int i, int q) { return 32 * (i >> 1) + 8 * (q >> 2) + 4 * (i & 1) + (q & 3); }
+__device__ __forceinline__ int w_swz(int n) { return (((n >> 3) & 1) << 1) | (((n >> 1) & 1) << 2); }
 
 constexpr int HP = 18;                        // halo pitch (pixels per halo row)
 constexpr int HPIECES = 41;                   // 1-KiB pieces (8 pixel rows each) covering the 324 halo pixels
@@ -79,9 +85,9 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       }
     }
   }
-  // weights: piece (phase i, n-block wave): lane -> n = 8 wave + (lane>>3), physical chunk lane&7 (N-image swizzle)
+  // weights: piece (phase i, n-block wave): lane -> n = 8 wave + (lane>>3), physical chunk lane&7 (w_swz)
   const int w_n = 8 * wave + (lane >> 3);
-  const int w_lchunk = (lane & 7) ^ ((w_n >> 1) & 7);
+  const int w_lchunk = (lane & 7) ^ w_swz(w_n);
   const bool w_nok = (n0 + w_n) < N;
   const unsigned w_off = (unsigned)(((n0 + w_n) * K + w_lchunk * 8) * 2);
 
@@ -129,7 +135,10 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
     for (int kk = 0; kk < 2; kk++) {
       u32x4_t wf[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) wf[i] = nimg_frag(wimg, i * 16, kk, lane);
+      for (int i = 0; i < 4; i++) {
+        const int n = w_row(i, ql);
+        wf[i] = lds_read128(wimg, n * 128 + (((4 * kk + g) ^ w_swz(n)) << 4));
+      }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int row = row0 + j * HP;
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   }
 #undef GCT2_HALO_ROUND
 
-  // ---- epilogue: lane holds out[pixel (row mhalf*8 + j, col q)][n = n0 + 16 i + 4 g + r], phase (ph, pw) --------------
+  // ---- epilogue: lane holds out[pixel (row mhalf*8 + j, col q)][n = n0 + 32 (i>>1) + 8 g + 4 (i&1) + r], phase (ph, pw) ----
   // EPI_BIAS_ACT: bias + ReLU (Conv2DTranspose forward).  EPI_MASK: ReLU mask of the tensor the gradient belongs to, optional
   // accumulation into the skip slice, column sums for the fused bias gradient (Conv2D input gradient), as in tapgemm_kernel.
   T* __restrict__ yout = reinterpret_cast<T*>(p.y);
@@ -185,33 +194,43 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
     const int sh = sh0 + mhalf * 8 + j, sw = sw0 + eq;
     const size_t opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int n = n0 + i * 16 + 4 * eg;
-      if (n >= N) continue;
-      f32x4_t v = acc[i][j];
+    for (int ip = 0; ip < 2; ip++) {                           // fragments 2 ip, 2 ip + 1: channels n .. n + 7 of this lane
+      const int n = n0 + 32 * ip + 8 * eg;
+      if (n >= N) continue;                                    // N is a multiple of 8
+      f32x4_t v0 = acc[2 * ip][j], v1 = acc[2 * ip + 1][j];
       if (EPI == EPI_BIAS_ACT) {
-        if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+        if (p.bias) {
+          v0 += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+          v1 += *reinterpret_cast<const f32x4_t*>(p.bias + n + 4);
+        }
         if (p.relu) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 4; r++) { v0[r] = fmaxf(v0[r], 0.f); v1[r] = fmaxf(v1[r], 0.f); }
         }
       } else {
         if (actp) {
-          const u32x2_t a2 = *reinterpret_cast<const u32x2_t*>(actp + opix * p.ldact + n);
-          if (!(unpack_lo<T>(a2[0]) > 0.f)) v[0] = 0.f;
-          if (!(unpack_hi<T>(a2[0]) > 0.f)) v[1] = 0.f;
-          if (!(unpack_lo<T>(a2[1]) > 0.f)) v[2] = 0.f;
-          if (!(unpack_hi<T>(a2[1]) > 0.f)) v[3] = 0.f;
+          const u32x4_t a4 = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            if (!(unpack_lo<T>(a4[h]) > 0.f)) v0[2 * h] = 0.f;
+            if (!(unpack_hi<T>(a4[h]) > 0.f)) v0[2 * h + 1] = 0.f;
+            if (!(unpack_lo<T>(a4[2 + h]) > 0.f)) v1[2 * h] = 0.f;
+            if (!(unpack_hi<T>(a4[2 + h]) > 0.f)) v1[2 * h + 1] = 0.f;
+          }
         }
-        bsum[i] += v;
+        bsum[2 * ip] += v0;
+        bsum[2 * ip + 1] += v1;
         if (p.accumulate) {
-          const u32x2_t o2 = *reinterpret_cast<const u32x2_t*>(yout + opix * p.ldy + n);
-          v[0] += unpack_lo<T>(o2[0]); v[1] += unpack_hi<T>(o2[0]);
-          v[2] += unpack_lo<T>(o2[1]); v[3] += unpack_hi<T>(o2[1]);
+          const u32x4_t o4 = *reinterpret_cast<const u32x4_t*>(yout + opix * p.ldy + n);
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            v0[2 * h] += unpack_lo<T>(o4[h]); v0[2 * h + 1] += unpack_hi<T>(o4[h]);
+            v1[2 * h] += unpack_lo<T>(o4[2 + h]); v1[2 * h + 1] += unpack_hi<T>(o4[2 + h]);
+          }
         }
       }
-      u32x2_t o = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-      *reinterpret_cast<u32x2_t*>(yout + opix * p.ldy + n) = o;
+      const u32x4_t o = {pack2<T>(v0[0], v0[1]), pack2<T>(v0[2], v0[3]), pack2<T>(v1[0], v1[1]), pack2<T>(v1[2], v1[3])};
+      *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + n) = o;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       for (int r = 0; r < 4; r++) {
         float t = bsum[i][r];
         t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-        const int c = i * 16 + 4 * eg + r;
+        const int c = 32 * (i >> 1) + 8 * eg + 4 * (i & 1) + r;   // the channel this accumulator belongs to (w_row)
         if (eq == 0) {
           if (p.dbws) red[wave * 64 + c] = t;
           else if (n0 + c < N) {
@@ -258,6 +277,8 @@ int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, h
 bool halo_convT_wanted(int epi, const TapGemmParams& p) {
   if (g_halo_mode == 1) return false;
   if ((p.Hs & 15) || (p.Ws & 15)) return false;
+  // 16-byte epilogue accesses: output (and mask) views aligned to 16 bytes with pixel strides that are multiples of 8 elements
+  if ((uintptr_t)p.y % 16 || p.ldy % 8 || (p.act && ((uintptr_t)p.act % 16 || p.ldact % 8))) return false;
   if (g_halo_mode == 2) return true;
   // automatic: layers whose source-tile traffic dominates (few output channels per pixel) and that fill the chip
   const int tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4) * ((p.N + 63) / 64);

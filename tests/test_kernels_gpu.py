@@ -606,15 +606,15 @@ def test_convT_fwd_halo_kernel(gpu, dt, shape):
     for mode in (2, 1):          # halo forced / halo off: both against the oracle, and close to each other
         L.load().gct2_debug_tapgemm_variant(mode << 24)
         try:
-            ld = Cout + 8
+            ld = Cout + 16                # view = channels [8, 8 + Cout): 16-byte aligned rows (the halo kernel's epilogue needs that)
             yt = torch.full((B, 2 * H, 2 * W, ld), 7.0, dtype=TDT[dt], device=gpu)
-            L.call("gct2_convT4s2_fwd", dt, xd.data_ptr(), Cin, wtd.data_ptr(), bd.data_ptr(), yt.data_ptr() + 4 * yt.element_size(), ld,
+            L.call("gct2_convT4s2_fwd", dt, xd.data_ptr(), Cin, wtd.data_ptr(), bd.data_ptr(), yt.data_ptr() + 8 * yt.element_size(), ld,
                    B, H, W, Cin, Cout, 1, stream())
             torch.cuda.synchronize()
         finally:
             L.load().gct2_debug_tapgemm_variant(0)
-        assert rel_l2(yt[..., 4:4 + Cout].double().cpu().numpy(), ref) <= TOL_OUT[dt], mode
-        assert float((yt[..., :4].float() - 7).abs().max()) == 0 and float((yt[..., 4 + Cout:].float() - 7).abs().max()) == 0
+        assert rel_l2(yt[..., 8:8 + Cout].double().cpu().numpy(), ref) <= TOL_OUT[dt], mode
+        assert float((yt[..., :8].float() - 7).abs().max()) == 0 and float((yt[..., 8 + Cout:].float() - 7).abs().max()) == 0
         outs.append(yt)
     assert rel_l2(outs[0].double().cpu().numpy(), outs[1].double().cpu().numpy()) <= TOL_OUT[dt]
 
