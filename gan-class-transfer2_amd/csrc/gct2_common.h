@@ -108,6 +108,7 @@ struct TapGemmParams {
   float* ws; int ksplit;         // split-K: fp32 partial slabs [ksplit][out pixels][N] in the registered workspace
   int m_tiles, n_tiles, xcd_chunk;   // launch geometry (filled by the launcher): see xcd_tile()
   int ablate;                        // timing-only ablation bits (gct2_debug_tapgemm_variant >> 8)
+  int wide;                          // output / mask views allow 16-byte accesses (filled by the launcher)
   float* db; int db_split; float* db2;   // EPI_MASK: bias-gradient targets (column sums of the masked result), may be null
   float* dbws;                           // partial bias-gradient rows [m_tiles*phases | finalize rows][N] in the workspace, or null (atomics)
 };

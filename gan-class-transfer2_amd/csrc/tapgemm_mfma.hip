@@ -264,6 +264,78 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   f32x4_t bsum[4];                                  // bias-gradient partial sums: [n-fragment i][r], over this lane's pixels
 #pragma unroll
   for (int i = 0; i < 4; i++) bsum[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool wide = p.wide && p.ksplit == 1;                 // block-uniform
+  if (wide) {
+    // 16-byte epilogue: v_permlane16_swap exchanges the odd 16-lane rows of fragment 2k with the even rows of fragment 2k+1, after
+    // which a lane holds EIGHT consecutive channels of its pixel (rows g = 0, 2: fragment 2k, channels 4g .. 4g+7; rows g = 1, 3:
+    // fragment 2k+1, channels 4(g-1) .. 4(g-1)+7): half the store / mask-load / accumulate-load instructions of the 8-byte form
+    // (measured on the halo kernel, which gets the same layout from its weight image: -10..-15 %).
+    const int eg = elane >> 4;
+    const int nlane = wn * 64 + 16 * (eg & 1) + 4 * (eg & ~1);
+#pragma unroll
+    for (int j = 0; j < MF; j++) {
+      f32x4_t v0[2], v1[2];
+#pragma unroll
+      for (int ip = 0; ip < 2; ip++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {                           // all lanes take part in the exchange (no divergence before it)
+          // inline asm: hipcc (ROCm 7.2) folds the four __builtin_amdgcn_permlane16_swap calls of this loop into one
+          float xa = acc[2 * ip][j][r], xb = acc[2 * ip + 1][j][r];
+          asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(xa), "+v"(xb));
+          v0[ip][r] = xa;
+          v1[ip][r] = xb;
+        }
+      }
+      const int m = m0 + wm * WM + j * 16 + (elane & 15);
+      if (m >= M) continue;
+      size_t opix;
+      if (FORM == FORM_CONV) opix = (size_t)m;
+      else {
+        const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
+        opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
+      }
+#pragma unroll
+      for (int ip = 0; ip < 2; ip++) {
+        const int n = n0 + nlane + 32 * ip;
+        if (n >= N) continue;                                   // N is a multiple of 8
+        f32x4_t a = v0[ip], c = v1[ip];
+        if (EPI == EPI_BIAS_ACT) {
+          if (p.bias) {
+            a += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+            c += *reinterpret_cast<const f32x4_t*>(p.bias + n + 4);
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { a[r] = fmaxf(a[r], 0.f); c[r] = fmaxf(c[r], 0.f); }
+          }
+        } else {
+          if (actp) {
+            const u32x4_t a4 = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              if (!(unpack_lo<T>(a4[h]) > 0.f)) a[2 * h] = 0.f;
+              if (!(unpack_hi<T>(a4[h]) > 0.f)) a[2 * h + 1] = 0.f;
+              if (!(unpack_lo<T>(a4[2 + h]) > 0.f)) c[2 * h] = 0.f;
+              if (!(unpack_hi<T>(a4[2 + h]) > 0.f)) c[2 * h + 1] = 0.f;
+            }
+          }
+          bsum[2 * ip] += a;
+          bsum[2 * ip + 1] += c;
+          if (p.accumulate) {
+            const u32x4_t o4 = *reinterpret_cast<const u32x4_t*>(yout + opix * p.ldy + n);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              a[2 * h] += unpack_lo<T>(o4[h]); a[2 * h + 1] += unpack_hi<T>(o4[h]);
+              c[2 * h] += unpack_lo<T>(o4[2 + h]); c[2 * h + 1] += unpack_hi<T>(o4[2 + h]);
+            }
+          }
+        }
+        const u32x4_t o = {pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(c[0], c[1]), pack2<T>(c[2], c[3])};
+        *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + n) = o;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < MF; j++) {
     const int m = m0 + wm * WM + j * 16 + (elane & 15);
@@ -313,6 +385,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     }
     __builtin_amdgcn_sched_barrier(0);   // one 16-pixel column of the tile at a time: bounds the epilogue's live registers
   }
+  }
   if (EPI == EPI_MASK && (p.db || p.db2) && p.ksplit == 1) {
     // column sums over the wave's WM pixels: butterfly over the 16 lanes that share (lane>>4); then the waves of one
     // tile column meet in LDS (free after the K loop's last barrier) and the work-group stores ONE partial row,
@@ -326,7 +399,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       for (int r = 0; r < 4; r++) {
         float t = bsum[i][r];
         t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-        const int c = wn * 64 + i * 16 + 4 * (elane >> 4) + r;
+        const int eg2 = elane >> 4;
+        const int c = wide ? wn * 64 + 32 * (i >> 1) + 16 * (eg2 & 1) + 4 * (eg2 & ~1) + 4 * (i & 1) + r   // bsum[2k + h][r] after the swap
+                           : wn * 64 + i * 16 + 4 * eg2 + r;
         if ((elane & 15) == 0) {
           if (p.dbws) red[wm * BN + c] = t;
           else if (n0 + c < N) {
@@ -463,6 +538,7 @@ int launch(TapGemmParams p, hipStream_t s) {
   p.ksplit = 1;
   p.ws = nullptr;
   p.ablate = g_tapgemm_ablate;
+  p.wide = ((uintptr_t)p.y % 16 == 0 && p.ldy % 8 == 0 && (!p.act || ((uintptr_t)p.act % 16 == 0 && p.ldact % 8 == 0))) ? 1 : 0;
   size_t ws_bytes = 0;
   float* ws = gct2_workspace(&ws_bytes);
   p.m_tiles = (M + BM - 1) / BM;
