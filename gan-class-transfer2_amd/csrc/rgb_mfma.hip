@@ -92,6 +92,46 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(TapGemmParams p) {
       for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
   }
   T* __restrict__ y = reinterpret_cast<T*>(p.y);
+  const bool wide = ((uintptr_t)p.y % 16 == 0) && (p.ldy % 8 == 0);     // 16-byte stores possible (block-uniform)
+  if (wide) {
+    // v_permlane16_swap pairs the n-fragments 2k / 2k+1: afterwards a lane owns 8 consecutive channels of its pixel (see the
+    // epilogue of tapgemm_kernel): half the store instructions of this store-bound layer
+    const int eg = lane >> 4;
+    const int nlane = wn * 64 + 16 * (eg & 1) + 4 * (eg & ~1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      f32x4_t v0[2], v1[2];
+#pragma unroll
+      for (int ip = 0; ip < 2; ip++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float xa = acc[2 * ip][j][r], xb = acc[2 * ip + 1][j][r];
+          asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(xa), "+v"(xb));
+          v0[ip][r] = xa;
+          v1[ip][r] = xb;
+        }
+      }
+      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int ip = 0; ip < 2; ip++) {
+        const int n = n0 + nlane + 32 * ip;
+        if (n >= N) continue;
+        f32x4_t a = v0[ip], c = v1[ip];
+        if (p.bias) {
+          a += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+          c += *reinterpret_cast<const f32x4_t*>(p.bias + n + 4);
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) { a[r] = fmaxf(a[r], 0.f); c[r] = fmaxf(c[r], 0.f); }
+        }
+        const u32x4_t o = {pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(c[0], c[1]), pack2<T>(c[2], c[3])};
+        *reinterpret_cast<u32x4_t*>(y + (size_t)m * p.ldy + n) = o;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int m = m0 + wm * 64 + j * 16 + (lane & 15);
