@@ -282,7 +282,7 @@ bool halo_convT_wanted(int epi, const TapGemmParams& p) {
   if (g_halo_mode == 2) return true;
   // automatic: layers whose source-tile traffic dominates (few output channels per pixel) and that fill the chip
   const int tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4) * ((p.N + 63) / 64);
-  return p.N <= 128 && tiles >= 512;          // measured: UpShuffle_0 (N = 64) 206 -> 153 us, UpShuffle_1 (N = 128) 141 -> 136 us
+  return p.N <= 256 && tiles >= 256;          // measured vs tapgemm: U0 fwd 177 -> 136 us, U1 fwd 126 -> 120, U2 fwd 124 -> 122, D1 dgrad 88 -> 81, D2 dgrad 70 -> 66
 }
 
 int halo_convT(int dtype, int epi, TapGemmParams p, hipStream_t s) {
