@@ -39,10 +39,10 @@ SIGNATURES = {
     "gct2_debug_tapgemm_variant": [_i],
     "gct2_conv4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_conv4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
-    "gct2_conv4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gct2_conv4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_convT4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_convT4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
-    "gct2_convT4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gct2_convT4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_dense_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gct2_dense_bwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "gct2_dense_head_train": [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],

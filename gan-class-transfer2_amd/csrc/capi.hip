@@ -112,7 +112,7 @@ int run_wgrad(int dtype, const WgradParams& p, void* stream) {
 
 extern "C" {
 
-int gct2_abi_version(void) { return 8; }
+int gct2_abi_version(void) { return 9; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
 void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant((v >> 16) & 0xff); halo_set_mode((v >> 24) & 3); }
@@ -160,11 +160,12 @@ int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const
 }
 
 int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
-                       int Cin, int Cout, void* stream) {
+                       int Cin, int Cout, int accumulate, void* stream) {
   if (int e = check_conv_args("conv4s2_wgrad", dtype, x, dz, dw, B, H, W, Cin, Cout)) return e;
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: H=%d W=%d must be even", H, W);
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: ld smaller than channel count");
   WgradParams p{x, ldx, dz, lddz, dw, B, H / 2, W / 2, Cin, Cout, 1};
+  p.accumulate = accumulate ? 1 : 0;
   if (!g_force_direct && rgb_wgrad_supported(dtype, p)) {
     if (int e = rgb_wgrad(dtype, p, S(stream))) return e;
   } else if (int e = run_wgrad(dtype, p, stream)) return e;
@@ -189,10 +190,11 @@ int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, cons
 }
 
 int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
-                        int Cin, int Cout, void* stream) {
+                        int Cin, int Cout, int accumulate, void* stream) {
   if (int e = check_conv_args("convT4s2_wgrad", dtype, x, dz, dw, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: ld smaller than channel count");
   WgradParams p{dz, lddz, x, ldx, dw, B, H, W, Cout, Cin, 1};
+  p.accumulate = accumulate ? 1 : 0;
   if (int e = run_wgrad(dtype, p, stream)) return e;
   if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, 1.f, S(stream));
   return GCT2_OK;

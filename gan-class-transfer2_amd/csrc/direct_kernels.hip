@@ -104,6 +104,7 @@ int launch_wgrad(WgradParams p, hipStream_t s) {
   rsplit = max(1, min(rsplit, (R + 63) / 64));
   p.rsplit = rsplit;
   dim3 grid((unsigned)((total + 255) / 256), 1, rsplit);
+  if (!p.accumulate) (void)hipMemsetAsync(p.dw, 0, total * sizeof(float), s);      // the kernel adds with atomics
   hipLaunchKernelGGL(direct_wgrad_kernel<T>, grid, dim3(256), 0, s, p);
   return gct2_check_launch("direct_wgrad");
 }

@@ -139,4 +139,5 @@ struct WgradParams {
   int rsplit;                     // number of r-range splits
   int ablate;                     // timing-only ablation bits
   float* ws;                      // partial-tile slabs [rsplit][16*Cb][Cs] in the registered workspace, or null (atomics)
+  int accumulate;                 // 1: dw += result (caller keeps a running / pre-zeroed gradient); 0: dw = result
 };

@@ -265,6 +265,7 @@ int rgb_wgrad(int dtype, const WgradParams& p, hipStream_t s) {
   // 512 work-groups (two per CU): measured 1024 -> 48 us (atomics of 1024 partial tiles), 512 -> 38 us, 256 -> 48 us
   int splits = max(1, min(512 / ntiles, steps_total / 4));
   dim3 grid(splits, ntiles);
+  if (!p.accumulate) (void)hipMemsetAsync(p.dw, 0, (size_t)16 * p.Cb * p.Cs * sizeof(float), s);   // the kernel adds with atomics
   const size_t lds = 4 * 64 * 256;
   if (dtype == GCT2_BF16) hipLaunchKernelGGL(rgb_wgrad_kernel<__bf16>, grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL(rgb_wgrad_kernel<_Float16>, grid, dim3(256), lds, s, p);

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
       if (col >= Cs) continue;                         // Cs is a multiple of 8: a 4-column group is inside or outside as a whole
       float* q = out + (size_t)row * Cs + col;
       if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
-      else if (mode == 1) *reinterpret_cast<f32x4_t*>(q) += acc[i][j];
+      else if (mode == 1) { if (p.accumulate) *reinterpret_cast<f32x4_t*>(q) += acc[i][j]; else *reinterpret_cast<f32x4_t*>(q) = acc[i][j]; }
       else {
 #pragma unroll
         for (int r = 0; r < 4; r++) atomicAdd(q + r, acc[i][j][r]);
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(WgradParams p) {
       if (col >= Cs) continue;
       float* q = out + (size_t)row * Cs + col;
       if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
-      else if (mode == 1) *reinterpret_cast<f32x4_t*>(q) += acc[i][j];
+      else if (mode == 1) { if (p.accumulate) *reinterpret_cast<f32x4_t*>(q) += acc[i][j]; else *reinterpret_cast<f32x4_t*>(q) = acc[i][j]; }
       else {
 #pragma unroll
         for (int r = 0; r < 4; r++) atomicAdd(q + r, acc[i][j][r]);
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
       if (col >= Cs) continue;
       float* q = out + (size_t)row * Cs + col;
       if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
-      else if (mode == 1) *reinterpret_cast<f32x4_t*>(q) += acc[i][j];
+      else if (mode == 1) { if (p.accumulate) *reinterpret_cast<f32x4_t*>(q) += acc[i][j]; else *reinterpret_cast<f32x4_t*>(q) = acc[i][j]; }
       else {
 #pragma unroll
         for (int r = 0; r < 4; r++) atomicAdd(q + r, acc[i][j][r]);
@@ -487,7 +487,8 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
 }
 
 // dw[e] += sum_s slab[s][e], 4 elements per thread, slabs added in index order
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n4, int nsplit) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n4, int nsplit,
+                                                            int accumulate) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const f32x4_t* src = reinterpret_cast<const f32x4_t*>(ws) + i;
@@ -501,7 +502,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int u = 0; u < 8; u++) a += t[u];
   }
   for (; s < nsplit; s++) a += src[(size_t)s * n4];
-  reinterpret_cast<f32x4_t*>(dw)[i] += a;
+  if (accumulate) a += reinterpret_cast<const f32x4_t*>(dw)[i];   // without it the gradient is written, not read: 4 B/parameter less
+  reinterpret_cast<f32x4_t*>(dw)[i] = a;
 }
 
 }  // namespace
@@ -544,6 +546,9 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
       g_wgrad_variant != 7)
     p.ws = ws;
   dim3 grid(rsplit >= 8 ? tiles * 8 * ((rsplit + 7) / 8) : tiles * rsplit);
+  if (!p.ws && rsplit > 1 && !p.accumulate) {     // atomics add into the target: start it from zero
+    (void)hipMemsetAsync(p.dw, 0, n * sizeof(float), s);
+  }
   const bool one_buf = g_wgrad_variant == 1;
   if (big_tile && g_wgrad_pipe) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256p_kernel<__bf16>, grid, dim3(512), 0, s, p);
@@ -558,7 +563,7 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
     if (one_buf) hipLaunchKernelGGL((wgrad_kernel<_Float16, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<_Float16, 2>), grid, dim3(256), 0, s, p);
   }
-  if (p.ws) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, p.ws, p.dw, n / 4, rsplit);
+  if (p.ws) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, p.ws, p.dw, n / 4, rsplit, p.accumulate);
   return gct2_check_launch("wgrad_mfma");
 }
 

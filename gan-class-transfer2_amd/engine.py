@@ -410,7 +410,7 @@ class UNetEngine:
             # it writes (fused into its epilogue), so only U_0's bias needs the wgrad entry point's db when the head is unfused
             db_u = A.gptr(f"U{i}.b") if (i == 0 and not head_done) else None
             side_waits_main()                                   # dz (and this layer's bias gradient) are complete
-            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), sw)
+            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), 0, sw)
             with torch.cuda.stream(side):
                 self._ready(f"U{i}")
             adam_upto(prev)
@@ -430,7 +430,7 @@ class UNetEngine:
             x, ldx = self._slice_ptr(b.R[i], t.fu(i)), b.ld[i]
             xw, ldxw = (b.img.data_ptr(), 4) if i == 0 else (x, ldx)
             side_waits_main()
-            call("gct2_conv4s2_wgrad", dt, xw, ldxw, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), sw)
+            call("gct2_conv4s2_wgrad", dt, xw, ldxw, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), 0, sw)
             with torch.cuda.stream(side):
                 self._ready(f"D{i}")
             adam_upto(prev)

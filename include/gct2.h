@@ -79,10 +79,10 @@ int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const
                        int accumulate, float* db, int db_split, float* db2, void* stream);
 
 /* weight + bias gradient: dw[kh,kw,i,o] += sum_{b,oh,ow} x[b,2oh+kh-1,2ow+kw-1,i]*dz[b,oh,ow,o],
- * db[o] += sum dz[..,o].  dw: fp32 (4,4,Cin,Cout), db: fp32[Cout] or NULL.  ACCUMULATES: the caller
- * provides zeroed (or running) buffers. */
+ * db[o] += sum dz[..,o].  dw: fp32 (4,4,Cin,Cout), db: fp32[Cout] or NULL.  accumulate != 0: dw is a running (or
+ * zeroed) buffer and is added to; accumulate == 0: dw is overwritten (saves reading it).  db always accumulates. */
 int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
-                       float* db, int B, int H, int W, int Cin, int Cout, void* stream);
+                       float* db, int B, int H, int W, int Cin, int Cout, int accumulate, void* stream);
 
 /* ---- UpShuffle = Conv2DTranspose(f, 4, 2, 'same', relu)   train.py:145-156 ------------------ */
 /* y[b,2ih+kh-1,2iw+kw-1,o] += x[b,ih,iw,i] * w[kh,kw,o,i]; then bias, relu.
@@ -99,7 +99,8 @@ int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, cons
 
 /* dw[kh,kw,o,i] += sum_{b,ih,iw} x[b,ih,iw,i] * dz[b,2ih+kh-1,2iw+kw-1,o]; db[o] += sum dz. */
 int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
-                        float* db, int B, int H, int W, int Cin, int Cout, void* stream);
+                        float* db, int B, int H, int W, int Cin, int Cout, int accumulate,
+                        void* stream);
 
 /* ---- Dense(3) head on a rank-4 input   train.py:198-202 ------------------------------------- */
 /* y[m,o] = b[o] + sum_i x[m,i] * w[i,o];  x: [M,Cin] view of `dtype`; w fp32 (Cin,Cout), Cout <= 4;

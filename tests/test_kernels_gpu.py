@@ -159,13 +159,13 @@ def test_conv4s2_wgrad(gpu, dt, shape):
     dw = torch.zeros(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)
     db = torch.zeros(Cout, dtype=torch.float32, device=gpu)
     lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(),
-               B, H, W, Cin, Cout, stream())
+               B, H, W, Cin, Cout, 1, stream())
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu().numpy(), dw_ref) <= TOL_F32OUT[dt]
     assert rel_l2(db.cpu().numpy(), db_ref) <= TOL_F32OUT[dt]
     # the entry point ACCUMULATES: a second call doubles the result
     lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(),
-               B, H, W, Cin, Cout, stream())
+               B, H, W, Cin, Cout, 1, stream())
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu().numpy(), 2 * dw_ref) <= TOL_F32OUT[dt]
 
@@ -185,7 +185,7 @@ def test_wgrad_reduction_modes_agree(gpu, shape):
     for use_ws in (False, True, True):
         lib().call("gct2_set_workspace", ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0)
         dw = torch.ones(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)       # running buffer: the call ACCUMULATES
-        lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, stream())
+        lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, stream())
         torch.cuda.synchronize()
         res.append(dw.cpu().numpy())
     lib().call("gct2_set_workspace", None, 0)
@@ -210,8 +210,8 @@ def test_wgrad_tile_variants(gpu, variant, shape):
         xd, dzd, dztd = dev(x, dt, gpu), dev(dz, dt, gpu), dev(dzt, dt, gpu)
         dw = torch.zeros(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)
         dwt = torch.zeros(4, 4, Cout, Cin, dtype=torch.float32, device=gpu)
-        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, stream())
-        L.call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), Cin, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, stream())
+        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, stream())
+        L.call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), Cin, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 1, stream())
         torch.cuda.synchronize()
         assert rel_l2(dw.cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
         assert rel_l2(dwt.cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
@@ -232,7 +232,7 @@ def test_convT4s2_wgrad(gpu, dt, shape):
     dw = torch.zeros(4, 4, Cout, Cin, dtype=torch.float32, device=gpu)
     db = torch.zeros(Cout, dtype=torch.float32, device=gpu)
     lib().call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(),
-               B, H, W, Cin, Cout, stream())
+               B, H, W, Cin, Cout, 1, stream())
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu().numpy(), dw_ref) <= TOL_F32OUT[dt]
     assert rel_l2(db.cpu().numpy(), db_ref) <= TOL_F32OUT[dt]
@@ -650,4 +650,42 @@ def test_conv_dgrad_halo_kernel(gpu, shape, use_ws):
         assert rel_l2(dxd.double().cpu().numpy(), contrib + prev) <= TOL_OUT[dt]
     finally:
         L.load().gct2_debug_tapgemm_variant(0)
+        L.call("gct2_set_workspace", None, 0)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 128), (2, 8, 8, 256, 512), (1, 16, 16, 3, 128)])
+def test_wgrad_overwrite_mode(gpu, dt, shape, use_ws):
+    """accumulate = 0: dw is overwritten (no pre-zeroing, no read) on every path - workspace slabs, one-owner tiles, atomics after
+    an internal memset (no workspace / direct fp32 kernels / the 3-channel layer); accumulate = 1 adds to what is there."""
+    B, H, W, Cin, Cout = shape
+    L = lib()
+    ws = torch.empty(16 << 18, dtype=torch.float32, device=gpu)
+    L.call("gct2_set_workspace", ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0)
+    try:
+        rng = np.random.default_rng(51)
+        x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+        dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+        ref = O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]
+        ldx = 4 if Cin == 3 else Cin
+        xd = torch.zeros(B, H, W, ldx, dtype=TDT[dt], device=gpu)
+        xd[..., :Cin] = dev(x, dt, gpu)
+        dzd = dev(dz, dt, gpu)
+        dw = torch.full((4, 4, Cin, Cout), 1e6, dtype=torch.float32, device=gpu)          # garbage that must disappear
+        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), ldx, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, stream())
+        torch.cuda.synchronize()
+        assert rel_l2(dw.cpu().numpy(), ref) <= TOL_F32OUT[dt]
+        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), ldx, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, stream())
+        torch.cuda.synchronize()
+        assert rel_l2(dw.cpu().numpy(), 2 * ref) <= TOL_F32OUT[dt]
+        if Cin != 3:
+            dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+            reft = O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]
+            dztd = dev(dzt, dt, gpu)
+            dwt = torch.full((4, 4, Cout, Cin), -3e5, dtype=torch.float32, device=gpu)
+            L.call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), ldx, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 0, stream())
+            torch.cuda.synchronize()
+            assert rel_l2(dwt.cpu().numpy(), reft) <= TOL_F32OUT[dt]
+    finally:
         L.call("gct2_set_workspace", None, 0)
