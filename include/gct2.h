@@ -46,7 +46,8 @@ void gct2_debug_force_direct(int on);
  * bits 0-7: dgrad/forward tile, 0 = automatic, 1/2 = 128x128 with 1/2 LDS buffers, 3 = 256x128 8 waves 3 buffers,
  * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles);  bits 8-9: timing-only ablation (results invalid);
  * bits 16-19: weight-gradient tile, 0 = automatic, 1/3 = 128x128 with 1/2 buffers, 2 = 256x256, 7 = atomics;
- * bit 22: 256x256 weight-gradient tile with two 64-row buffers instead of the four-stage pipeline. */
+ * bit 22: 256x256 weight-gradient tile with two 64-row buffers instead of the four-stage pipeline;
+ * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D dgrad), 0 = automatic, 1 = never, 2 = wherever the shape allows. */
 void gct2_debug_tapgemm_variant(int v);
 /* optional caller-owned device scratch (16-byte aligned) for the split-K partial sums of layers whose output
  * is too small to fill the chip (the U-Net's bottleneck levels).  Process-wide; kernels that use it must be
