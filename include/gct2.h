@@ -98,7 +98,8 @@ int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, cons
                         int ldact, void* dx, int lddx, int B, int H, int W, int Cin, int Cout,
                         int accumulate, float* db, int db_split, float* db2, void* stream);
 
-/* dw[kh,kw,o,i] += sum_{b,ih,iw} x[b,ih,iw,i] * dz[b,2ih+kh-1,2iw+kw-1,o]; db[o] += sum dz. */
+/* dw[kh,kw,o,i] (+)= sum_{b,ih,iw} x[b,ih,iw,i] * dz[b,2ih+kh-1,2iw+kw-1,o]; db[o] += sum dz; accumulate as for
+ * conv4s2_wgrad. */
 int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
                         float* db, int B, int H, int W, int Cin, int Cout, int accumulate,
                         void* stream);
