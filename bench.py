@@ -79,7 +79,7 @@ class KernelTimer:
             fam = timer.FAMILY.get(name) if timer.enabled else None
             # D0 (Cin = 3) runs the direct kernel: keep it out of the MFMA families
             if fam is not None and ((name == "gct2_conv4s2_fwd" and args[-4] == 3) or
-                                    (name == "gct2_conv4s2_wgrad" and args[-4] == 3)):
+                                    (name == "gct2_conv4s2_wgrad" and args[-5] == 3)):
                 fam = None
             if fam is None:
                 return orig(name, *args)

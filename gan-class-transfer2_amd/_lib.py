@@ -23,6 +23,13 @@ class LossScaleState(C.Structure):
     _fields_ = [("scale", C.c_float), ("inv_scale", C.c_float), ("good_steps", C.c_int32), ("found_inf", C.c_int32)]
 
 
+class AdamArgs(C.Structure):
+    """gct2_adam_args (include/gct2.h): the optimizer step fused behind a weight-gradient call."""
+    _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("shadow", C.c_void_p), ("shadow_dtype", C.c_int),
+                ("n", C.c_size_t), ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("grad_mul", C.c_float)]
+
+
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
 # name -> argtypes, exactly the prototypes of include/gct2.h
@@ -39,10 +46,10 @@ SIGNATURES = {
     "gct2_debug_tapgemm_variant": [_i],
     "gct2_conv4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_conv4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
-    "gct2_conv4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_conv4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "gct2_convT4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_convT4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
-    "gct2_convT4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_convT4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "gct2_dense_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gct2_dense_bwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "gct2_dense_head_train": [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],

@@ -12,7 +12,7 @@ void tapgemm_set_variant(int v);
 void wgrad_set_variant(int v);
 void halo_set_mode(int m);
 bool wgrad_mfma_supported(int dtype, const WgradParams& p);
-int wgrad_mfma(int dtype, WgradParams p, hipStream_t s);
+int wgrad_mfma(int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer);
 int wgrad_direct(int dtype, const WgradParams& p, hipStream_t s);
 bool rgb_fwd_supported(int dtype, const TapGemmParams& p);
 int rgb_fwd(int dtype, const TapGemmParams& p, hipStream_t s);
@@ -32,7 +32,8 @@ int pw_diffusion_mix(int, const float*, const float*, float, float*, void*, int,
 int pw_diffusion_update(const float*, const float*, float, float*, float*, size_t, hipStream_t);
 int pw_noise_edits(const float*, const float*, int, float*, int, int, int, hipStream_t);
 int pw_image_prepare(const uint8_t*, const int64_t*, const int32_t*, float*, int, int, hipStream_t);
-int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const float*, const int32_t*, int, hipStream_t);
+int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const float*, const int32_t*, int, hipStream_t,
+            const float* slabs = nullptr, int nslab = 0, size_t slab_stride = 0, size_t n_slab = 0, size_t zero_from = 0);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
 int pw_ls_init(gct2_loss_scale_state*, float, hipStream_t);
 int pw_ls_begin(gct2_loss_scale_state*, hipStream_t);
@@ -104,15 +105,27 @@ int run_dgrad(int dtype, int form, TapGemmParams p, size_t out_pixels, float* db
   if (int e = tapgemm_direct(dtype, form, EPI_MASK, p, S(stream))) return e;
   return (db || db2) ? sums(1.f) : GCT2_OK;
 }
-int run_wgrad(int dtype, const WgradParams& p, void* stream) {
-  if (!g_force_direct && wgrad_mfma_supported(dtype, p)) return wgrad_mfma(dtype, p, S(stream));
+int run_wgrad(int dtype, const WgradParams& p, void* stream, WgradSlabs* defer = nullptr) {
+  if (defer) *defer = WgradSlabs{nullptr, 0, 0};
+  if (!g_force_direct && wgrad_mfma_supported(dtype, p)) return wgrad_mfma(dtype, p, S(stream), defer);
   return wgrad_direct(dtype, p, S(stream));
+}
+// Keras Adam right behind a weight-gradient launch, on the same stream (gct2_adam_args): the layer's parameters [weights | pad |
+// bias] are one contiguous range of the caller's arenas; the weight gradient comes from the slabs the launch left (never
+// materialised) or from dw (written, not accumulated: no zeroing), the bias gradient from g (accumulated elsewhere: zeroed here)
+int adam_after_wgrad(const gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& sl, void* stream) {
+  if (!a->p || !a->m || !a->v) return gct2_fail(GCT2_EINVAL, "wgrad + adam: null arena pointers");
+  if (a->n < nw || ((uintptr_t)a->p | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)dw) % 16)
+    return gct2_fail(GCT2_EINVAL, "wgrad + adam: range shorter than the weight tensor or misaligned");
+  const size_t nw4 = (nw + 3) & ~(size_t)3;
+  return pw_adam(a->p, a->m, a->v, dw, a->shadow, a->shadow_dtype, a->n, a->alpha, a->beta1, a->beta2, a->eps, a->grad_mul, nullptr, nullptr,
+                 1, S(stream), sl.base, sl.nslab, sl.stride, sl.nslab ? nw : 0, nw4);
 }
 }  // namespace
 
 extern "C" {
 
-int gct2_abi_version(void) { return 9; }
+int gct2_abi_version(void) { return 10; }
 const char* gct2_last_error(void) { return g_err; }
 void gct2_debug_force_direct(int on) { g_force_direct = on; }
 void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant((v >> 16) & 0xff); halo_set_mode((v >> 24) & 3); }
@@ -160,16 +173,20 @@ int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const
 }
 
 int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
-                       int Cin, int Cout, int accumulate, void* stream) {
+                       int Cin, int Cout, int accumulate, const gct2_adam_args* adam, void* stream) {
   if (int e = check_conv_args("conv4s2_wgrad", dtype, x, dz, dw, B, H, W, Cin, Cout)) return e;
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: H=%d W=%d must be even", H, W);
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: ld smaller than channel count");
+  if (adam && accumulate) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: the fused optimizer step needs accumulate = 0");
   WgradParams p{x, ldx, dz, lddz, dw, B, H / 2, W / 2, Cin, Cout, 1};
   p.accumulate = accumulate ? 1 : 0;
+  WgradSlabs sl{nullptr, 0, 0};
   if (!g_force_direct && rgb_wgrad_supported(dtype, p)) {
     if (int e = rgb_wgrad(dtype, p, S(stream))) return e;
-  } else if (int e = run_wgrad(dtype, p, stream)) return e;
-  if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, 1.f, S(stream));
+  } else if (int e = run_wgrad(dtype, p, stream, adam ? &sl : nullptr)) return e;
+  if (db)
+    if (int e = pw_colsum(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, 1.f, S(stream))) return e;
+  if (adam) return adam_after_wgrad(adam, dw, (size_t)16 * Cin * Cout, sl, stream);
   return GCT2_OK;
 }
 
@@ -190,13 +207,17 @@ int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, cons
 }
 
 int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
-                        int Cin, int Cout, int accumulate, void* stream) {
+                        int Cin, int Cout, int accumulate, const gct2_adam_args* adam, void* stream) {
   if (int e = check_conv_args("convT4s2_wgrad", dtype, x, dz, dw, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: ld smaller than channel count");
+  if (adam && accumulate) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: the fused optimizer step needs accumulate = 0");
   WgradParams p{dz, lddz, x, ldx, dw, B, H, W, Cout, Cin, 1};
   p.accumulate = accumulate ? 1 : 0;
-  if (int e = run_wgrad(dtype, p, stream)) return e;
-  if (db) return pw_colsum(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, 1.f, S(stream));
+  WgradSlabs sl{nullptr, 0, 0};
+  if (int e = run_wgrad(dtype, p, stream, adam ? &sl : nullptr)) return e;
+  if (db)
+    if (int e = pw_colsum(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, 1.f, S(stream))) return e;
+  if (adam) return adam_after_wgrad(adam, dw, (size_t)16 * Cin * Cout, sl, stream);
   return GCT2_OK;
 }
 

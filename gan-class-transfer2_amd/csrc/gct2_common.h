@@ -141,3 +141,6 @@ struct WgradParams {
   float* ws;                      // partial-tile slabs [rsplit][16*Cb][Cs] in the registered workspace, or null (atomics)
   int accumulate;                 // 1: dw += result (caller keeps a running / pre-zeroed gradient); 0: dw = result
 };
+// wgrad_mfma(): when `defer` is non-null and the launch left its result as workspace slabs, the slab reduction is NOT launched and
+// the slabs are described here (the caller folds them into the optimizer read); nslab = 0 means dw holds the gradient
+struct WgradSlabs { const float* base; int nslab; size_t stride; };

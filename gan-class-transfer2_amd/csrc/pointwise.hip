@@ -705,15 +705,37 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float* __restrict__ g, S* __restrict__ shadow, size_t n, float alpha,
                                                    float b1, float b2, float eps, float grad_mul,
                                                    const float* __restrict__ inv_scale_ptr,
-                                                   const int32_t* __restrict__ found_inf, int zero_grad) {
+                                                   const int32_t* __restrict__ found_inf, int zero_grad,
+                                                   const float* __restrict__ slabs, int nslab, size_t slab_stride, size_t n_slab,
+                                                   size_t zero_from) {
+  // slabs != NULL: the gradient of the first n_slab elements (a multiple of 4) is the ordered sum of `nslab` partial slabs
+  // (slab s at slabs + s * slab_stride) left by a weight-gradient launch - it is never written to or read from g.
+  // zero_from: with zero_grad, only elements >= zero_from (a multiple of 4) are zeroed (a written, not accumulated, weight
+  // gradient needs no zeroing; the bias gradients behind it do).
   const bool skip = found_inf && *found_inf != 0;
   const float inv_scale = (inv_scale_ptr ? *inv_scale_ptr : 1.f) * grad_mul;
   const size_t n4 = n >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const float ob1 = 1.f - b1, ob2 = 1.f - b2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4_t gv = reinterpret_cast<f32x4_t*>(g)[i];
-    if (zero_grad) reinterpret_cast<f32x4_t*>(g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t gv;
+    if (slabs && (i << 2) < n_slab) {
+      const f32x4_t* src = reinterpret_cast<const f32x4_t*>(slabs) + i;
+      const size_t st4 = slab_stride >> 2;
+      gv = src[0];
+      int sidx = 1;
+      for (; sidx + 8 <= nslab; sidx += 8) {     // 8 independent slab loads in flight, added in slab order
+        f32x4_t t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = src[(size_t)(sidx + u) * st4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) gv += t[u];
+      }
+      for (; sidx < nslab; sidx++) gv += src[(size_t)sidx * st4];
+    } else {
+      gv = reinterpret_cast<f32x4_t*>(g)[i];
+      if (zero_grad && (i << 2) >= zero_from) reinterpret_cast<f32x4_t*>(g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     if (skip) continue;
     f32x4_t pv = reinterpret_cast<f32x4_t*>(p)[i], mv = reinterpret_cast<f32x4_t*>(m)[i], vv = reinterpret_cast<f32x4_t*>(v)[i];
 #pragma unroll
@@ -952,10 +974,11 @@ int pw_colsum(int dtype, const void* dz, int ld, float* db, size_t M, int C, flo
   return colsum_t<_Float16>(dz, ld, db, M, C, sign, s);
 }
 int pw_adam(float* p, float* m, float* v, float* g, void* shadow, int sdt, size_t n, float alpha, float b1, float b2, float eps,
-            float grad_mul, const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad, hipStream_t s) {
+            float grad_mul, const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad, hipStream_t s,
+            const float* slabs, int nslab, size_t slab_stride, size_t n_slab, size_t zero_from) {
   if (n == 0) return GCT2_OK;
   const int nb = blocks_for(n / 4 + 4, 256);
-#define GCT2_ADAM(S, HS) hipLaunchKernelGGL((adam_kernel<S, HS>), dim3(nb), dim3(256), 0, s, p, m, v, g, reinterpret_cast<S*>(shadow), n, alpha, b1, b2, eps, grad_mul, inv_scale_ptr, found_inf, zero_grad)
+#define GCT2_ADAM(S, HS) hipLaunchKernelGGL((adam_kernel<S, HS>), dim3(nb), dim3(256), 0, s, p, m, v, g, reinterpret_cast<S*>(shadow), n, alpha, b1, b2, eps, grad_mul, inv_scale_ptr, found_inf, zero_grad, slabs, nslab, slab_stride, n_slab, zero_from)
   if (!shadow) GCT2_ADAM(float, false);
   else if (sdt == GCT2_BF16) GCT2_ADAM(__bf16, true);
   else if (sdt == GCT2_F16) GCT2_ADAM(_Float16, true);

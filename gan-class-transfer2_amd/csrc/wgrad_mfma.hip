@@ -517,7 +517,8 @@ bool wgrad_mfma_supported(int dtype, const WgradParams& p) {
   return true;
 }
 
-int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
+int wgrad_mfma(int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer) {
+  if (defer) *defer = WgradSlabs{nullptr, 0, 0};
   const int R = p.B * p.Hs * p.Ws;
   // 256 x 256 tile (one work-group per CU) whenever the 128 x 128 tiling would have to split the reduction anyway
   // (fewer than 512 tiles): measured -10..-22 % on U0/U1/U2/D1/D2 (profiles/r01_wgrad_variants.txt)
@@ -563,7 +564,8 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s) {
     if (one_buf) hipLaunchKernelGGL((wgrad_kernel<_Float16, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<_Float16, 2>), grid, dim3(256), 0, s, p);
   }
-  if (p.ws) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, p.ws, p.dw, n / 4, rsplit, p.accumulate);
+  if (p.ws && defer && !p.accumulate) *defer = WgradSlabs{p.ws, rsplit, n};     // the caller's optimizer kernel sums the slabs
+  else if (p.ws) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, p.ws, p.dw, n / 4, rsplit, p.accumulate);
   return gct2_check_launch("wgrad_mfma");
 }
 

@@ -12,6 +12,7 @@ HBM layout (all NHWC, `ld` = pixel stride in elements):
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
@@ -184,6 +185,7 @@ class UNetEngine:
         # second stream + its own scratch: the weight-gradient kernels (and, single-GPU, the per-layer Adam launches) run
         # beside the dgrad chain instead of between its links (backward())
         self.overlap = True
+        self.fuse_adam = True          # per-layer Adam fused behind the weight-gradient calls (single replica, no loss scaling)
         self._side = torch.cuda.Stream(device=self.device)
         self.wgrad_workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
         self._ensure_workspace()
@@ -368,9 +370,9 @@ class UNetEngine:
 
         Two streams: the dgrad chain (the only true dependency chain of the reverse pass) stays on the current stream;
         every weight gradient is enqueued on the side stream behind an event of the dgrad launch that produced its dz, so
-        its work-groups fill the tails and the small bottleneck launches of the chain.  adam_inline (single GPU, no loss
-        scaling): a layer's Adam update follows on the side stream once its dgrad (the last reader of its weights) is
-        done.  The current stream joins the side stream before returning."""
+        its work-groups fill the tails and the small bottleneck launches of the chain.  adam_inline (single replica, no loss
+        scaling): each layer's Adam step is fused behind its weight-gradient call (gct2_adam_args) once the layer's dgrad -
+        the last reader of its weights - is done.  The current stream joins the side stream before returning."""
         self._ensure_workspace()
         t, n, dt, A = self.topo, self.topo.octaves, self.dtype, self.arena
         main = torch.cuda.current_stream(self.device)
@@ -398,7 +400,24 @@ class UNetEngine:
                 self.apply_adam(adam_lo, hi, stream=sw)
                 adam_lo = hi
 
-        prev: Optional[str] = "dense"                           # layers whose weights have no reader left on main
+        # adam_inline: every layer's Keras-Adam step is fused behind its weight-gradient call (gct2_adam_args): the gradient of
+        # the kernel is consumed from the launch's partial sums or from the arena without ever being zeroed.  The update writes
+        # the layer's operand copy, so it must follow the layer's dgrad (the last reader): in that mode the dgrad is enqueued
+        # first and the side stream waits for it - the weight gradient of layer L then runs beside the dgrad of layer L+1.
+        def fused(layer: str):
+            if not adam_inline:
+                return None
+            lo, hi = A.layer_ranges[layer]
+            args = _lib.AdamArgs(A.p.data_ptr() + 4 * lo, A.m.data_ptr() + 4 * lo, A.v.data_ptr() + 4 * lo,
+                                 (A.shadow.data_ptr() + 2 * lo) if A.shadow is not None else None, self.dtype, hi - lo,
+                                 self.adam_alpha(), self.beta_1, self.beta_2, self.epsilon, 1.0)
+            keep.append(args)
+            return ctypes.addressof(args)
+
+        keep: list = []
+        if adam_inline:
+            side_waits_main()                                   # the head (and its gradients) are done
+            adam_upto("dense", force=True)                      # the head's parameters: nothing reads them any more
         for i in range(n):                                      # UpShuffle_i backward, outermost first
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
@@ -409,18 +428,24 @@ class UNetEngine:
             # bias gradients are column sums of pre-activation gradients: each dgrad launch adds the sums of the tensor
             # it writes (fused into its epilogue), so only U_0's bias needs the wgrad entry point's db when the head is unfused
             db_u = A.gptr(f"U{i}.b") if (i == 0 and not head_done) else None
-            side_waits_main()                                   # dz (and this layer's bias gradient) are complete
-            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), 0, sw)
-            with torch.cuda.stream(side):
-                self._ready(f"U{i}")
-            adam_upto(prev)
             if i < n - 1:       # dx = dR_{i+1}: channels [0, Fu_{i+1}) belong to U_{i+1}, the rest to D_i
                 db, split, db2 = A.gptr(f"U{i + 1}.b"), t.fu(i + 1), A.gptr(f"D{i}.b")
             else:               # dx = gradient of D_{n-1}'s output
                 db, split, db2 = A.gptr(f"D{i}.b"), t.fd(i), None
-            call("gct2_convT4s2_dgrad", dt, dz, lddz, A.wptr(f"U{i}.w"), x, ldx, dx, lddx, b.B, Hi, Wi, t.up_in(i),
-                 t.fu(i), 0, db, split, db2, s)
-            prev = f"U{i}"
+
+            def dgrad_u():
+                call("gct2_convT4s2_dgrad", dt, dz, lddz, A.wptr(f"U{i}.w"), x, ldx, dx, lddx, b.B, Hi, Wi, t.up_in(i),
+                     t.fu(i), 0, db, split, db2, s)
+
+            if adam_inline:
+                dgrad_u()
+            side_waits_main()                                   # dz (and this layer's bias gradient) are complete
+            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), 0,
+                 fused(f"U{i}"), sw)
+            with torch.cuda.stream(side):
+                self._ready(f"U{i}")
+            if not adam_inline:
+                dgrad_u()
         for i in reversed(range(n)):                            # DownShuffle_i backward, innermost first
             H, W = b.hw[i]
             if i < n - 1:
@@ -429,16 +454,21 @@ class UNetEngine:
                 dz, lddz = b.dDlast.data_ptr(), t.fd(i)
             x, ldx = self._slice_ptr(b.R[i], t.fu(i)), b.ld[i]
             xw, ldxw = (b.img.data_ptr(), 4) if i == 0 else (x, ldx)
+
+            def dgrad_d():
+                if i > 0:                                       # the image itself needs no gradient
+                    call("gct2_conv4s2_dgrad", dt, dz, lddz, A.wptr(f"D{i}.w"), x, ldx, self._slice_ptr(b.dR[i], t.fu(i)),
+                         b.ld[i], b.B, H, W, t.cx(i), t.fd(i), 1, A.gptr(f"D{i - 1}.b"), t.cx(i), None, s)
+
+            if adam_inline:
+                dgrad_d()
             side_waits_main()
-            call("gct2_conv4s2_wgrad", dt, xw, ldxw, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), 0, sw)
+            call("gct2_conv4s2_wgrad", dt, xw, ldxw, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), 0,
+                 fused(f"D{i}"), sw)
             with torch.cuda.stream(side):
                 self._ready(f"D{i}")
-            adam_upto(prev)
-            if i > 0:                                           # the image itself needs no gradient
-                call("gct2_conv4s2_dgrad", dt, dz, lddz, A.wptr(f"D{i}.w"), x, ldx, self._slice_ptr(b.dR[i], t.fu(i)),
-                     b.ld[i], b.B, H, W, t.cx(i), t.fd(i), 1, A.gptr(f"D{i - 1}.b"), t.cx(i), None, s)
-            prev = f"D{i}"
-        adam_upto(None, force=True)                             # D_0 has no dgrad: nothing on main reads the weights any more
+            if not adam_inline:
+                dgrad_d()
         if side is not main:
             main.wait_stream(side)
 
@@ -509,7 +539,7 @@ class UNetEngine:
         loss = self.head_train(b, x) if fused else self.loss_and_dpred(b, x)
         # single GPU without loss scaling: Adam rides the side stream inside backward(); the loss-scaled step has to see
         # every gradient (finite check) before any update
-        inline = apply and self.overlap and self.ls_state is None
+        inline = apply and self.fuse_adam and self.ls_state is None
         self.backward(b, head_done=fused, adam_inline=inline)
         if apply:
             if not inline:

@@ -79,11 +79,26 @@ int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const
                        int ldact, void* dx, int lddx, int B, int H, int W, int Cin, int Cout,
                        int accumulate, float* db, int db_split, float* db2, void* stream);
 
+/* optional optimizer step fused behind a weight-gradient call (single-replica training without loss scaling): Keras Adam
+ * (as gct2_adam_keras_multi) over the layer's contiguous parameter range [kernel | padding | bias ...] of the caller's
+ * arenas, enqueued on the same stream right after the gradient.  p, m, v: fp32, start of the kernel's slice; n: elements of
+ * the whole range (>= the kernel's 16*Cin*Cout); dw (the call's gradient pointer) must be the matching start of the gradient
+ * arena.  The kernel gradient is consumed straight from the launch's partial sums where it has them (it is then never
+ * written to dw) or from dw; gradients behind the kernel in the range (the bias, accumulated by the dgrad calls) are read
+ * from the gradient arena and zeroed.  Needs accumulate = 0. */
+typedef struct gct2_adam_args {
+  float* p; float* m; float* v;
+  void* shadow; int shadow_dtype;      /* compute-dtype copy of p over the same range, or NULL */
+  size_t n;
+  float alpha, beta1, beta2, eps, grad_mul;
+} gct2_adam_args;
+
 /* weight + bias gradient: dw[kh,kw,i,o] += sum_{b,oh,ow} x[b,2oh+kh-1,2ow+kw-1,i]*dz[b,oh,ow,o],
  * db[o] += sum dz[..,o].  dw: fp32 (4,4,Cin,Cout), db: fp32[Cout] or NULL.  accumulate != 0: dw is a running (or
  * zeroed) buffer and is added to; accumulate == 0: dw is overwritten (saves reading it).  db always accumulates. */
 int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
-                       float* db, int B, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+                       float* db, int B, int H, int W, int Cin, int Cout, int accumulate,
+                       const gct2_adam_args* adam /* or NULL */, void* stream);
 
 /* ---- UpShuffle = Conv2DTranspose(f, 4, 2, 'same', relu)   train.py:145-156 ------------------ */
 /* y[b,2ih+kh-1,2iw+kw-1,o] += x[b,ih,iw,i] * w[kh,kw,o,i]; then bias, relu.
@@ -102,7 +117,7 @@ int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, cons
  * conv4s2_wgrad. */
 int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
                         float* db, int B, int H, int W, int Cin, int Cout, int accumulate,
-                        void* stream);
+                        const gct2_adam_args* adam /* or NULL */, void* stream);
 
 /* ---- Dense(3) head on a rank-4 input   train.py:198-202 ------------------------------------- */
 /* y[m,o] = b[o] + sum_i x[m,i] * w[i,o];  x: [M,Cin] view of `dtype`; w fp32 (Cin,Cout), Cout <= 4;

@@ -42,4 +42,4 @@ print("D0 forward        %7.1f us" % timeit(lambda: L.call("gct2_conv4s2_fwd", 1
       y1.data_ptr() + 2 * 128, 256, B, H, W, 3, 128, 1, s)))
 dz1 = torch.randn(B, H // 2, W // 2, 256, device=dev).to(bf); dw0 = torch.zeros(4, 4, 3, 128, device=dev)
 print("D0 weight grad    %7.1f us" % timeit(lambda: L.call("gct2_conv4s2_wgrad", 1, img.data_ptr(), 4, dz1.data_ptr() + 2 * 128, 256,
-      dw0.data_ptr(), None, B, H, W, 3, 128, 1, s)))
+      dw0.data_ptr(), None, B, H, W, 3, 128, 1, None, s)))

@@ -22,12 +22,12 @@ def run(name, code, iters=20):
     if kind == "conv":
         x = torch.randn(B, H, W, Cin, device=dev).to(bf); dz = torch.randn(B, H // 2, W // 2, Cout, device=dev).to(bf)
         dw = torch.zeros(4, 4, Cin, Cout, device=dev)
-        f = lambda: L.call("gct2_conv4s2_wgrad", 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, s)
+        f = lambda: L.call("gct2_conv4s2_wgrad", 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, s)
         flops = 2.0 * B * (H // 2) * (W // 2) * Cout * 16 * Cin
     else:
         x = torch.randn(B, H, W, Cin, device=dev).to(bf); dz = torch.randn(B, 2 * H, 2 * W, Cout, device=dev).to(bf)
         dw = torch.zeros(4, 4, Cout, Cin, device=dev)
-        f = lambda: L.call("gct2_convT4s2_wgrad", 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, s)
+        f = lambda: L.call("gct2_convT4s2_wgrad", 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, s)
         flops = 2.0 * B * H * W * Cout * 16 * Cin
     for _ in range(3): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gct2.h but not exported"
     # and the ctypes table binds exactly the declared entry points (minus last_error, bound separately)
     assert sorted(set(g._lib.SIGNATURES) | {"gct2_last_error"}) == names
-    assert g._lib.load().gct2_abi_version() == 9
+    assert g._lib.load().gct2_abi_version() == 10
 
 
 def test_argument_validation_needs_no_gpu():

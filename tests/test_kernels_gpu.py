@@ -159,13 +159,13 @@ def test_conv4s2_wgrad(gpu, dt, shape):
     dw = torch.zeros(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)
     db = torch.zeros(Cout, dtype=torch.float32, device=gpu)
     lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(),
-               B, H, W, Cin, Cout, 1, stream())
+               B, H, W, Cin, Cout, 1, None, stream())
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu().numpy(), dw_ref) <= TOL_F32OUT[dt]
     assert rel_l2(db.cpu().numpy(), db_ref) <= TOL_F32OUT[dt]
     # the entry point ACCUMULATES: a second call doubles the result
     lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(),
-               B, H, W, Cin, Cout, 1, stream())
+               B, H, W, Cin, Cout, 1, None, stream())
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu().numpy(), 2 * dw_ref) <= TOL_F32OUT[dt]
 
@@ -185,7 +185,7 @@ def test_wgrad_reduction_modes_agree(gpu, shape):
     for use_ws in (False, True, True):
         lib().call("gct2_set_workspace", ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0)
         dw = torch.ones(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)       # running buffer: the call ACCUMULATES
-        lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, stream())
+        lib().call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, stream())
         torch.cuda.synchronize()
         res.append(dw.cpu().numpy())
     lib().call("gct2_set_workspace", None, 0)
@@ -210,8 +210,8 @@ def test_wgrad_tile_variants(gpu, variant, shape):
         xd, dzd, dztd = dev(x, dt, gpu), dev(dz, dt, gpu), dev(dzt, dt, gpu)
         dw = torch.zeros(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)
         dwt = torch.zeros(4, 4, Cout, Cin, dtype=torch.float32, device=gpu)
-        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, stream())
-        L.call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), Cin, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 1, stream())
+        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, stream())
+        L.call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), Cin, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 1, None, stream())
         torch.cuda.synchronize()
         assert rel_l2(dw.cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
         assert rel_l2(dwt.cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
@@ -232,7 +232,7 @@ def test_convT4s2_wgrad(gpu, dt, shape):
     dw = torch.zeros(4, 4, Cout, Cin, dtype=torch.float32, device=gpu)
     db = torch.zeros(Cout, dtype=torch.float32, device=gpu)
     lib().call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(),
-               B, H, W, Cin, Cout, 1, stream())
+               B, H, W, Cin, Cout, 1, None, stream())
     torch.cuda.synchronize()
     assert rel_l2(dw.cpu().numpy(), dw_ref) <= TOL_F32OUT[dt]
     assert rel_l2(db.cpu().numpy(), db_ref) <= TOL_F32OUT[dt]
@@ -673,10 +673,10 @@ def test_wgrad_overwrite_mode(gpu, dt, shape, use_ws):
         xd[..., :Cin] = dev(x, dt, gpu)
         dzd = dev(dz, dt, gpu)
         dw = torch.full((4, 4, Cin, Cout), 1e6, dtype=torch.float32, device=gpu)          # garbage that must disappear
-        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), ldx, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, stream())
+        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), ldx, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
         torch.cuda.synchronize()
         assert rel_l2(dw.cpu().numpy(), ref) <= TOL_F32OUT[dt]
-        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), ldx, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, stream())
+        L.call("gct2_conv4s2_wgrad", dt, xd.data_ptr(), ldx, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, stream())
         torch.cuda.synchronize()
         assert rel_l2(dw.cpu().numpy(), 2 * ref) <= TOL_F32OUT[dt]
         if Cin != 3:
@@ -684,7 +684,7 @@ def test_wgrad_overwrite_mode(gpu, dt, shape, use_ws):
             reft = O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]
             dztd = dev(dzt, dt, gpu)
             dwt = torch.full((4, 4, Cout, Cin), -3e5, dtype=torch.float32, device=gpu)
-            L.call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), ldx, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 0, stream())
+            L.call("gct2_convT4s2_wgrad", dt, xd.data_ptr(), ldx, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
             torch.cuda.synchronize()
             assert rel_l2(dwt.cpu().numpy(), reft) <= TOL_F32OUT[dt]
     finally:
