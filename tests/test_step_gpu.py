@@ -326,3 +326,30 @@ def test_config3_full_size_properties(gpu):
     losses = [float(eng.train_step(x, t_int, eps)[0]) for _ in range(4)]                    # (d)
     torch.cuda.synchronize()
     assert losses[-1] < losses[0] and all(np.isfinite(losses))
+
+
+def test_fused_adam_equals_separate_adam(gpu):
+    """the optimizer step fused behind the weight-gradient calls (gct2_adam_args: slab gradients consumed in place, no zeroing of
+    kernel gradients, dgrad enqueued before the weight gradient) gives the same parameters, Adam slots and operand copies, bit
+    for bit, as backward + one separate Adam launch - on the reference-width topology so that the slab paths are taken."""
+    import gan_class_transfer2_amd as g
+    topo = g.Topology(128, 512, 4)
+    gen = torch.Generator().manual_seed(8)
+    xs = [(torch.randint(0, 256, (16, 64, 64, 3), generator=gen).float() / 128 - 1).to(gpu) for _ in range(3)]
+    ts = [torch.randint(1, 201, (16,), generator=gen, dtype=torch.int32) for _ in range(3)]
+    es = [torch.randn(16, 64, 64, 3, generator=gen) for _ in range(3)]
+    engines = []
+    for fuse in (False, True):
+        eng = g.UNetEngine(topo, g.BF16, gpu, seed=77)
+        eng.fuse_adam = fuse
+        losses = [float(eng.train_step(x, t, e)[0]) for x, t, e in zip(xs, ts, es)]
+        torch.cuda.synchronize()
+        engines.append((eng, losses))
+    (a, la), (b, lb) = engines
+    assert la == lb and a.iterations == b.iterations == 3
+    lo, hi = a.arena.layer_ranges["D0"]                      # the 3-channel layer's weight gradient adds with fp32 atomics
+    det = torch.ones(a.arena.total, dtype=torch.bool, device=gpu)
+    det[lo:hi] = False
+    for name in ("p", "m", "v", "shadow"):
+        assert torch.equal(getattr(a.arena, name)[det], getattr(b.arena, name)[det]), name
+        assert rel_l2(getattr(a.arena, name)[lo:hi].float().cpu().numpy(), getattr(b.arena, name)[lo:hi].float().cpu().numpy()) <= 1e-5
