@@ -353,3 +353,34 @@ def test_fused_adam_equals_separate_adam(gpu):
     for name in ("p", "m", "v", "shadow"):
         assert torch.equal(getattr(a.arena, name)[det], getattr(b.arena, name)[det]), name
         assert rel_l2(getattr(a.arena, name)[lo:hi].float().cpu().numpy(), getattr(b.arena, name)[lo:hi].float().cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("size,batch", [(64, 3), (192, 2), (128, 5), (256, 1)])
+def test_dispatch_sweep_default_vs_plain_kernels(gpu, size, batch):
+    """shapes the oracle tests do not reach (odd batches, 3 x 64 pixels, 256 pixels): the default dispatch (halo kernel, 256-wide
+    tiles, pipelined weight gradients, split-K rules, 16-byte epilogues, two streams) against the plainest one (128 x 128 tiles
+    everywhere, no halo kernel, one stream).  The two differ only in summation order, so gradients agree to the bf16 noise level
+    of the gradient chain (see test_config3_full_size_properties); an indexing error anywhere would be an O(1) difference."""
+    import gan_class_transfer2_amd as g
+    topo = g.Topology(128, 512, 6)
+    gen = torch.Generator().manual_seed(size + batch)
+    x = (torch.randint(0, 256, (batch, size, size, 3), generator=gen).float() / 128 - 1).to(gpu)
+    t_int = torch.randint(1, 201, (batch,), generator=gen, dtype=torch.int32)
+    eps = torch.randn(batch, size, size, 3, generator=gen)
+    L = g._lib.load()
+    res = []
+    for plain in (False, True):
+        L.gct2_debug_tapgemm_variant((2 | (3 << 16) | (1 << 24)) if plain else 0)
+        try:
+            eng = g.UNetEngine(topo, g.BF16, gpu, seed=5)
+            eng.overlap = not plain
+            loss = eng.train_step(x, t_int, eps, apply=False)
+            torch.cuda.synchronize()
+            res.append((float(loss[0]), eng.arena.g.clone(), eng.arena.layer_ranges))
+        finally:
+            L.gct2_debug_tapgemm_variant(0)
+    (l0, g0, ranges), (l1, g1, _) = res
+    assert np.isfinite(l0) and abs(l0 - l1) <= 2e-3 * abs(l1)
+    assert bool(torch.isfinite(g0).all()) and bool(torch.isfinite(g1).all())
+    errs = {k: rel_l2(g0[a:b].cpu().numpy(), g1[a:b].cpu().numpy()) for k, (a, b) in ranges.items()}
+    assert rel_l2(g0.cpu().numpy(), g1.cpu().numpy()) <= 5e-2 and max(errs.values()) <= 0.15, errs
