@@ -189,7 +189,6 @@ class UNetEngine:
         self._side = torch.cuda.Stream(device=self.device)
         self.wgrad_workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
         self._ensure_workspace()
-        self.adam_merge_elems = 2 << 20    # inline Adam launches cover at least this many parameters
         self.ls_state = None
         if loss_scaling:
             self.ls_state = torch.zeros(4, dtype=torch.int32, device=self.device)  # 16-byte gct2_loss_scale_state
@@ -383,22 +382,12 @@ class UNetEngine:
             call("gct2_dense_bwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), b.dpred.data_ptr(), b.dR[0].data_ptr(),
                  b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), s)
         self._ready("dense")
-        adam_lo = 0                                             # arena prefix [0, adam_lo) already updated
 
         def side_waits_main() -> None:                          # side stream: everything enqueued on main so far is visible
             if side is not main:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
-
-        def adam_upto(layer: Optional[str], force: bool = False) -> None:
-            nonlocal adam_lo
-            if not adam_inline:
-                return
-            hi = A.total if layer is None else A.layer_ranges[layer][1]
-            if hi > adam_lo and (force or hi - adam_lo >= self.adam_merge_elems):
-                self.apply_adam(adam_lo, hi, stream=sw)
-                adam_lo = hi
 
         # adam_inline: every layer's Keras-Adam step is fused behind its weight-gradient call (gct2_adam_args): the gradient of
         # the kernel is consumed from the launch's partial sums or from the arena without ever being zeroed.  The update writes
@@ -417,7 +406,7 @@ class UNetEngine:
         keep: list = []
         if adam_inline:
             side_waits_main()                                   # the head (and its gradients) are done
-            adam_upto("dense", force=True)                      # the head's parameters: nothing reads them any more
+            self.apply_adam(0, A.layer_ranges["dense"][1], stream=sw)   # the head's parameters: nothing reads them any more
         for i in range(n):                                      # UpShuffle_i backward, outermost first
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
