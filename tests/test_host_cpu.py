@@ -127,3 +127,15 @@ def test_bench_flop_model_matches_survey_appendix_b():
     assert abs(bench.f_train_per_image(t, 128, 128) / 1e9 - 32.1314) < 1e-3
     assert abs(bench.f_train_per_image(t, 64, 64) / 1e9 - 8.0328) < 1e-3
     assert abs(bench.f_train_per_image(g.Topology(128, 512, 5), 32, 32) / 1e9 - 1.9705) < 1e-3
+
+
+def test_lds_swizzles_are_conflict_free_in_the_bank_model():
+    """scripts/lds_swizzle_search.py: the three LDS image layouts of csrc/ against the ds_read_b128 lane-group model of
+    MI355X_MICROARCH.md (the asserts inside main() are the check)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "lds_swizzle_search.py")
+    spec = importlib.util.spec_from_file_location("lds_swizzle_search", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()
