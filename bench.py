@@ -176,10 +176,10 @@ def main():
     from gan_class_transfer2_amd.distributed import DataParallelStep
 
     dtype = {"bf16": g.BF16, "f16": g.F16, "f32": g.F32}[args.dtype]
-    if args.variant:
-        _lib.load().gct2_debug_tapgemm_variant(args.variant)
     topo = g.Topology(128, 512, 6)                      # reference defaults, train.py:18-21
     eng = g.UNetEngine(topo, dtype, dev, rng_seed=rank, loss_scaling=(args.dtype == "f16"))
+    if args.variant:
+        eng.ctx.set_tuning(args.variant)
     eng.overlap = not args.serial_streams
     dp = DataParallelStep(eng)
     dp.broadcast_parameters(0)

@@ -20,7 +20,9 @@ class Gct2Error(RuntimeError):
 
 
 class LossScaleState(C.Structure):
-    _fields_ = [("scale", C.c_float), ("inv_scale", C.c_float), ("good_steps", C.c_int32), ("found_inf", C.c_int32)]
+    """gct2_loss_scale_state (32 bytes): dynamic loss scale + the optimizer step counter it gates."""
+    _fields_ = [("scale", C.c_float), ("inv_scale", C.c_float), ("good_steps", C.c_int32), ("found_inf", C.c_int32),
+                ("applied_steps", C.c_int32), ("alpha", C.c_float), ("reserved", C.c_int32 * 2)]
 
 
 class AdamArgs(C.Structure):
@@ -36,32 +38,34 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 SIGNATURES = {
     "gct2_abi_version": [],
     "gct2_device_check": [],
-    "gct2_debug_force_direct": [_i],
+    "gct2_ctx_create": [C.POINTER(C.c_void_p)],
+    "gct2_ctx_destroy": [_vp],
+    "gct2_ctx_set_workspace": [_vp, _vp, _sz],
+    "gct2_ctx_set_wgrad_workspace": [_vp, _vp, _sz],
+    "gct2_ctx_set_tuning": [_vp, _i],
+    "gct2_ctx_force_direct": [_vp, _i],
     "gct2_diffusion_mix": [_i, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _sz, _i, _vp],
     "gct2_diffusion_update": [_vp, _vp, _f, _vp, _vp, _sz, _vp],
     "gct2_noise_edits": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "gct2_image_prepare": [_vp, _vp, _vp, _vp, _i, _i, _vp],
-    "gct2_set_workspace": [_vp, _sz],
-    "gct2_set_wgrad_workspace": [_vp, _sz],
-    "gct2_debug_tapgemm_variant": [_i],
-    "gct2_conv4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "gct2_conv4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
-    "gct2_conv4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "gct2_convT4s2_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "gct2_convT4s2_dgrad": [_i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
-    "gct2_convT4s2_wgrad": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "gct2_conv4s2_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_conv4s2_dgrad": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp],
+    "gct2_conv4s2_wgrad": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "gct2_convT4s2_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_convT4s2_dgrad": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp],
+    "gct2_convT4s2_wgrad": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "gct2_dense_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "gct2_dense_bwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
-    "gct2_dense_head_train": [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "gct2_dense_bwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gct2_dense_head_train": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
     "gct2_rng_uniform_int": [_u64, _u64, _u64, _vp, _sz, _i, _i, _vp],
     "gct2_rng_normal": [_u64, _u64, _u64, _vp, _sz, _vp],
     "gct2_noise_image": [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "gct2_noise_image_rng": [_i, _vp, _vp, _u64, _u64, _u64, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "gct2_mse_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
-    "gct2_adam_keras_multi": [_vp, _vp, _vp, _vp, _vp, _i, _sz, _f, _f, _f, _f, _f, _vp, _vp, _i, _vp],
+    "gct2_adam_keras_multi": [_vp, _vp, _vp, _vp, _vp, _i, _sz, _f, _f, _f, _f, _f, _vp, _i, _vp],
     "gct2_cast_from_f32": [_i, _vp, _vp, _sz, _vp],
     "gct2_loss_scale_init": [_vp, _f, _vp],
-    "gct2_loss_scale_begin": [_vp, _vp],
+    "gct2_loss_scale_begin": [_vp, _f, _i, _f, _f, _vp],
     "gct2_scale_check_finite": [_vp, _sz, _vp, _vp],
     "gct2_loss_scale_update": [_vp, _i, _vp],
 }
@@ -82,7 +86,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = None if name.startswith("gct2_debug_") else _i
+        fn.restype = _i
     lib.gct2_last_error.argtypes = []
     lib.gct2_last_error.restype = C.c_char_p
     _lib = lib
@@ -97,3 +101,39 @@ def check(rc: int, what: str = "") -> None:
 
 def call(name: str, *args) -> None:
     check(getattr(load(), name)(*args), name)
+
+
+class Context:
+    """gct2_ctx (include/gct2.h): the caller-owned scratch and tile-selection knobs that the convolution / head entry points
+    take as their first argument.  The device tensors stay owned by whoever passes them in (kept alive here by reference);
+    two Context objects never share anything, so two engines / threads / streams are independent."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        call("gct2_ctx_create", C.byref(h))
+        self.handle = h.value
+        self._keep = [None, None]
+
+    def set_workspace(self, tensor) -> None:
+        self._keep[0] = tensor
+        call("gct2_ctx_set_workspace", self.handle, tensor.data_ptr() if tensor is not None else None,
+             tensor.numel() * tensor.element_size() if tensor is not None else 0)
+
+    def set_wgrad_workspace(self, tensor) -> None:
+        self._keep[1] = tensor
+        call("gct2_ctx_set_wgrad_workspace", self.handle, tensor.data_ptr() if tensor is not None else None,
+             tensor.numel() * tensor.element_size() if tensor is not None else 0)
+
+    def set_tuning(self, v: int) -> None:
+        call("gct2_ctx_set_tuning", self.handle, int(v))
+
+    def force_direct(self, on: bool) -> None:
+        call("gct2_ctx_force_direct", self.handle, int(bool(on)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and _lib is not None:
+                _lib.gct2_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:       # interpreter shutdown
+            pass

@@ -6,13 +6,10 @@
 
 // implemented in the kernel translation units
 bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p);
-int tapgemm_mfma(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
+int tapgemm_mfma(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
 int tapgemm_direct(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
-void tapgemm_set_variant(int v);
-void wgrad_set_variant(int v);
-void halo_set_mode(int m);
 bool wgrad_mfma_supported(int dtype, const WgradParams& p);
-int wgrad_mfma(int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer);
+int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer);
 int wgrad_direct(int dtype, const WgradParams& p, hipStream_t s);
 bool rgb_fwd_supported(int dtype, const TapGemmParams& p);
 int rgb_fwd(int dtype, const TapGemmParams& p, hipStream_t s);
@@ -23,38 +20,26 @@ int pw_rng_normal(uint64_t, uint64_t, uint64_t, float*, size_t, hipStream_t);
 int pw_noise(int, const float*, const int32_t*, const float*, void*, int, void*, int, int, int, int, int, hipStream_t);
 int pw_noise_rng(int, const float*, const int32_t*, uint64_t, uint64_t, uint64_t, float*, void*, int, void*, int, int, int, int, int, hipStream_t);
 int pw_dense_fwd(int, const void*, int, const float*, const float*, float*, int, int, int, hipStream_t);
-int pw_dense_bwd(int, const void*, int, const float*, const float*, void*, int, float*, float*, int, int, int, int, hipStream_t);
+int pw_dense_bwd(int, const void*, int, const float*, const float*, void*, int, float*, float*, int, int, int, int, int, hipStream_t);
 int pw_mse(const float*, const float*, float*, float*, float*, size_t, const float*, hipStream_t);
-int pw_dense_head_train(int, const void*, int, const float*, const float*, const float*, float*, void*, int, float*, float*, float*, float*,
-                        int, int, int, int, const float*, float*, const void*, int, hipStream_t);
+int pw_dense_head_train(const gct2_ctx&, int, const void*, int, const float*, const float*, const float*, float*, void*, int, float*, float*,
+                        float*, float*, int, int, int, int, const float*, float*, const void*, int, int, hipStream_t);
 int pw_colsum(int, const void*, int, float*, size_t, int, float, hipStream_t);
 int pw_diffusion_mix(int, const float*, const float*, float, float*, void*, int, void*, int, size_t, int, hipStream_t);
 int pw_diffusion_update(const float*, const float*, float, float*, float*, size_t, hipStream_t);
 int pw_noise_edits(const float*, const float*, int, float*, int, int, int, hipStream_t);
 int pw_image_prepare(const uint8_t*, const int64_t*, const int32_t*, float*, int, int, hipStream_t);
-int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const float*, const int32_t*, int, hipStream_t,
-            const float* slabs = nullptr, int nslab = 0, size_t slab_stride = 0, size_t n_slab = 0, size_t zero_from = 0);
+int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const gct2_loss_scale_state*, int, hipStream_t,
+            const float* slabs = nullptr, int nslab = 0, size_t slab_stride = 0, size_t n_slab = 0);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
 int pw_ls_init(gct2_loss_scale_state*, float, hipStream_t);
-int pw_ls_begin(gct2_loss_scale_state*, hipStream_t);
+int pw_ls_begin(gct2_loss_scale_state*, float, int, float, float, hipStream_t);
 int pw_ls_check(const float*, size_t, gct2_loss_scale_state*, hipStream_t);
 int pw_ls_update(gct2_loss_scale_state*, int, hipStream_t);
 
+// the only static storage of the library: the per-thread text of the last error, and an immutable default context for ctx = NULL
 static thread_local char g_err[512] = "";
-static int g_force_direct = 0;   // test hook: route every conv through the direct kernels
-static float* g_ws = nullptr;    // caller-owned split-K scratch (gct2_set_workspace)
-static size_t g_ws_bytes = 0;
-static float* g_wws = nullptr;   // optional second scratch for the weight-gradient kernels (gct2_set_wgrad_workspace)
-static size_t g_wws_bytes = 0;
-
-float* gct2_workspace(size_t* bytes) {
-  *bytes = g_ws_bytes;
-  return g_ws;
-}
-float* gct2_wgrad_workspace(size_t* bytes) {
-  if (g_wws) { *bytes = g_wws_bytes; return g_wws; }
-  return gct2_workspace(bytes);
-}
+static const gct2_ctx g_default_ctx{};
 
 int gct2_fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -81,19 +66,20 @@ int check_conv_args(const char* fn, int dtype, const void* a, const void* b, con
   if ((size_t)B * H * W * 4 >= ((size_t)1 << 31)) return gct2_fail(GCT2_EINVAL, "%s: B*H*W too large for 32-bit pixel indices", fn);
   return GCT2_OK;
 }
-int run_tapgemm(int dtype, int form, int epi, const TapGemmParams& p, void* stream) {
-  if (!g_force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(dtype, form, epi, p, S(stream));
+inline const gct2_ctx& C(const gct2_ctx* c) { return c ? *c : g_default_ctx; }
+int run_tapgemm(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, void* stream) {
+  if (!c.force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(c, dtype, form, epi, p, S(stream));
   return tapgemm_direct(dtype, form, epi, p, S(stream));
 }
 // input-gradient launch with optional fused bias gradient: db (+)= column sums of the masked gradient THIS call produces
 // (channels [0, split) -> db, the rest -> db2).  MFMA path: fused into the epilogue / split-K finalize.  Direct path:
 // column sums of the output view after the launch, minus those before it when the launch accumulates.
-int run_dgrad(int dtype, int form, TapGemmParams p, size_t out_pixels, float* db, int split, float* db2, void* stream) {
+int run_dgrad(const gct2_ctx& c, int dtype, int form, TapGemmParams p, size_t out_pixels, float* db, int split, float* db2, int db_acc,
+              void* stream) {
   if (split < 0 || split > p.N) return gct2_fail(GCT2_EINVAL, "dgrad: db_split out of range");
-  if (!g_force_direct && tapgemm_mfma_supported(dtype, p)) {
-    p.db = db; p.db_split = split; p.db2 = db2;
-    return tapgemm_mfma(dtype, form, EPI_MASK, p, S(stream));
-  }
+  p.db = db; p.db_split = split; p.db2 = db2; p.db_acc = db_acc;
+  if (!c.force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(c, dtype, form, EPI_MASK, p, S(stream));
+  zero_overwritten_db(p, S(stream));        // the column-sum kernels below add with atomics
   const size_t es = esize(dtype);
   auto sums = [&](float sign) -> int {
     if (db && split > 0) if (int e = pw_colsum(dtype, p.y, p.ldy, db, out_pixels, split, sign, S(stream))) return e;
@@ -105,42 +91,70 @@ int run_dgrad(int dtype, int form, TapGemmParams p, size_t out_pixels, float* db
   if (int e = tapgemm_direct(dtype, form, EPI_MASK, p, S(stream))) return e;
   return (db || db2) ? sums(1.f) : GCT2_OK;
 }
-int run_wgrad(int dtype, const WgradParams& p, void* stream, WgradSlabs* defer = nullptr) {
+int run_wgrad(const gct2_ctx& c, int dtype, const WgradParams& p, void* stream, WgradSlabs* defer = nullptr) {
   if (defer) *defer = WgradSlabs{nullptr, 0, 0};
-  if (!g_force_direct && wgrad_mfma_supported(dtype, p)) return wgrad_mfma(dtype, p, S(stream), defer);
+  if (!c.force_direct && wgrad_mfma_supported(dtype, p)) return wgrad_mfma(c, dtype, p, S(stream), defer);
   return wgrad_direct(dtype, p, S(stream));
+}
+// bias gradient of a weight-gradient call: db (+)= column sums of dz (atomics: an overwritten target starts from zero)
+int wgrad_db(int dtype, const void* dz, int lddz, float* db, size_t pixels, int Cout, int accumulate, void* stream) {
+  if (!accumulate) (void)hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), S(stream));
+  return pw_colsum(dtype, dz, lddz, db, pixels, Cout, 1.f, S(stream));
 }
 // Keras Adam right behind a weight-gradient launch, on the same stream (gct2_adam_args): the layer's parameters [weights | pad |
 // bias] are one contiguous range of the caller's arenas; the weight gradient comes from the slabs the launch left (never
-// materialised) or from dw (written, not accumulated: no zeroing), the bias gradient from g (accumulated elsewhere: zeroed here)
+// materialised) or from dw (written, not accumulated: no zeroing), the bias gradient from g (written by the dgrad launches); nothing is zeroed
 int adam_after_wgrad(const gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& sl, void* stream) {
   if (!a->p || !a->m || !a->v) return gct2_fail(GCT2_EINVAL, "wgrad + adam: null arena pointers");
   if (a->n < nw || ((uintptr_t)a->p | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)dw) % 16)
     return gct2_fail(GCT2_EINVAL, "wgrad + adam: range shorter than the weight tensor or misaligned");
-  const size_t nw4 = (nw + 3) & ~(size_t)3;
-  return pw_adam(a->p, a->m, a->v, dw, a->shadow, a->shadow_dtype, a->n, a->alpha, a->beta1, a->beta2, a->eps, a->grad_mul, nullptr, nullptr,
-                 1, S(stream), sl.base, sl.nslab, sl.stride, sl.nslab ? nw : 0, nw4);
+  return pw_adam(a->p, a->m, a->v, dw, a->shadow, a->shadow_dtype, a->n, a->alpha, a->beta1, a->beta2, a->eps, a->grad_mul, nullptr, 0,
+                 S(stream), sl.base, sl.nslab, sl.stride, sl.nslab ? nw : 0);
 }
 }  // namespace
 
 extern "C" {
 
-int gct2_abi_version(void) { return 10; }
+int gct2_abi_version(void) { return 11; }
 const char* gct2_last_error(void) { return g_err; }
-void gct2_debug_force_direct(int on) { g_force_direct = on; }
-void gct2_debug_tapgemm_variant(int v) { tapgemm_set_variant(v & 0xffff); wgrad_set_variant((v >> 16) & 0xff); halo_set_mode((v >> 24) & 3); }
 
-int gct2_set_workspace(void* ws, size_t bytes) {
-  if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "set_workspace: pointer must be 16-byte aligned");
-  g_ws = ws ? reinterpret_cast<float*>(ws) : nullptr;
-  g_ws_bytes = ws ? bytes : 0;
+int gct2_ctx_create(gct2_ctx** ctx) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_create: null output pointer");
+  *ctx = new (std::nothrow) gct2_ctx();
+  return *ctx ? GCT2_OK : gct2_fail(GCT2_EINVAL, "ctx_create: out of host memory");
+}
+int gct2_ctx_destroy(gct2_ctx* ctx) {
+  delete ctx;
   return GCT2_OK;
 }
-
-int gct2_set_wgrad_workspace(void* ws, size_t bytes) {
-  if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "set_wgrad_workspace: pointer must be 16-byte aligned");
-  g_wws = ws ? reinterpret_cast<float*>(ws) : nullptr;
-  g_wws_bytes = ws ? bytes : 0;
+int gct2_ctx_set_workspace(gct2_ctx* ctx, void* ws, size_t bytes) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_workspace: null ctx");
+  if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "ctx_set_workspace: pointer must be 16-byte aligned");
+  ctx->ws = ws ? reinterpret_cast<float*>(ws) : nullptr;
+  ctx->ws_bytes = ws ? bytes : 0;
+  return GCT2_OK;
+}
+int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_wgrad_workspace: null ctx");
+  if (ws && ((uintptr_t)ws % 16)) return gct2_fail(GCT2_EINVAL, "ctx_set_wgrad_workspace: pointer must be 16-byte aligned");
+  ctx->wws = ws ? reinterpret_cast<float*>(ws) : nullptr;
+  ctx->wws_bytes = ws ? bytes : 0;
+  return GCT2_OK;
+}
+int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_tuning: null ctx");
+  ctx->tap_variant = v & 0xff;
+  const int wv = (v >> 16) & 0xff;
+  ctx->wgrad_variant = wv & 0xf;
+  ctx->wgrad_pipe = (wv & 0x40) ? 0 : 1;
+  ctx->wgrad_target = (wv & 0x10) ? 512 : 256;
+  ctx->wgrad_slab_max = (wv & 0x20) ? 64 : 24;
+  ctx->halo_mode = (v >> 24) & 3;
+  return GCT2_OK;
+}
+int gct2_ctx_force_direct(gct2_ctx* ctx, int on) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_force_direct: null ctx");
+  ctx->force_direct = on ? 1 : 0;
   return GCT2_OK;
 }
 
@@ -153,27 +167,29 @@ int gct2_device_check(void) {
   return GCT2_OK;
 }
 
-int gct2_conv4s2_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
+int gct2_conv4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
                      int Cin, int Cout, int relu, void* stream) {
+  const gct2_ctx& c = C(ctx);
   if (int e = check_conv_args("conv4s2_fwd", dtype, x, w, y, B, H, W, Cin, Cout)) return e;
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: H=%d W=%d must be even (skip concat, train.py:114-119)", H, W);
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: ld smaller than channel count");
   TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H / 2, W / 2, Cin, Cout, relu, 0};
-  if (!g_force_direct && rgb_fwd_supported(dtype, p)) return rgb_fwd(dtype, p, S(stream));   // image layer (Cin <= 4)
-  return run_tapgemm(dtype, FORM_CONV, EPI_BIAS_ACT, p, stream);
+  if (!c.force_direct && rgb_fwd_supported(dtype, p)) return rgb_fwd(dtype, p, S(stream));   // image layer (Cin <= 4)
+  return run_tapgemm(c, dtype, FORM_CONV, EPI_BIAS_ACT, p, stream);
 }
 
-int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
-                       int H, int W, int Cin, int Cout, int accumulate, float* db, int db_split, float* db2, void* stream) {
+int gct2_conv4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
+                       int H, int W, int Cin, int Cout, int accumulate, float* db, int db_split, float* db2, int db_accumulate, void* stream) {
   if (int e = check_conv_args("conv4s2_dgrad", dtype, dz, w, dx, B, H, W, Cin, Cout)) return e;
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: H=%d W=%d must be even", H, W);
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: ld smaller than channel count");
   TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H / 2, W / 2, Cout, Cin, 0, accumulate};
-  return run_dgrad(dtype, FORM_CONVT, p, (size_t)B * H * W, db, db_split, db2, stream);
+  return run_dgrad(C(ctx), dtype, FORM_CONVT, p, (size_t)B * H * W, db, db_split, db2, db_accumulate, stream);
 }
 
-int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
+int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
                        int Cin, int Cout, int accumulate, const gct2_adam_args* adam, void* stream) {
+  const gct2_ctx& c = C(ctx);
   if (int e = check_conv_args("conv4s2_wgrad", dtype, x, dz, dw, B, H, W, Cin, Cout)) return e;
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: H=%d W=%d must be even", H, W);
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: ld smaller than channel count");
@@ -181,32 +197,32 @@ int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int ld
   WgradParams p{x, ldx, dz, lddz, dw, B, H / 2, W / 2, Cin, Cout, 1};
   p.accumulate = accumulate ? 1 : 0;
   WgradSlabs sl{nullptr, 0, 0};
-  if (!g_force_direct && rgb_wgrad_supported(dtype, p)) {
+  if (!c.force_direct && rgb_wgrad_supported(dtype, p)) {
     if (int e = rgb_wgrad(dtype, p, S(stream))) return e;
-  } else if (int e = run_wgrad(dtype, p, stream, adam ? &sl : nullptr)) return e;
+  } else if (int e = run_wgrad(c, dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)
-    if (int e = pw_colsum(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, 1.f, S(stream))) return e;
+    if (int e = wgrad_db(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, accumulate, stream)) return e;
   if (adam) return adam_after_wgrad(adam, dw, (size_t)16 * Cin * Cout, sl, stream);
   return GCT2_OK;
 }
 
-int gct2_convT4s2_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
+int gct2_convT4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
                       int Cin, int Cout, int relu, void* stream) {
   if (int e = check_conv_args("convT4s2_fwd", dtype, x, w, y, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_fwd: ld smaller than channel count");
   TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H, W, Cin, Cout, relu, 0};
-  return run_tapgemm(dtype, FORM_CONVT, EPI_BIAS_ACT, p, stream);
+  return run_tapgemm(C(ctx), dtype, FORM_CONVT, EPI_BIAS_ACT, p, stream);
 }
 
-int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
-                        int H, int W, int Cin, int Cout, int accumulate, float* db, int db_split, float* db2, void* stream) {
+int gct2_convT4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
+                        int H, int W, int Cin, int Cout, int accumulate, float* db, int db_split, float* db2, int db_accumulate, void* stream) {
   if (int e = check_conv_args("convT4s2_dgrad", dtype, dz, w, dx, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "convT4s2_dgrad: ld smaller than channel count");
   TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H, W, Cout, Cin, 0, accumulate};
-  return run_dgrad(dtype, FORM_CONV, p, (size_t)B * H * W, db, db_split, db2, stream);
+  return run_dgrad(C(ctx), dtype, FORM_CONV, p, (size_t)B * H * W, db, db_split, db2, db_accumulate, stream);
 }
 
-int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
+int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
                         int Cin, int Cout, int accumulate, const gct2_adam_args* adam, void* stream) {
   if (int e = check_conv_args("convT4s2_wgrad", dtype, x, dz, dw, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: ld smaller than channel count");
@@ -214,9 +230,9 @@ int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int l
   WgradParams p{dz, lddz, x, ldx, dw, B, H, W, Cout, Cin, 1};
   p.accumulate = accumulate ? 1 : 0;
   WgradSlabs sl{nullptr, 0, 0};
-  if (int e = run_wgrad(dtype, p, stream, adam ? &sl : nullptr)) return e;
+  if (int e = run_wgrad(C(ctx), dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)
-    if (int e = pw_colsum(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, 1.f, S(stream))) return e;
+    if (int e = wgrad_db(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, accumulate, stream)) return e;
   if (adam) return adam_after_wgrad(adam, dw, (size_t)16 * Cin * Cout, sl, stream);
   return GCT2_OK;
 }
@@ -228,19 +244,19 @@ int gct2_dense_fwd(int dtype, const void* x, int ldx, const float* w, const floa
 }
 
 int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float* dy, void* dx, int lddx, float* dw, float* db, int M,
-                   int Cin, int Cout, int Cmask, void* stream) {
+                   int Cin, int Cout, int Cmask, int accumulate, void* stream) {
   if (!dtype_ok(dtype) || !x || !w || !dy || !dx || !dw) return gct2_fail(GCT2_EINVAL, "dense_bwd: bad dtype or null pointer");
   if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout > 4 || ldx < Cin || Cmask < 0 || Cmask > Cin || lddx < Cmask)
     return gct2_fail(GCT2_EINVAL, "dense_bwd: bad shape");
   if ((Cin + 1) * Cout > 256) return gct2_fail(GCT2_EINVAL, "dense_bwd: (Cin+1)*Cout = %d exceeds 256", (Cin + 1) * Cout);
   if ((size_t)Cin * 16 + 128 * 16 + (size_t)128 * Cin * esize(dtype) > 160 * 1024)
     return gct2_fail(GCT2_EINVAL, "dense_bwd: Cin=%d too large for the LDS tile", Cin);
-  return pw_dense_bwd(dtype, x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, S(stream));
+  return pw_dense_bwd(dtype, x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, accumulate, S(stream));
 }
 
-int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, const float* b, const float* target, float* pred, void* dx,
-                          int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
-                          const float* loss_scale_ptr, float* db_dx, const void* x2, int ldx2, void* stream) {
+int gct2_dense_head_train(gct2_ctx* ctx, int dtype, const void* x, int ldx, const float* w, const float* b, const float* target, float* pred,
+                          void* dx, int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
+                          const float* loss_scale_ptr, float* db_dx, const void* x2, int ldx2, int accumulate, void* stream) {
   if ((dtype != GCT2_BF16 && dtype != GCT2_F16) || !x || !w || !target || !dx || !dw || !loss || !partials)
     return gct2_fail(GCT2_EINVAL, "dense_head_train: 16-bit dtypes only / null pointer (use dense_fwd + mse_fwd_bwd + dense_bwd)");
   if (x2 && (ldx2 < Cin - Cmask || ldx2 % 4 || (uintptr_t)x2 % 8 || Cin - Cmask > 4))
@@ -251,8 +267,8 @@ int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, con
   if ((uintptr_t)x % 16 || (uintptr_t)dx % 16) return gct2_fail(GCT2_EINVAL, "dense_head_train: views must be 16-byte aligned");
   if ((size_t)256 * ldx * 2 + (size_t)256 * Cmask * 2 + 256 * 16 + (size_t)ldx * 16 > 160 * 1024)
     return gct2_fail(GCT2_EINVAL, "dense_head_train: ldx=%d too large for the LDS tile", ldx);
-  return pw_dense_head_train(dtype, x, ldx, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, loss_scale_ptr,
-                             db_dx, x2, ldx2, S(stream));
+  return pw_dense_head_train(C(ctx), dtype, x, ldx, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, loss_scale_ptr,
+                             db_dx, x2, ldx2, accumulate, S(stream));
 }
 
 int gct2_rng_uniform_int(uint64_t seed, uint64_t stream_id, uint64_t offset, int32_t* out, size_t n, int lo, int hi, void* stream) {
@@ -312,13 +328,12 @@ int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float
 }
 
 int gct2_adam_keras_multi(float* p, float* m, float* v, float* g, void* shadow, int shadow_dtype, size_t n, float alpha, float beta1,
-                          float beta2, float eps, float grad_mul, const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad,
-                          void* stream) {
+                          float beta2, float eps, float grad_mul, const gct2_loss_scale_state* ls, int zero_grad, void* stream) {
   if (!p || !m || !v || !g) return gct2_fail(GCT2_EINVAL, "adam_keras_multi: null pointer");
   if (shadow && !dtype_ok(shadow_dtype)) return gct2_fail(GCT2_EINVAL, "adam_keras_multi: bad shadow dtype");
   if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) % 16 || (shadow && (uintptr_t)shadow % 8))
     return gct2_fail(GCT2_EINVAL, "adam_keras_multi: arenas must be 16-byte aligned");
-  return pw_adam(p, m, v, g, shadow, shadow_dtype, n, alpha, beta1, beta2, eps, grad_mul, inv_scale_ptr, found_inf, zero_grad, S(stream));
+  return pw_adam(p, m, v, g, shadow, shadow_dtype, n, alpha, beta1, beta2, eps, grad_mul, ls, zero_grad, S(stream));
 }
 
 int gct2_cast_from_f32(int dtype, const float* src, void* dst, size_t n, void* stream) {
@@ -330,9 +345,9 @@ int gct2_loss_scale_init(gct2_loss_scale_state* st, float initial_scale, void* s
   if (!st || !(initial_scale > 0.f)) return gct2_fail(GCT2_EINVAL, "loss_scale_init: null state or non-positive scale");
   return pw_ls_init(st, initial_scale, S(stream));
 }
-int gct2_loss_scale_begin(gct2_loss_scale_state* st, void* stream) {
-  if (!st) return gct2_fail(GCT2_EINVAL, "loss_scale_begin: null state");
-  return pw_ls_begin(st, S(stream));
+int gct2_loss_scale_begin(gct2_loss_scale_state* st, float base_lr, int warmup_steps, float beta1, float beta2, void* stream) {
+  if (!st || warmup_steps < 0) return gct2_fail(GCT2_EINVAL, "loss_scale_begin: null state or negative warm-up");
+  return pw_ls_begin(st, base_lr, warmup_steps, beta1, beta2, S(stream));
 }
 int gct2_scale_check_finite(const float* g, size_t n, gct2_loss_scale_state* st, void* stream) {
   if (!g || !st) return gct2_fail(GCT2_EINVAL, "scale_check_finite: null pointer");

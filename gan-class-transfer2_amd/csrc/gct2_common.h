@@ -17,6 +17,20 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 int gct2_fail(int code, const char* fmt, ...);
 int gct2_check_launch(const char* what);
 
+// the call context of include/gct2.h: caller-owned scratch + tile-selection knobs.  Host memory, read-only during a call.
+struct gct2_ctx {
+  float* ws = nullptr; size_t ws_bytes = 0;        // split-K slabs, partial rows (forward / input-gradient / head calls)
+  float* wws = nullptr; size_t wws_bytes = 0;      // weight-gradient slabs (falls back to ws)
+  int tap_variant = 0;                             // forward / input-gradient tile (0 = automatic)
+  int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 24;
+  int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
+  int force_direct = 0;
+  float* wgrad_scratch(size_t* bytes) const {
+    if (wws) { *bytes = wws_bytes; return wws; }
+    *bytes = ws_bytes; return ws;
+  }
+};
+
 template <typename T> struct is16 { static constexpr bool value = sizeof(T) == 2; };
 
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
@@ -107,9 +121,9 @@ struct TapGemmParams {
   int relu, accumulate;
   float* ws; int ksplit;         // split-K: fp32 partial slabs [ksplit][out pixels][N] in the registered workspace
   int m_tiles, n_tiles, xcd_chunk;   // launch geometry (filled by the launcher): see xcd_tile()
-  int ablate;                        // timing-only ablation bits (gct2_debug_tapgemm_variant >> 8)
   int wide;                          // output / mask views allow 16-byte accesses (filled by the launcher)
   float* db; int db_split; float* db2;   // EPI_MASK: bias-gradient targets (column sums of the masked result), may be null
+  int db_acc;                            // bit 0: db is added to (else overwritten); bit 1: the same for db2
   float* dbws;                           // partial bias-gradient rows [m_tiles*phases | finalize rows][N] in the workspace, or null (atomics)
 };
 
@@ -125,10 +139,11 @@ __device__ __forceinline__ bool xcd_tile(int id, int m_tiles, int inner, int chu
   return (j / inner) < chunk && m_tile < m_tiles;
 }
 
-// caller-registered scratch (gct2_set_workspace); null when absent
-float* gct2_workspace(size_t* bytes);
-// scratch of the weight-gradient kernels: gct2_set_wgrad_workspace's if registered, else the one above
-float* gct2_wgrad_workspace(size_t* bytes);
+// the atomic fall-backs of the fused bias gradients add into their targets: overwritten targets start from zero
+inline void zero_overwritten_db(const TapGemmParams& p, hipStream_t s) {
+  if (p.db && !(p.db_acc & 1) && p.db_split > 0) (void)hipMemsetAsync(p.db, 0, (size_t)p.db_split * sizeof(float), s);
+  if (p.db2 && !(p.db_acc & 2) && p.N > p.db_split) (void)hipMemsetAsync(p.db2, 0, (size_t)(p.N - p.db_split) * sizeof(float), s);
+}
 
 // wgrad: dw[tap][cb][cs] += sum_r big[pix_big(r,tap)][cb] * small[r][cs], r over the SMALL grid.
 struct WgradParams {
@@ -137,7 +152,6 @@ struct WgradParams {
   float* dw;                      // fp32 [16][Cb][Cs]
   int B, Hs, Ws, Cb, Cs;
   int rsplit;                     // number of r-range splits
-  int ablate;                     // timing-only ablation bits
   float* ws;                      // partial-tile slabs [rsplit][16*Cb][Cs] in the registered workspace, or null (atomics)
   int accumulate;                 // 1: dw += result (caller keeps a running / pre-zeroed gradient); 0: dw = result
 };

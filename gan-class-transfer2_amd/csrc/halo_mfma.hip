@@ -22,7 +22,6 @@ namespace {
 
 constexpr unsigned OOB = 0x80000000u;
 typedef __attribute__((address_space(3))) void lds_void_t;
-int g_halo_mode = 0;                 // 0 = automatic, 1 = never, 2 = whenever the shape allows (tests / A-B timing)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)OOB, 0x00020000);
@@ -268,13 +267,12 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 
 }  // namespace
 
-void halo_set_mode(int m) { g_halo_mode = m; }
-
 int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, hipStream_t s);   // tapgemm_mfma.hip
 
 // the halo kernel takes FORM_CONVT problems whose SMALL grid tiles into 16 x 16 patches: the Conv2DTranspose forward
 // (bias + ReLU) and the Conv2D input gradient (mask / accumulate / fused bias gradient)
-bool halo_convT_wanted(int epi, const TapGemmParams& p) {
+bool halo_convT_wanted(const gct2_ctx& c, int epi, const TapGemmParams& p) {
+  const int g_halo_mode = c.halo_mode;
   if (g_halo_mode == 1) return false;
   if ((p.Hs & 15) || (p.Ws & 15)) return false;
   // 16-byte epilogue accesses: output (and mask) views aligned to 16 bytes with pixel strides that are multiples of 8 elements
@@ -285,17 +283,18 @@ bool halo_convT_wanted(int epi, const TapGemmParams& p) {
   return p.N <= 256 && tiles >= 256;          // measured vs tapgemm: U0 fwd 177 -> 136 us, U1 fwd 126 -> 120, U2 fwd 124 -> 122, D1 dgrad 88 -> 81, D2 dgrad 70 -> 66
 }
 
-int halo_convT(int dtype, int epi, TapGemmParams p, hipStream_t s) {
+int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) {
   p.m_tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4);
   p.n_tiles = (p.N + 63) / 64;
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   p.ksplit = 1;
   p.dbws = nullptr;
   if (epi == EPI_MASK && (p.db || p.db2)) {      // partial bias-gradient rows at the tail of the workspace, one per work-group row
-    size_t ws_bytes = 0;
-    float* ws = gct2_workspace(&ws_bytes);
+    const size_t ws_bytes = c.ws_bytes;
+    float* ws = c.ws;
     const size_t need = (size_t)p.m_tiles * p.N * sizeof(float);
     if (ws && ws_bytes >= need + 16) p.dbws = ws + (ws_bytes - need) / sizeof(float) / 4 * 4;
+    if (!p.dbws) zero_overwritten_db(p, s);
   }
   dim3 grid(8 * p.xcd_chunk * p.n_tiles);
   if (epi == EPI_BIAS_ACT) {

@@ -62,13 +62,41 @@ __global__ void rng_normal_kernel(uint64_t seed, uint64_t stream_id, uint64_t of
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = philox_normal(seed, stream_id, offset + i);
 }
 
+// noised = x sqrt(a) + eps sqrt(1 - a), a = alpha_dash(t) (train.py:85-93, 229-234).  fp32 / bf16: fp32 arithmetic, one rounding at
+// the store.  fp16 = Keras' mixed_float16 policy, where x, eps and t are fp16 tensors (train.py:38, 227, 292): every operation
+// rounds to fp16 (t/(steps+1), 1-t, the square, *0.25, both square roots, both products, the sum).
+template <typename T> struct NoiseCoef {
+  float sa, sb;
+  __device__ __forceinline__ NoiseCoef(int t_int, int steps1) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) {
+      const _Float16 t = (_Float16)((_Float16)(float)t_int / (_Float16)(float)steps1);
+      const _Float16 om = (_Float16)1.0f - t;
+      const _Float16 a = (_Float16)(om * om) * (_Float16)0.25f;
+      sa = (float)(_Float16)sqrtf((float)a);
+      sb = (float)(_Float16)sqrtf((float)(_Float16)((_Float16)1.0f - a));
+    } else {
+      const float t = (float)t_int * (1.0f / (float)steps1);
+      const float a = (1.f - t) * (1.f - t) * 0.25f;
+      sa = sqrtf(a); sb = sqrtf(1.f - a);
+    }
+  }
+  __device__ __forceinline__ T mix(float x, float eps) const {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) {
+      const _Float16 xs = (_Float16)x * (_Float16)sa, es = (_Float16)eps * (_Float16)sb;     // x is exact in fp16 (u8/128 - 1)
+      return (T)(xs + es);
+    } else {
+      return from_f32<T>(x * sa + eps * sb);
+    }
+  }
+};
+
 // noising with eps drawn on the fly from the same stream positions rng_normal_kernel would use.  One thread per Philox
 // counter = 4 consecutive elements of the flattened [pixel][channel] image: one Philox call, two logs and two sin/cos pairs
 // make four normals (philox_normal spends a whole call per element); values are bit-identical to it.
 template <typename T>
 __global__ void noise_rng_kernel(const float* __restrict__ x, const int32_t* __restrict__ t_int, uint64_t seed, uint64_t stream_id,
                                  uint64_t offset, float* __restrict__ eps_out, T* __restrict__ out, int ldout,
-                                 T* __restrict__ out2, int ldout2, size_t n, int HW, int C, float inv_steps1) {
+                                 T* __restrict__ out2, int ldout2, size_t n, int HW, int C, int steps1) {
   const uint64_t c0 = offset >> 2;
   const size_t ncounters = (size_t)(((offset + n + 3) >> 2) - c0);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -86,21 +114,19 @@ __global__ void noise_rng_kernel(const float* __restrict__ x, const int32_t* __r
     const uint32_t i0 = (uint32_t)(first - offset);
     uint32_t pix = i0 / (uint32_t)C, c = i0 - pix * (uint32_t)C;
     uint32_t b = pix / (uint32_t)HW, rem = pix - b * (uint32_t)HW;
-    float sa = 0.f, sb = 0.f;
+    NoiseCoef<T> nc(1, steps1);
     bool have = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint64_t e = e0 + k;
       if (e < first || e >= offset + n) continue;
       if (!have) {
-        const float tt = (float)t_int[b] * inv_steps1;
-        const float a = (1.f - tt) * (1.f - tt) * 0.25f;
-        sa = sqrtf(a); sb = sqrtf(1.f - a);
+        nc = NoiseCoef<T>(t_int[b], steps1);
         have = true;
       }
       const size_t i = (size_t)(e - offset);
       if (eps_out) eps_out[i] = nrm[k];
-      const T v = from_f32<T>(x[i] * sa + nrm[k] * sb);
+      const T v = nc.mix(x[i], nrm[k]);
       out[(size_t)pix * ldout + c] = v;
       if (out2) out2[(size_t)pix * ldout2 + c] = v;
       if (++c == (uint32_t)C) {
@@ -114,22 +140,28 @@ __global__ void noise_rng_kernel(const float* __restrict__ x, const int32_t* __r
 template <typename T>
 __global__ void noise_kernel(const float* __restrict__ x, const int32_t* __restrict__ t_int, const float* __restrict__ eps,
                              T* __restrict__ out, int ldout, T* __restrict__ out2, int ldout2, size_t npix, int HW, int C,
-                             float inv_steps1) {
+                             int steps1) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t total = npix * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const size_t pix = i / C;
     const int c = (int)(i - pix * C);
     const int b = (int)(pix / HW);
-    const float t = (float)t_int[b] * inv_steps1;              // t /= (steps + 1)      train.py:87
-    const float a = (1.f - t) * (1.f - t) * 0.25f;             // alpha_dash            train.py:93
-    const float v = x[i] * sqrtf(a) + eps[i] * sqrtf(1.f - a); // train.py:231-234
-    out[pix * ldout + c] = from_f32<T>(v);
-    if (out2) out2[pix * ldout2 + c] = from_f32<T>(v);
+    const NoiseCoef<T> nc(t_int[b], steps1);                   // alpha_dash, train.py:87-93
+    const T v = nc.mix(x[i], eps[i]);                          // train.py:231-234
+    out[pix * ldout + c] = v;
+    if (out2) out2[pix * ldout2 + c] = v;
   }
 }
 
 // ---- Dense(3) head -------------------------------------------------------------------------------------
+// Keras' mixed_float16 policy (train.py:43-45) makes the Dense output and the gradient entering it fp16 tensors; the loss is
+// taken on the fp16 values cast to fp32 (train.py:262-263).  GCT2_F16 reproduces those two rounding points; fp32 / bf16 keep fp32.
+template <typename T> __device__ __forceinline__ float keras_f16_point(float v) {
+  if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) return (float)(_Float16)v;
+  else return v;
+}
+
 template <typename T>
 __global__ void dense_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
                                  float* __restrict__ y, int M, int Cin, int Cout) {
@@ -149,7 +181,7 @@ __global__ void dense_fwd_kernel(const T* __restrict__ x, int ldx, const float* 
       a2 = fmaf(v, wsm[4 * k + 2], a2); a3 = fmaf(v, wsm[4 * k + 3], a3);
     }
     const float acc[4] = {a0, a1, a2, a3};
-    for (int o = 0; o < Cout; o++) y[(size_t)m * Cout + o] = acc[o] + (b ? b[o] : 0.f);
+    for (int o = 0; o < Cout; o++) y[(size_t)m * Cout + o] = keras_f16_point<T>(acc[o] + (b ? b[o] : 0.f));
   }
 }
 
@@ -181,7 +213,7 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const T* __restrict__ x,
     }
     for (int i = tid; i < PIX * 4; i += 256) {
       const int pm = i >> 2, o = i & 3;
-      dys[i] = (o < Cout && mbase + pm < M) ? dy[(size_t)(mbase + pm) * Cout + o] : 0.f;
+      dys[i] = (o < Cout && mbase + pm < M) ? keras_f16_point<T>(dy[(size_t)(mbase + pm) * Cout + o]) : 0.f;
     }
     __syncthreads();
     for (int i = tid; i < PIX * Cmask; i += 256) {
@@ -290,11 +322,11 @@ __global__ __launch_bounds__(256) void dense_head_train_kernel(const T* __restri
       }
       float dp[4] = {0.f, 0.f, 0.f, 0.f};
       for (int o = 0; o < Cout; o++) {
-        const float pr = a[o] + (bias ? bias[o] : 0.f);
+        const float pr = keras_f16_point<T>(a[o] + (bias ? bias[o] : 0.f));
         const float d = pr - target[(size_t)m * Cout + o];
         if (pred_out) pred_out[(size_t)m * Cout + o] = pr;
         lacc = fmaf(d, d, lacc);
-        dp[o] = d * gscale;
+        dp[o] = keras_f16_point<T>(d * gscale);
       }
       *reinterpret_cast<f32x4_t*>(dps + 4 * tid) = f32x4_t{dp[0], dp[1], dp[2], dp[3]};
       u32x4_t* drow = reinterpret_cast<u32x4_t*>(dxs + tid * Cmask);
@@ -369,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void dense_head_mfma_kernel(const T* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, q = lane & 15;
   const float gscale = (loss_scale_ptr ? *loss_scale_ptr : 1.f) * 2.0f / ((float)M * (float)Cout);
+  const float inv_gscale = 1.0f / gscale;
   auto split = [](float v, T& hi, T& lo) { hi = from_f32<T>(v); lo = from_f32<T>(v - to_f32(hi)); };
   auto pk = [](T a, T b) { return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16); };
   // forward A operands: row o = q, reduction slots = channels 32 kk + 8 g + j
@@ -463,21 +496,28 @@ __global__ __launch_bounds__(256, 2) void dense_head_mfma_kernel(const T* __rest
 #pragma unroll
       for (int o = 0; o < 3; o++) {
         if (o < Cout) {
-          const float pr = acc[o] + bv[o];
+          const float pr = keras_f16_point<T>(acc[o] + bv[o]);
           d[o] = pr - target[(size_t)p * Cout + o];
           if (pred_out) pred_out[(size_t)p * Cout + o] = pr;
           lacc = fmaf(d[o], d[o], lacc);
         }
       }
     }
+    // the gradient entering the Dense output, dsc = d * gscale (an fp16 tensor under mixed_float16: keras_f16_point); the backward
+    // MFMAs take it unscaled (dsc / gscale, = d itself when nothing is rounded) and multiply by gscale afterwards
     T dh[3], dl[3];
+    float dsc[3];
 #pragma unroll
-    for (int o = 0; o < 3; o++) split(d[o], dh[o], dl[o]);
+    for (int o = 0; o < 3; o++) {
+      dsc[o] = keras_f16_point<T>(d[o] * gscale);
+      constexpr bool kF16 = sizeof(T) == 2 && !__is_same(T, __bf16);
+      split(kF16 ? dsc[o] * inv_gscale : d[o], dh[o], dl[o]);
+    }
     const u32x4_t bb = {pk(dh[0], dh[1]), pk(dh[2], dl[0]), pk(dl[1], dl[2]), 0u};   // zero in lanes g > 0 (d = 0 there)
     float dp[3];
 #pragma unroll
     for (int o = 0; o < 3; o++) {
-      dp[o] = __shfl(d[o] * gscale, q, 64);                    // every lane group gets the gradient of its pixel
+      dp[o] = __shfl(dsc[o], q, 64);                           // every lane group gets the gradient of its pixel
       if (g == 0) dbacc[o] += dp[o];
     }
     u32x4_t gout[2];
@@ -558,7 +598,8 @@ __global__ __launch_bounds__(256, 2) void dense_head_mfma_kernel(const T* __rest
 // sums the head's partial rows: column -> dW / db / loss / db of the layer below.  9 work-groups x (32 columns x 32 row lanes).
 __global__ __launch_bounds__(1024) void dense_head_finish_kernel(const float* __restrict__ part, int rows, float* __restrict__ dw,
                                                                  float* __restrict__ db, float* __restrict__ loss,
-                                                                 float* __restrict__ db_dx, int ndw, int Cout, float inv_n) {
+                                                                 float* __restrict__ db_dx, int ndw, int Cout, float inv_n,
+                                                                 int accumulate) {
   const int tid = threadIdx.x, cx = tid & 31, rl = tid >> 5;
   const int c = blockIdx.x * 32 + cx;
   double acc = 0.0;
@@ -569,10 +610,11 @@ __global__ __launch_bounds__(1024) void dense_head_finish_kernel(const float* __
   if (rl == 0) {
     double t = 0.0;
     for (int k = 0; k < 32; k++) t += red[k][cx];
-    if (c < ndw) dw[c] += (float)t;
-    else if (c >= 216 && c < 216 + Cout) { if (db) db[c - 216] += (float)t; }
+    const float tf = (float)t;
+    if (c < ndw) dw[c] = accumulate ? dw[c] + tf : tf;
+    else if (c >= 216 && c < 216 + Cout) { if (db) db[c - 216] = accumulate ? db[c - 216] + tf : tf; }
     else if (c == 219) *loss = (float)(t * (double)inv_n);
-    else if (c >= 224 && db_dx) db_dx[c - 224] += (float)t;
+    else if (c >= 224 && db_dx) db_dx[c - 224] = accumulate ? db_dx[c - 224] + tf : tf;
   }
 }
 
@@ -704,16 +746,14 @@ template <typename S, bool HAS_SHADOW>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ g, S* __restrict__ shadow, size_t n, float alpha,
                                                    float b1, float b2, float eps, float grad_mul,
-                                                   const float* __restrict__ inv_scale_ptr,
-                                                   const int32_t* __restrict__ found_inf, int zero_grad,
-                                                   const float* __restrict__ slabs, int nslab, size_t slab_stride, size_t n_slab,
-                                                   size_t zero_from) {
+                                                   const gct2_loss_scale_state* __restrict__ ls, int zero_grad,
+                                                   const float* __restrict__ slabs, int nslab, size_t slab_stride, size_t n_slab) {
   // slabs != NULL: the gradient of the first n_slab elements (a multiple of 4) is the ordered sum of `nslab` partial slabs
   // (slab s at slabs + s * slab_stride) left by a weight-gradient launch - it is never written to or read from g.
-  // zero_from: with zero_grad, only elements >= zero_from (a multiple of 4) are zeroed (a written, not accumulated, weight
-  // gradient needs no zeroing; the bias gradients behind it do).
-  const bool skip = found_inf && *found_inf != 0;
-  const float inv_scale = (inv_scale_ptr ? *inv_scale_ptr : 1.f) * grad_mul;
+  // ls != NULL (LossScaleOptimizer): unscale, skip on non-finite gradients, alpha of the device-side step counter.
+  const bool skip = ls && ls->found_inf != 0;
+  const float inv_scale = (ls ? ls->inv_scale : 1.f) * grad_mul;
+  if (ls) alpha = ls->alpha;
   const size_t n4 = n >> 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const float ob1 = 1.f - b1, ob2 = 1.f - b2;
@@ -734,7 +774,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
       for (; sidx < nslab; sidx++) gv += src[(size_t)sidx * st4];
     } else {
       gv = reinterpret_cast<f32x4_t*>(g)[i];
-      if (zero_grad && (i << 2) >= zero_from) reinterpret_cast<f32x4_t*>(g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (zero_grad) reinterpret_cast<f32x4_t*>(g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     if (skip) continue;
     f32x4_t pv = reinterpret_cast<f32x4_t*>(p)[i], mv = reinterpret_cast<f32x4_t*>(m)[i], vv = reinterpret_cast<f32x4_t*>(v)[i];
@@ -778,8 +818,17 @@ __global__ void cast_kernel(const float* __restrict__ src, S* __restrict__ dst, 
 // ---- loss scale ------------------------------------------------------------------------------------------
 __global__ void ls_init_kernel(gct2_loss_scale_state* s, float scale) {
   s->scale = scale; s->inv_scale = 1.f / scale; s->good_steps = 0; s->found_inf = 0;
+  s->applied_steps = 0; s->alpha = 0.f; s->reserved[0] = s->reserved[1] = 0;
 }
-__global__ void ls_begin_kernel(gct2_loss_scale_state* s) { s->found_inf = 0; }
+// found_inf = 0; alpha of THIS step: WarmUp (train.py:57-65, float32 like the reference) x Adam's bias correction [TF], with
+// k = applied_steps = optimizer.iterations (a skipped step does not advance it)
+__global__ void ls_begin_kernel(gct2_loss_scale_state* s, float base_lr, int warmup_steps, float b1, float b2) {
+  s->found_inf = 0;
+  const int k = s->applied_steps;
+  const float lr = k < warmup_steps ? base_lr * (float)(k + 1) / (float)(warmup_steps + 1) : base_lr;
+  const double t = (double)(k + 1);
+  s->alpha = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+}
 __global__ void ls_check_kernel(const float* __restrict__ g, size_t n, gct2_loss_scale_state* s) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   bool bad = false;
@@ -793,6 +842,7 @@ __global__ void ls_update_kernel(gct2_loss_scale_state* s, int growth_interval) 
   if (s->found_inf) {
     s->scale = fmaxf(s->scale * 0.5f, 1.f); s->good_steps = 0;
   } else {
+    s->applied_steps += 1;
     s->good_steps += 1;
     if (s->good_steps >= growth_interval) { s->scale *= 2.f; s->good_steps = 0; }
   }
@@ -823,7 +873,7 @@ static int noise_t(const float* x, const int32_t* t, const float* eps, void* out
                    int steps, hipStream_t s) {
   const size_t npix = (size_t)B * HW;
   hipLaunchKernelGGL(noise_kernel<T>, dim3(blocks_for(npix * C, 256)), dim3(256), 0, s, x, t, eps, reinterpret_cast<T*>(out), ldout,
-                     reinterpret_cast<T*>(out2), ldout2, npix, HW, C, 1.0f / (float)(steps + 1));
+                     reinterpret_cast<T*>(out2), ldout2, npix, HW, C, steps + 1);
   return gct2_check_launch("noise_image");
 }
 int pw_noise(int dtype, const float* x, const int32_t* t, const float* eps, void* out, int ldout, void* out2, int ldout2, int B, int HW,
@@ -837,7 +887,7 @@ static int noise_rng_t(const float* x, const int32_t* t, uint64_t seed, uint64_t
                        void* out2, int ldout2, int B, int HW, int C, int steps, hipStream_t s) {
   const size_t npix = (size_t)B * HW;
   hipLaunchKernelGGL(noise_rng_kernel<T>, dim3(blocks_for(npix * C / 4 + 2, 256)), dim3(256), 0, s, x, t, seed, sid, off, eps_out,
-                     reinterpret_cast<T*>(out), ldout, reinterpret_cast<T*>(out2), ldout2, npix * C, HW, C, 1.0f / (float)(steps + 1));
+                     reinterpret_cast<T*>(out), ldout, reinterpret_cast<T*>(out2), ldout2, npix * C, HW, C, steps + 1);
   return gct2_check_launch("noise_image_rng");
 }
 int pw_noise_rng(int dtype, const float* x, const int32_t* t, uint64_t seed, uint64_t sid, uint64_t off, float* eps_out, void* out,
@@ -859,8 +909,12 @@ int pw_dense_fwd(int dtype, const void* x, int ldx, const float* w, const float*
 }
 template <typename T>
 static int dense_bwd_t(const void* x, int ldx, const float* w, const float* dy, void* dx, int lddx, float* dw, float* db, int M, int Cin,
-                       int Cout, int Cmask, hipStream_t s) {
+                       int Cout, int Cmask, int accumulate, hipStream_t s) {
   constexpr int PIX = 128;
+  if (!accumulate) {            // the kernel adds its per-work-group sums with atomics
+    (void)hipMemsetAsync(dw, 0, (size_t)Cin * Cout * sizeof(float), s);
+    if (db) (void)hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s);
+  }
   const size_t lds = (size_t)Cin * 16 + PIX * 16 + (size_t)PIX * Cin * sizeof(T);
   const int ntiles = (M + PIX - 1) / PIX;
   const int grid = ntiles < 1024 ? ntiles : 1024;
@@ -871,18 +925,18 @@ static int dense_bwd_t(const void* x, int ldx, const float* w, const float* dy, 
   return gct2_check_launch("dense_bwd");
 }
 int pw_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float* dy, void* dx, int lddx, float* dw, float* db, int M,
-                 int Cin, int Cout, int Cmask, hipStream_t s) {
-  if (dtype == GCT2_F32) return dense_bwd_t<float>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, s);
-  if (dtype == GCT2_BF16) return dense_bwd_t<__bf16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, s);
-  return dense_bwd_t<_Float16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, s);
+                 int Cin, int Cout, int Cmask, int accumulate, hipStream_t s) {
+  if (dtype == GCT2_F32) return dense_bwd_t<float>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, accumulate, s);
+  if (dtype == GCT2_BF16) return dense_bwd_t<__bf16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, accumulate, s);
+  return dense_bwd_t<_Float16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, accumulate, s);
 }
 template <typename T>
-static int dense_head_train_t(const void* x, int ld, const float* w, const float* b, const float* target, float* pred, void* dx, int lddx,
-                              float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask, const float* ls,
-                              float* db_dx, const void* x2, int ldx2, hipStream_t s) {
-  // matrix-core version: the reference head (64 masked U_0 channels + 3 image channels -> 3 outputs) with a registered workspace
-  size_t ws_bytes = 0;
-  float* ws = gct2_workspace(&ws_bytes);
+static int dense_head_train_t(const gct2_ctx& c, const void* x, int ld, const float* w, const float* b, const float* target, float* pred,
+                              void* dx, int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
+                              const float* ls, float* db_dx, const void* x2, int ldx2, int accumulate, hipStream_t s) {
+  // matrix-core version: the reference head (64 masked U_0 channels + 3 image channels -> 3 outputs) with a workspace in the ctx
+  const size_t ws_bytes = c.ws_bytes;
+  float* ws = c.ws;
   if (Cmask == 64 && Cin >= 64 && Cin <= (x2 ? 68 : 72) && (x2 || ld >= 72) && Cout <= 3) {
     const int ngroups = (M + 15) / 16;
     const int grid = std::min(512, (ngroups + 3) / 4);
@@ -890,12 +944,17 @@ static int dense_head_train_t(const void* x, int ld, const float* w, const float
       hipLaunchKernelGGL(dense_head_mfma_kernel<T>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const T*>(x), ld, w, b, target, pred,
                          reinterpret_cast<T*>(dx), lddx, ws, M, Cin, Cout, ls, reinterpret_cast<const T*>(x2), ldx2);
       hipLaunchKernelGGL(dense_head_finish_kernel, dim3(HEAD_ROW / 32), dim3(1024), 0, s, ws, grid, dw, db, loss, db_dx, Cin * Cout, Cout,
-                         1.0f / ((float)M * (float)Cout));
+                         1.0f / ((float)M * (float)Cout), accumulate);
       return gct2_check_launch("dense_head_train");
     }
   }
   if (x2) return gct2_fail(GCT2_EINVAL, "dense_head_train: a split input (x2) needs the matrix-core version: Cmask = 64, Cin <= 68, "
                                         "Cout <= 3 and a registered workspace");
+  if (!accumulate) {            // the LDS-tile kernel adds its per-work-group sums with atomics
+    (void)hipMemsetAsync(dw, 0, (size_t)Cin * Cout * sizeof(float), s);
+    if (db) (void)hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), s);
+    if (db_dx) (void)hipMemsetAsync(db_dx, 0, (size_t)Cmask * sizeof(float), s);
+  }
   constexpr int PIX = 256;
   const size_t lds = (size_t)PIX * ld * 2 + (size_t)PIX * Cmask * 2 + PIX * 16 + (size_t)ld * 16;
   const int ntiles = (M + PIX - 1) / PIX;
@@ -911,12 +970,14 @@ static int dense_head_train_t(const void* x, int ld, const float* w, const float
   hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, s, partials, grid, loss, 1.0f / ((float)M * (float)Cout));
   return gct2_check_launch("dense_head_train");
 }
-int pw_dense_head_train(int dtype, const void* x, int ld, const float* w, const float* b, const float* target, float* pred, void* dx,
-                        int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
-                        const float* ls, float* db_dx, const void* x2, int ldx2, hipStream_t s) {
+int pw_dense_head_train(const gct2_ctx& c, int dtype, const void* x, int ld, const float* w, const float* b, const float* target, float* pred,
+                        void* dx, int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
+                        const float* ls, float* db_dx, const void* x2, int ldx2, int accumulate, hipStream_t s) {
   if (dtype == GCT2_BF16)
-    return dense_head_train_t<__bf16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, x2, ldx2, s);
-  return dense_head_train_t<_Float16>(x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, x2, ldx2, s);
+    return dense_head_train_t<__bf16>(c, x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, x2, ldx2,
+                                      accumulate, s);
+  return dense_head_train_t<_Float16>(c, x, ld, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, ls, db_dx, x2, ldx2,
+                                      accumulate, s);
 }
 template <typename T>
 static int diffusion_mix_t(const float* x, const float* e, float a, float* fake, void* out, int ldout, void* out2, int ldout2, size_t npix,
@@ -974,11 +1035,11 @@ int pw_colsum(int dtype, const void* dz, int ld, float* db, size_t M, int C, flo
   return colsum_t<_Float16>(dz, ld, db, M, C, sign, s);
 }
 int pw_adam(float* p, float* m, float* v, float* g, void* shadow, int sdt, size_t n, float alpha, float b1, float b2, float eps,
-            float grad_mul, const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad, hipStream_t s,
-            const float* slabs, int nslab, size_t slab_stride, size_t n_slab, size_t zero_from) {
+            float grad_mul, const gct2_loss_scale_state* ls, int zero_grad, hipStream_t s,
+            const float* slabs, int nslab, size_t slab_stride, size_t n_slab) {
   if (n == 0) return GCT2_OK;
   const int nb = blocks_for(n / 4 + 4, 256);
-#define GCT2_ADAM(S, HS) hipLaunchKernelGGL((adam_kernel<S, HS>), dim3(nb), dim3(256), 0, s, p, m, v, g, reinterpret_cast<S*>(shadow), n, alpha, b1, b2, eps, grad_mul, inv_scale_ptr, found_inf, zero_grad, slabs, nslab, slab_stride, n_slab, zero_from)
+#define GCT2_ADAM(S, HS) hipLaunchKernelGGL((adam_kernel<S, HS>), dim3(nb), dim3(256), 0, s, p, m, v, g, reinterpret_cast<S*>(shadow), n, alpha, b1, b2, eps, grad_mul, ls, zero_grad, slabs, nslab, slab_stride, n_slab)
   if (!shadow) GCT2_ADAM(float, false);
   else if (sdt == GCT2_BF16) GCT2_ADAM(__bf16, true);
   else if (sdt == GCT2_F16) GCT2_ADAM(_Float16, true);
@@ -998,8 +1059,8 @@ int pw_ls_init(gct2_loss_scale_state* st, float scale, hipStream_t s) {
   hipLaunchKernelGGL(ls_init_kernel, dim3(1), dim3(1), 0, s, st, scale);
   return gct2_check_launch("loss_scale_init");
 }
-int pw_ls_begin(gct2_loss_scale_state* st, hipStream_t s) {
-  hipLaunchKernelGGL(ls_begin_kernel, dim3(1), dim3(1), 0, s, st);
+int pw_ls_begin(gct2_loss_scale_state* st, float base_lr, int warmup_steps, float b1, float b2, hipStream_t s) {
+  hipLaunchKernelGGL(ls_begin_kernel, dim3(1), dim3(1), 0, s, st, base_lr, warmup_steps, b1, b2);
   return gct2_check_launch("loss_scale_begin");
 }
 int pw_ls_check(const float* g, size_t n, gct2_loss_scale_state* st, hipStream_t s) {

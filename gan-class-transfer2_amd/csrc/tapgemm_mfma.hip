@@ -25,8 +25,6 @@
 namespace {
 
 constexpr int BK = 64;
-int g_tapgemm_ablate = 0;                        // timing-only ablation: bit 0 = no DMA in the K loop, bit 1 = no MFMAs (wrong results)
-int g_tapgemm_variant = 0;                       // 0 = auto, 2 = force the 4-wave/2-buffer tile, 3 = force the 8-wave/3-buffer tile
 constexpr unsigned OOB = 0x80000000u;            // >= num_records of every descriptor below
 // s_waitcnt immediate that waits for vmcnt <= n only (expcnt / lgkmcnt fields at their no-wait maxima), gfx9 encoding
 #define VMCNT_ONLY(n) ((((n) & 0xF) | 0x70 | 0xF00 | ((((n) >> 4) & 3) << 14)))
@@ -55,6 +53,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_pie
 __device__ __forceinline__ float* db_target(const TapGemmParams& p, int n) {
   return n < p.db_split ? (p.db ? p.db + n : nullptr) : (p.db2 ? p.db2 + (n - p.db_split) : nullptr);
 }
+// whether the target of channel n is added to (db_accumulate bits of include/gct2.h) or overwritten
+__device__ __forceinline__ bool db_adds(const TapGemmParams& p, int n) { return (p.db_acc >> (n < p.db_split ? 0 : 1)) & 1; }
 
 // NBUF = 2: 4 waves (256 threads), 2 work-groups per CU cover each other's DMA latency, vmcnt(0) per step.
 // NBUF = 3: 8 waves (512 threads, 256 x 128 tile), 1 work-group per CU, the DMA of step t+2 stays in flight
@@ -204,10 +204,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   if constexpr (NBUF == 1) {
     // one LDS buffer (32 KiB): no overlap inside a work-group; 4 work-groups per CU cover each other instead
     for (int it = it_lo; it < it_hi; it++) {
-      if (!(p.ablate & 1) || it == it_lo) issue(it, lds0);
+      issue(it, lds0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (!(p.ablate & 2)) compute(lds0);
+      compute(lds0);
       __syncthreads();
     }
   } else if constexpr (NBUF == 2) {
@@ -215,13 +215,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int it = it_lo; it < it_hi; it += 2) {    // two steps per trip: buffer roles are compile-time
-      if (it + 1 < it_hi && !(p.ablate & 1)) issue(it + 1, lds1);
-      if (!(p.ablate & 2)) compute(lds0);
+      if (it + 1 < it_hi) issue(it + 1, lds1);
+      compute(lds0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (it + 1 >= it_hi) break;
-      if (it + 2 < it_hi && !(p.ablate & 1)) issue(it + 2, lds0);
-      if (!(p.ablate & 2)) compute(lds1);
+      if (it + 2 < it_hi) issue(it + 2, lds0);
+      compute(lds1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -231,8 +231,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     // (a __syncthreads() here would drain vmcnt to 0).  Step t+1 is read only after that barrier.
     auto step = [&](int it, const char* cur, char* tgt) {
       const bool more = it + 2 < it_hi;
-      if (more && !(p.ablate & 1)) issue(it + 2, tgt);
-      if (!(p.ablate & 2)) compute(cur);
+      if (more) issue(it + 2, tgt);
+      compute(cur);
       if (more) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(NDMA));   // the builtin (not asm) so hipcc's own vmcnt bookkeeping sees it
       else __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(0));
       __builtin_amdgcn_s_barrier();
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(1024) void dbpart_reduce_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       float* q = db_target(p, n + r);
-      if (q) *q += t[r];
+      if (q) *q = db_adds(p, n + r) ? *q + t[r] : t[r];
     }
   }
 }
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, 
 }
 
 template <typename T, int FORM, int BM, int BN, int EPI, int NBUF, int WM = 64>
-int launch(TapGemmParams p, hipStream_t s) {
+int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   const int M = p.B * p.Hs * p.Ws;
   constexpr int PH = FORM == FORM_CONVT ? 4 : 1;
   const int tiles = ((M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * PH;
@@ -537,10 +537,9 @@ int launch(TapGemmParams p, hipStream_t s) {
   // small-M layers (bottleneck of the U-Net) cannot fill 256 CUs with output tiles: split the reduction
   p.ksplit = 1;
   p.ws = nullptr;
-  p.ablate = g_tapgemm_ablate;
   p.wide = ((uintptr_t)p.y % 16 == 0 && p.ldy % 8 == 0 && (!p.act || ((uintptr_t)p.act % 16 == 0 && p.ldact % 8 == 0))) ? 1 : 0;
-  size_t ws_bytes = 0;
-  float* ws = gct2_workspace(&ws_bytes);
+  const size_t ws_bytes = c.ws_bytes;
+  float* ws = c.ws;
   p.m_tiles = (M + BM - 1) / BM;
   p.n_tiles = (p.N + BN - 1) / BN;
   const bool want_db = EPI == EPI_MASK && (p.db || p.db2);
@@ -565,6 +564,7 @@ int launch(TapGemmParams p, hipStream_t s) {
   dim3 grid(8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
   auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF, WM>;
   p.dbws = db_rows ? ws + (ws_bytes - dbws_bytes) / sizeof(float) / 4 * 4 : nullptr;
+  if (want_db && !p.dbws) zero_overwritten_db(p, s);
   hipLaunchKernelGGL(kern, grid, dim3((BM / WM) * (BN / 64) * 64), 0, s, p);
   if (p.ksplit > 1) {
     hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)fin_rows, (p.N + 127) / 128), dim3(256), 0, s, p, npix);
@@ -577,7 +577,8 @@ int launch(TapGemmParams p, hipStream_t s) {
 }
 
 template <typename T>
-int dispatch(int form, int epi, const TapGemmParams& p, hipStream_t s) {
+int dispatch(const gct2_ctx& c, int form, int epi, const TapGemmParams& p, hipStream_t s) {
+  const int g_tapgemm_variant = c.tap_variant;
   // big layers: 256 x 128 tile, 8 waves, 3 LDS buffers; layers with few output pixels keep the 128 x 128 tile
   // (more work-groups + split-K); N <= 64 (UpShuffle_0) uses the 256 x 64 tile
   const int M = p.B * p.Hs * p.Ws;
@@ -587,39 +588,39 @@ int dispatch(int form, int epi, const TapGemmParams& p, hipStream_t s) {
   const int tiles256 = ((M + 255) / 256) * ((p.N + 127) / 128) * (form == FORM_CONVT ? 4 : 1);
   const bool auto5 = g_tapgemm_variant == 0 && tiles256 >= 512;
   if ((g_tapgemm_variant == 5 || auto5) && p.N > 64) {   // 256 x 128 tile, 8 waves, one LDS buffer (48 KiB), 2 work-groups per CU
-    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 128, EPI_BIAS_ACT, 1>(p, s)
-                                                      : launch<T, FORM_CONV, 256, 128, EPI_MASK, 1>(p, s);
-    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 128, EPI_BIAS_ACT, 1>(p, s)
-                               : launch<T, FORM_CONVT, 256, 128, EPI_MASK, 1>(p, s);
+    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 128, EPI_BIAS_ACT, 1>(c, p, s)
+                                                      : launch<T, FORM_CONV, 256, 128, EPI_MASK, 1>(c, p, s);
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 128, EPI_BIAS_ACT, 1>(c, p, s)
+                               : launch<T, FORM_CONVT, 256, 128, EPI_MASK, 1>(c, p, s);
   }
   // 256 x 256 tile, 8 waves of 128 x 64, two 64-KiB LDS buffers, one work-group per CU
   const int tiles6 = ((M + 255) / 256) * ((p.N + 255) / 256) * (form == FORM_CONVT ? 4 : 1);
   const bool auto6 = false && tiles6 >= 192;
   if ((g_tapgemm_variant == 6 || auto6) && p.N >= 256) {
-    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 256, EPI_BIAS_ACT, 2, 128>(p, s)
-                                                      : launch<T, FORM_CONV, 256, 256, EPI_MASK, 2, 128>(p, s);
-    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 256, EPI_BIAS_ACT, 2, 128>(p, s)
-                               : launch<T, FORM_CONVT, 256, 256, EPI_MASK, 2, 128>(p, s);
+    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 256, EPI_BIAS_ACT, 2, 128>(c, p, s)
+                                                      : launch<T, FORM_CONV, 256, 256, EPI_MASK, 2, 128>(c, p, s);
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 256, EPI_BIAS_ACT, 2, 128>(c, p, s)
+                               : launch<T, FORM_CONVT, 256, 256, EPI_MASK, 2, 128>(c, p, s);
   }
   if (g_tapgemm_variant == 1) {
-    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 1>(p, s)
-                                                      : launch<T, FORM_CONV, 128, 128, EPI_MASK, 1>(p, s);
-    if (p.N > 64) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT, 1>(p, s)
-                                             : launch<T, FORM_CONVT, 128, 128, EPI_MASK, 1>(p, s);
+    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 1>(c, p, s)
+                                                      : launch<T, FORM_CONV, 128, 128, EPI_MASK, 1>(c, p, s);
+    if (p.N > 64) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT, 1>(c, p, s)
+                                             : launch<T, FORM_CONVT, 128, 128, EPI_MASK, 1>(c, p, s);
   }
   if (form == FORM_CONV) {
-    if (big) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 128, EPI_BIAS_ACT, 3>(p, s)
-                                        : launch<T, FORM_CONV, 256, 128, EPI_MASK, 3>(p, s);
-    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 2>(p, s)
-                               : launch<T, FORM_CONV, 128, 128, EPI_MASK, 2>(p, s);
+    if (big) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 128, EPI_BIAS_ACT, 3>(c, p, s)
+                                        : launch<T, FORM_CONV, 256, 128, EPI_MASK, 3>(c, p, s);
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 2>(c, p, s)
+                               : launch<T, FORM_CONV, 128, 128, EPI_MASK, 2>(c, p, s);
   }
   const bool narrow = p.N <= 64;
   if (epi == EPI_BIAS_ACT) {
-    if (narrow) return launch<T, FORM_CONVT, 256, 64, EPI_BIAS_ACT, 2>(p, s);
-    return big ? launch<T, FORM_CONVT, 256, 128, EPI_BIAS_ACT, 3>(p, s) : launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT, 2>(p, s);
+    if (narrow) return launch<T, FORM_CONVT, 256, 64, EPI_BIAS_ACT, 2>(c, p, s);
+    return big ? launch<T, FORM_CONVT, 256, 128, EPI_BIAS_ACT, 3>(c, p, s) : launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT, 2>(c, p, s);
   }
-  if (narrow) return launch<T, FORM_CONVT, 256, 64, EPI_MASK, 2>(p, s);
-  return big ? launch<T, FORM_CONVT, 256, 128, EPI_MASK, 3>(p, s) : launch<T, FORM_CONVT, 128, 128, EPI_MASK, 2>(p, s);
+  if (narrow) return launch<T, FORM_CONVT, 256, 64, EPI_MASK, 2>(c, p, s);
+  return big ? launch<T, FORM_CONVT, 256, 128, EPI_MASK, 3>(c, p, s) : launch<T, FORM_CONVT, 128, 128, EPI_MASK, 2>(c, p, s);
 }
 
 }  // namespace
@@ -639,10 +640,8 @@ bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {
   return true;
 }
 
-void tapgemm_set_variant(int v) { g_tapgemm_variant = v & 0xff; g_tapgemm_ablate = (v >> 8) & 3; }
-
-bool halo_convT_wanted(int epi, const TapGemmParams& p);      // halo_mfma.hip
-int halo_convT(int dtype, int epi, TapGemmParams p, hipStream_t s);
+bool halo_convT_wanted(const gct2_ctx& c, int epi, const TapGemmParams& p);      // halo_mfma.hip
+int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s);
 
 // the ordered row reduction of the fused bias gradients, for the other translation units that leave partial rows
 int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, hipStream_t s) {
@@ -650,8 +649,8 @@ int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, h
   return gct2_check_launch("dbpart_reduce");
 }
 
-int tapgemm_mfma(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s) {
-  if (form == FORM_CONVT && g_tapgemm_variant == 0 && halo_convT_wanted(epi, p)) return halo_convT(dtype, epi, p, s);
-  if (dtype == GCT2_BF16) return dispatch<__bf16>(form, epi, p, s);
-  return dispatch<_Float16>(form, epi, p, s);
+int tapgemm_mfma(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s) {
+  if (form == FORM_CONVT && c.tap_variant == 0 && halo_convT_wanted(c, epi, p)) return halo_convT(c, dtype, epi, p, s);
+  if (dtype == GCT2_BF16) return dispatch<__bf16>(c, form, epi, p, s);
+  return dispatch<_Float16>(c, form, epi, p, s);
 }

@@ -20,9 +20,6 @@
 namespace {
 
 constexpr unsigned OOB = 0x80000000u;
-int g_wgrad_variant = 0, g_wgrad_ablate = 0;     // tuning / timing hooks (gct2_debug_tapgemm_variant)
-int g_wgrad_target = 256, g_wgrad_slab_max = 24;  // big-tile work-group target and largest split count reduced through slabs
-int g_wgrad_pipe = 1;                             // big tile: 1 = four 32-row stages with a spanning pipeline (default), 0 = two 64-row buffers
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -127,14 +124,13 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
     }
   };
 
-  const bool no_dma = p.ablate & 1, no_mfma = p.ablate & 2;      // timing-only ablations (wrong results)
   if constexpr (NBUF == 1) {
     // one 32-KiB buffer, 4 work-groups per CU cover each other's DMA latency
     for (int step = step_lo; step < step_hi; step++) {
-      if (!no_dma || step == step_lo) issue(step, lds0);
+      issue(step, lds0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (!no_mfma) compute(lds0);
+      compute(lds0);
       __syncthreads();
     }
   } else {
@@ -142,22 +138,18 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int step = step_lo; step < step_hi; step += 2) {        // two steps per trip: buffer roles are compile-time
-      if (step + 1 < step_hi && !no_dma) issue(step + 1, lds1);
-      if (!no_mfma) compute(lds0);
+      if (step + 1 < step_hi) issue(step + 1, lds1);
+      compute(lds0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (step + 1 >= step_hi) break;
-      if (step + 2 < step_hi && !no_dma) issue(step + 2, lds0);
-      if (!no_mfma) compute(lds1);
+      if (step + 2 < step_hi) issue(step + 2, lds0);
+      compute(lds1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   }
 
-  if (p.ablate & 4) {          // timing-only: keep the accumulators alive but skip the atomics
-    if (acc[0][0][0] == 12345.678f) p.dw[0] = acc[3][3][3] + acc[1][2][0];
-    return;
-  }
   // MFMA operand order A = small (cs), B = big (gc): lane holds dW[gc = .. + (lane&15)][cs = .. + 4*(lane>>4) + r], i.e. four
   // consecutive columns of one row -> 16-byte stores (the other order costs four times the store instructions: -7..-24 %)
   //   rsplit == 1        : the tile has one owner -> plain read-add-write (no atomic unit, reproducible)
@@ -286,24 +278,19 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(WgradParams p) {
     }
   };
 
-  const bool no_dma = p.ablate & 1, no_mfma = p.ablate & 2;
   issue(step_lo, lds0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int step = step_lo; step < step_hi; step += 2) {
-    if (step + 1 < step_hi && !no_dma) issue(step + 1, lds1);
-    if (!no_mfma) compute(lds0);
+    if (step + 1 < step_hi) issue(step + 1, lds1);
+    compute(lds0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (step + 1 >= step_hi) break;
-    if (step + 2 < step_hi && !no_dma) issue(step + 2, lds0);
-    if (!no_mfma) compute(lds1);
+    if (step + 2 < step_hi) issue(step + 2, lds0);
+    compute(lds1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  }
-  if (p.ablate & 4) {
-    if (acc[0][0][0] == 12345.678f) p.dw[0] = acc[7][3][3] + acc[1][2][0];
-    return;
   }
   float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
@@ -434,13 +421,11 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
     }
   };
 
-  const bool no_dma = p.ablate & 1, no_mfma = p.ablate & 2;
   // stage s: issue s+3, multiply s, wait until only the DMAs of the stages beyond s+1 are outstanding, barrier
   auto stage = [&](int st, const char* cur, char* tgt) {
-    if (st + 3 < st_hi && !no_dma) issue(st + 3, tgt);
-    if (!no_mfma) compute(cur);
-    if (no_dma) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
-    else if (st + 3 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
+    if (st + 3 < st_hi) issue(st + 3, tgt);
+    compute(cur);
+    if (st + 3 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
     else if (st + 2 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
     else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
     __builtin_amdgcn_s_barrier();
@@ -460,10 +445,6 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
     stage(st + 2, lds2, lds1);
     if (st + 3 >= st_hi) break;
     stage(st + 3, lds3, lds2);
-  }
-  if (p.ablate & 4) {
-    if (acc[0][0][0] == 12345.678f) p.dw[0] = acc[7][3][3] + acc[1][2][0];
-    return;
   }
   float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
@@ -517,8 +498,9 @@ bool wgrad_mfma_supported(int dtype, const WgradParams& p) {
   return true;
 }
 
-int wgrad_mfma(int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer) {
+int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer) {
   if (defer) *defer = WgradSlabs{nullptr, 0, 0};
+  const int g_wgrad_variant = c.wgrad_variant, g_wgrad_target = c.wgrad_target, g_wgrad_slab_max = c.wgrad_slab_max, g_wgrad_pipe = c.wgrad_pipe;
   const int R = p.B * p.Hs * p.Ws;
   // 256 x 256 tile (one work-group per CU) whenever the 128 x 128 tiling would have to split the reduction anyway
   // (fewer than 512 tiles): measured -10..-22 % on U0/U1/U2/D1/D2 (profiles/r01_wgrad_variants.txt)
@@ -536,11 +518,10 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer) {
   const int per = (steps_total + rsplit - 1) / rsplit;
   rsplit = (steps_total + per - 1) / per;            // every split non-empty (each one owns a slab)
   p.rsplit = rsplit;
-  p.ablate = g_wgrad_ablate;
   p.ws = nullptr;
   const size_t n = (size_t)16 * p.Cb * p.Cs;
   size_t ws_bytes = 0;
-  float* ws = gct2_wgrad_workspace(&ws_bytes);
+  float* ws = c.wgrad_scratch(&ws_bytes);
   // measured (scripts/bench_wgrad.py): slabs beat atomics up to ~24 splits; beyond that (UpShuffle_0: 16 tiles x 48
   // splits) the many 1-MiB slabs cost more than the atomics they replace
   if (rsplit > 1 && rsplit <= (big_tile ? 64 : g_wgrad_slab_max) && ws && n % 4 == 0 && (uintptr_t)p.dw % 16 == 0 && n * sizeof(float) * rsplit <= ws_bytes &&
@@ -569,10 +550,3 @@ int wgrad_mfma(int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer) {
   return gct2_check_launch("wgrad_mfma");
 }
 
-void wgrad_set_variant(int v) {
-  g_wgrad_variant = v & 0xf; g_wgrad_ablate = (v >> 8) & 7;
-  g_wgrad_pipe = (v & 0x40) ? 0 : 1;          // 0x40: the two-buffer big-tile kernel (A/B timing, parity tests)
-  if (v & 0x10) g_wgrad_target = 512;          // experiment bits
-  if (v & 0x20) g_wgrad_slab_max = 64;
-  if (v == 0) { g_wgrad_target = 256; g_wgrad_slab_max = 24; }
-}

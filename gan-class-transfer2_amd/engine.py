@@ -145,18 +145,6 @@ class _Buffers:
     pass
 
 
-# the library's scratch registrations are process-wide: remember which engine's tensors are registered, so that an engine
-# re-registers its own before it launches and un-registers them when it dies (no dangling pointers inside the library)
-_WS_OWNER: List[Optional[int]] = [None]
-
-
-def reset_workspace_registration() -> None:
-    """forget every scratch registration (library and bookkeeping); engines re-register on their next launch."""
-    call("gct2_set_workspace", None, 0)
-    call("gct2_set_wgrad_workspace", None, 0)
-    _WS_OWNER[0] = None
-
-
 class UNetEngine:
     """the planned (zero-copy concat) forward / backward / optimizer step of the Denoiser U-Net."""
 
@@ -177,10 +165,12 @@ class UNetEngine:
         self.arena = ParamArena(topo, dtype, self.device)
         self.arena.glorot_init(seed)
         self.arena.refresh_shadow(self._stream())
-        self.iterations = 0            # optimizer.iterations [TF]
+        self._iterations = 0           # optimizer.iterations [TF] (with loss scaling the counter lives on the device)
         self.rng_seed, self.rng_offset_t, self.rng_offset_eps = rng_seed, 0, 0
         self._bufs: Dict[Tuple[int, int, int], _Buffers] = {}
-        # split-K scratch for the bottleneck layers (include/gct2.h gct2_set_workspace); caller-owned = this tensor
+        # the call context (include/gct2.h gct2_ctx): this engine's scratch tensors and tile knobs; nothing is process-wide
+        self.ctx = _lib.Context()
+        # split-K scratch for the bottleneck layers, partial rows of the fused bias gradients / the head; caller-owned = this tensor
         self.workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
         # second stream + its own scratch: the weight-gradient kernels (and, single-GPU, the per-layer Adam launches) run
         # beside the dgrad chain instead of between its links (backward())
@@ -188,30 +178,42 @@ class UNetEngine:
         self.fuse_adam = True          # per-layer Adam fused behind the weight-gradient calls (single replica, no loss scaling)
         self._side = torch.cuda.Stream(device=self.device)
         self.wgrad_workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
-        self._ensure_workspace()
+        self.ctx.set_workspace(self.workspace)
+        self.ctx.set_wgrad_workspace(self.wgrad_workspace)
         self.ls_state = None
         if loss_scaling:
-            self.ls_state = torch.zeros(4, dtype=torch.int32, device=self.device)  # 16-byte gct2_loss_scale_state
-            call("gct2_loss_scale_init", self.ls_state.data_ptr(), float(2 ** 15), self._stream())
+            self.enable_loss_scaling()
         # called with the layer name as soon as that layer's gradient kernels are enqueued (DP all-reduce)
         self.grad_ready_hook: Optional[Callable[[str], None]] = None
+        self._grads_in_arena = True    # False after a step whose fused optimizer consumed weight-gradient slabs in place
 
     # ------------------------------------------------------------------------------------------
-    def _ensure_workspace(self) -> None:
-        """(re-)register this engine's scratch tensors with the library unless they already are the registered ones."""
-        if _WS_OWNER[0] == id(self):
+    def enable_loss_scaling(self, initial_scale: float = 2.0 ** 15) -> None:
+        """tf.keras.mixed_precision.LossScaleOptimizer (train.py:82-83): allocate the device-side state (32-byte
+        gct2_loss_scale_state).  Allowed until the first optimizer step, so `trainer(example)` may come before `compile`
+        exactly as in train.py:505-514."""
+        if self.ls_state is not None:
             return
-        ws, wws = self.workspace, self.wgrad_workspace
-        call("gct2_set_workspace", ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0)
-        call("gct2_set_wgrad_workspace", wws.data_ptr() if wws is not None else None, wws.numel() * 4 if wws is not None else 0)
-        _WS_OWNER[0] = id(self)
+        if self._iterations != 0:
+            raise _lib.Gct2Error("loss scaling cannot be switched on after optimizer steps have been applied")
+        self.loss_scaling = True
+        self.ls_state = torch.zeros(8, dtype=torch.int32, device=self.device)
+        call("gct2_loss_scale_init", self.ls_state.data_ptr(), float(initial_scale), self._stream())
 
-    def __del__(self):
-        try:
-            if _WS_OWNER[0] == id(self):
-                reset_workspace_registration()
-        except Exception:       # interpreter shutdown: the library may already be gone
-            pass
+    @property
+    def iterations(self) -> int:
+        """optimizer.iterations [TF].  Under LossScaleOptimizer a skipped step does not advance it, and whether a step was
+        skipped is only known on the device: the counter lives there (gct2_loss_scale_state.applied_steps) and reading it
+        synchronises."""
+        if self.ls_state is not None:
+            return int(self.ls_state[4].item())
+        return self._iterations
+
+    @iterations.setter
+    def iterations(self, k: int) -> None:
+        self._iterations = int(k)
+        if self.ls_state is not None:
+            self.ls_state[4] = int(k)
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -267,6 +269,12 @@ class UNetEngine:
         return {k: self.arena.param(k).detach().cpu().numpy().copy() for k in self.arena.shapes}
 
     def get_grads(self) -> Dict[str, np.ndarray]:
+        """the gradient arena of the LAST backward pass (every step overwrites it; nothing accumulates across steps).  Not
+        available after a step whose fused optimizer consumed the weight-gradient partial sums in place (train_step with
+        apply=True on one replica without loss scaling): run that step with apply=False, or set fuse_adam = False."""
+        if not self._grads_in_arena:
+            raise _lib.Gct2Error("the last step applied its weight gradients straight from the kernels' partial sums: the "
+                                 "gradient arena does not hold them (use train_step(..., apply=False) or fuse_adam = False)")
         return {k: self.arena.grad(k).detach().cpu().numpy().copy() for k in self.arena.shapes}
 
     # ---- Trainer.call pieces --------------------------------------------------------------------
@@ -289,16 +297,17 @@ class UNetEngine:
         self.rng_offset_t += b.B
         self.rng_offset_eps += b.eps.numel()
 
-    def _noise_targets(self, b: _Buffers) -> Tuple[int, int, Optional[int], int]:
+    def _noise_targets(self, b: _Buffers, unfused_head: bool = False) -> Tuple[int, int, Optional[int], int]:
         """where the noised image goes: always the packed copy `img` (DownShuffle_0 reads it, and so does the fused head
         through its x2 argument); the image slice of R_0 only when the unfused Dense kernels will read R_0 as one
-        67-channel view (its 6-byte writes into 144-byte rows cost more than the rest of the noising)."""
-        if self.fused_head_ok():
+        67-channel view (its 6-byte writes into 144-byte rows cost more than the rest of the noising).  unfused_head: the
+        caller runs forward(head=True) afterwards (Trainer.call, no gradients), which always reads the 67-channel view."""
+        if self.fused_head_ok() and not unfused_head:
             return b.img.data_ptr(), 4, None, 0
         return self._slice_ptr(b.R[0], self.topo.fu(0)), b.ld[0], b.img.data_ptr(), 4
 
-    def noise_into_r0(self, b: _Buffers, x: torch.Tensor) -> None:
-        out, ldout, out2, ldout2 = self._noise_targets(b)
+    def noise_into_r0(self, b: _Buffers, x: torch.Tensor, unfused_head: bool = False) -> None:
+        out, ldout, out2, ldout2 = self._noise_targets(b, unfused_head)
         call("gct2_noise_image", self.dtype, x.data_ptr(), b.t_int.data_ptr(), b.eps.data_ptr(), out, ldout, out2, ldout2,
              b.B, b.H * b.W, 3, self.steps, self._stream())
 
@@ -311,8 +320,7 @@ class UNetEngine:
     def forward(self, b: _Buffers, head: bool = True) -> torch.Tensor:
         """Denoiser.call (train.py:206-215): R_0's image slice must already hold the network input.
         head=False stops before Dense(3) (the train step runs the fused head kernel instead)."""
-        self._ensure_workspace()
-        t, n, s, dt, A = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena
+        t, n, s, dt, A, cx = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena, self.ctx.handle
         for i in range(n):                                      # DownShuffle_i  (train.py:184)
             H, W = b.hw[i]
             if i < n - 1:
@@ -320,14 +328,14 @@ class UNetEngine:
             else:
                 y, ldy = b.Dlast.data_ptr(), t.fd(i)
             x, ldx = (b.img.data_ptr(), 4) if i == 0 else (self._slice_ptr(b.R[i], t.fu(i)), b.ld[i])
-            call("gct2_conv4s2_fwd", dt, x, ldx, A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"), y, ldy, b.B, H, W, t.cx(i), t.fd(i), 1, s)
+            call("gct2_conv4s2_fwd", cx, dt, x, ldx, A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"), y, ldy, b.B, H, W, t.cx(i), t.fd(i), 1, s)
         for i in reversed(range(n)):                            # UpShuffle_i    (train.py:188)
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
                 x, ldx = b.R[i + 1].data_ptr(), b.ld[i + 1]
             else:
                 x, ldx = b.Dlast.data_ptr(), t.fd(i)
-            call("gct2_convT4s2_fwd", dt, x, ldx, A.wptr(f"U{i}.w"), A.pptr(f"U{i}.b"), b.R[i].data_ptr(), b.ld[i],
+            call("gct2_convT4s2_fwd", cx, dt, x, ldx, A.wptr(f"U{i}.w"), A.pptr(f"U{i}.b"), b.R[i].data_ptr(), b.ld[i],
                  b.B, Hi, Wi, t.up_in(i), t.fu(i), 1, s)
         if not head:
             return b.pred
@@ -350,13 +358,12 @@ class UNetEngine:
 
     def head_train(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
         """Dense(3) + fp32 MSE + both of their gradients in one pass over R_0 (gct2_dense_head_train)."""
-        self._ensure_workspace()
         t, A = self.topo, self.arena
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
-        call("gct2_dense_head_train", self.dtype, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"),
+        call("gct2_dense_head_train", self.ctx.handle, self.dtype, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"),
              target.data_ptr(), b.pred.data_ptr(), b.dR[0].data_ptr(), b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"),
              b.loss.data_ptr(), b.partials.data_ptr(), b.B * b.H * b.W, t.fu(0) + 3, 3, t.fu(0), ls_ptr, A.gptr("U0.b"),
-             b.img.data_ptr(), 4, self._stream())
+             b.img.data_ptr(), 4, 0, self._stream())
         return b.loss
 
     def _ready(self, layer: str) -> None:
@@ -372,15 +379,14 @@ class UNetEngine:
         its work-groups fill the tails and the small bottleneck launches of the chain.  adam_inline (single replica, no loss
         scaling): each layer's Adam step is fused behind its weight-gradient call (gct2_adam_args) once the layer's dgrad -
         the last reader of its weights - is done.  The current stream joins the side stream before returning."""
-        self._ensure_workspace()
-        t, n, dt, A = self.topo, self.topo.octaves, self.dtype, self.arena
+        t, n, dt, A, cx = self.topo, self.topo.octaves, self.dtype, self.arena, self.ctx.handle
         main = torch.cuda.current_stream(self.device)
         side = self._side if self.overlap else main
         s, sw = main.cuda_stream, side.cuda_stream
         M = b.B * b.H * b.W
         if not head_done:
             call("gct2_dense_bwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), b.dpred.data_ptr(), b.dR[0].data_ptr(),
-                 b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), s)
+                 b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), 0, s)
         self._ready("dense")
 
         def side_waits_main() -> None:                          # side stream: everything enqueued on main so far is visible
@@ -414,8 +420,10 @@ class UNetEngine:
             else:
                 x, ldx, dx, lddx = b.Dlast.data_ptr(), t.fd(i), b.dDlast.data_ptr(), t.fd(i)
             dz, lddz = b.dR[i].data_ptr(), b.ld[i]
-            # bias gradients are column sums of pre-activation gradients: each dgrad launch adds the sums of the tensor
-            # it writes (fused into its epilogue), so only U_0's bias needs the wgrad entry point's db when the head is unfused
+            # bias gradients are column sums of pre-activation gradients: each dgrad launch produces the sums of the tensor it
+            # writes (fused into its epilogue), so only U_0's bias needs the wgrad entry point's db when the head is unfused.
+            # Nothing accumulates across steps: the first writer of a bias gradient overwrites it (db_accumulate bit clear),
+            # the second one - DownShuffle_{i+1}'s dgrad adding the skip part of the concat - adds (bit set).
             db_u = A.gptr(f"U{i}.b") if (i == 0 and not head_done) else None
             if i < n - 1:       # dx = dR_{i+1}: channels [0, Fu_{i+1}) belong to U_{i+1}, the rest to D_i
                 db, split, db2 = A.gptr(f"U{i + 1}.b"), t.fu(i + 1), A.gptr(f"D{i}.b")
@@ -423,13 +431,13 @@ class UNetEngine:
                 db, split, db2 = A.gptr(f"D{i}.b"), t.fd(i), None
 
             def dgrad_u():
-                call("gct2_convT4s2_dgrad", dt, dz, lddz, A.wptr(f"U{i}.w"), x, ldx, dx, lddx, b.B, Hi, Wi, t.up_in(i),
-                     t.fu(i), 0, db, split, db2, s)
+                call("gct2_convT4s2_dgrad", cx, dt, dz, lddz, A.wptr(f"U{i}.w"), x, ldx, dx, lddx, b.B, Hi, Wi, t.up_in(i),
+                     t.fu(i), 0, db, split, db2, 0, s)
 
             if adam_inline:
                 dgrad_u()
             side_waits_main()                                   # dz (and this layer's bias gradient) are complete
-            call("gct2_convT4s2_wgrad", dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), 0,
+            call("gct2_convT4s2_wgrad", cx, dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), 0,
                  fused(f"U{i}"), sw)
             with torch.cuda.stream(side):
                 self._ready(f"U{i}")
@@ -446,13 +454,13 @@ class UNetEngine:
 
             def dgrad_d():
                 if i > 0:                                       # the image itself needs no gradient
-                    call("gct2_conv4s2_dgrad", dt, dz, lddz, A.wptr(f"D{i}.w"), x, ldx, self._slice_ptr(b.dR[i], t.fu(i)),
-                         b.ld[i], b.B, H, W, t.cx(i), t.fd(i), 1, A.gptr(f"D{i - 1}.b"), t.cx(i), None, s)
+                    call("gct2_conv4s2_dgrad", cx, dt, dz, lddz, A.wptr(f"D{i}.w"), x, ldx, self._slice_ptr(b.dR[i], t.fu(i)),
+                         b.ld[i], b.B, H, W, t.cx(i), t.fd(i), 1, A.gptr(f"D{i - 1}.b"), t.cx(i), None, 1, s)
 
             if adam_inline:
                 dgrad_d()
             side_waits_main()
-            call("gct2_conv4s2_wgrad", dt, xw, ldxw, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), 0,
+            call("gct2_conv4s2_wgrad", cx, dt, xw, ldxw, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), 0,
                  fused(f"D{i}"), sw)
             with torch.cuda.stream(side):
                 self._ready(f"D{i}")
@@ -470,32 +478,37 @@ class UNetEngine:
         return float(np.float32(self.base_lr))
 
     def adam_alpha(self, k: Optional[int] = None) -> float:
+        """lr_k * sqrt(1 - b2^t) / (1 - b1^t), t = k + 1, with the betas as the float32 hyper-parameters Keras holds them as
+        [TF]; gct2_loss_scale_begin computes the same on the device when the step counter lives there."""
         k = self.iterations if k is None else k
         tt = k + 1
-        return self.learning_rate(k) * math.sqrt(1.0 - self.beta_2 ** tt) / (1.0 - self.beta_1 ** tt)
+        b1, b2 = float(np.float32(self.beta_1)), float(np.float32(self.beta_2))
+        return self.learning_rate(k) * math.sqrt(1.0 - b2 ** tt) / (1.0 - b1 ** tt)
 
     def apply_adam(self, lo: int = 0, hi: Optional[int] = None, grad_div: float = 1.0, stream: Optional[int] = None) -> None:
         """Keras Adam on arena range [lo, hi); does not advance `iterations` (see finish_step).
         grad_div > 1 folds the data-parallel mean (sum over ranks / world size) into the gradient read."""
         A, s = self.arena, (self._stream() if stream is None else stream)
         hi = A.total if hi is None else hi
-        if self.ls_state is not None:      # device-resident inv_scale / found_inf of the loss-scale state
-            inv_ptr, inf_ptr = self.ls_state.data_ptr() + 4, self.ls_state.data_ptr() + 12
-        else:
-            inv_ptr, inf_ptr = None, None
+        # with loss scaling the kernel takes inv_scale / found_inf / alpha from the device-resident state (the step counter that
+        # alpha depends on only advances on applied steps); otherwise alpha comes from the host's counter
+        ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
+        alpha = 0.0 if self.ls_state is not None else self.adam_alpha()
         shadow = None if A.shadow is None else A.shadow.data_ptr() + 2 * lo
         call("gct2_adam_keras_multi", A.p.data_ptr() + 4 * lo, A.m.data_ptr() + 4 * lo, A.v.data_ptr() + 4 * lo,
-             A.g.data_ptr() + 4 * lo, shadow, self.dtype, hi - lo, self.adam_alpha(), self.beta_1, self.beta_2,
-             self.epsilon, 1.0 / grad_div, inv_ptr, inf_ptr, 1, s)
+             A.g.data_ptr() + 4 * lo, shadow, self.dtype, hi - lo, alpha, self.beta_1, self.beta_2,
+             self.epsilon, 1.0 / grad_div, ls_ptr, 0, s)
 
     def finish_step(self) -> None:
-        if self.ls_state is not None:
+        if self.ls_state is not None:      # applied_steps (= optimizer.iterations) advances on the device, only if finite
             call("gct2_loss_scale_update", self.ls_state.data_ptr(), 2000, self._stream())
-        self.iterations += 1
+        else:
+            self._iterations += 1
 
     def begin_step(self) -> None:
         if self.ls_state is not None:
-            call("gct2_loss_scale_begin", self.ls_state.data_ptr(), self._stream())
+            call("gct2_loss_scale_begin", self.ls_state.data_ptr(), float(self.base_lr), int(self.warm_up), float(self.beta_1),
+                 float(self.beta_2), self._stream())
 
     def check_finite(self) -> None:
         if self.ls_state is not None:
@@ -530,6 +543,7 @@ class UNetEngine:
         # every gradient (finite check) before any update
         inline = apply and self.fuse_adam and self.ls_state is None
         self.backward(b, head_done=fused, adam_inline=inline)
+        self._grads_in_arena = not inline
         if apply:
             if not inline:
                 self.check_finite()
@@ -566,9 +580,10 @@ class UNetEngine:
         for name in ("p", "m", "v"):
             getattr(A, name).copy_(sd["arena." + name].to(self.device, torch.float32))
         A.g.zero_()
-        self.iterations, self.rng_seed, self.rng_offset_t, self.rng_offset_eps = (int(v) for v in sd["counters"])
+        its, self.rng_seed, self.rng_offset_t, self.rng_offset_eps = (int(v) for v in sd["counters"])
         if self.ls_state is not None:
             self.ls_state.copy_(sd["loss_scale_state"].to(self.device))
+        self.iterations = its
         A.refresh_shadow(self._stream())
 
     def save_checkpoint(self, path: str) -> None:

@@ -91,8 +91,13 @@ class Adam:
 
     def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
-        self.iterations = 0
         self.loss_scaling = False
+        self._engine = None            # bound by Trainer.compile / train_step: the step counter lives with the engine
+
+    @property
+    def iterations(self) -> int:
+        """optimizer.iterations [TF]: applied steps (a step skipped by the loss-scale logic does not count)."""
+        return 0 if self._engine is None else self._engine.iterations
 
     def lr(self, step: int) -> float:
         return self.learning_rate(step) if callable(self.learning_rate) else float(self.learning_rate)
@@ -233,7 +238,7 @@ class UpShuffle(_ConvLayer):
         B, H, W, C = x.shape
         y = torch.empty(B, 2 * H, 2 * W, self.filters, dtype=x.dtype, device=x.device)
         w = self._operand_tensor()
-        call("gct2_convT4s2_fwd", self.dtype_code, x.data_ptr(), C, w.data_ptr(), self.bias.data_ptr(), y.data_ptr(),
+        call("gct2_convT4s2_fwd", None, self.dtype_code, x.data_ptr(), C, w.data_ptr(), self.bias.data_ptr(), y.data_ptr(),
              self.filters, B, H, W, C, self.filters, 1, _stream(x))
         return y
 
@@ -251,7 +256,7 @@ class DownShuffle(_ConvLayer):
             raise ValueError(f"DownShuffle needs even spatial dims, got {H}x{W}")
         y = torch.empty(B, H // 2, W // 2, self.filters, dtype=x.dtype, device=x.device)
         w = self._operand_tensor()
-        call("gct2_conv4s2_fwd", self.dtype_code, x.data_ptr(), C, w.data_ptr(), self.bias.data_ptr(), y.data_ptr(),
+        call("gct2_conv4s2_fwd", None, self.dtype_code, x.data_ptr(), C, w.data_ptr(), self.bias.data_ptr(), y.data_ptr(),
              self.filters, B, H, W, C, self.filters, 1, _stream(x))
         return y
 
@@ -323,7 +328,9 @@ class Denoiser(Layer):
 
     def ensure_engine(self, **engine_kw) -> UNetEngine:
         if self.engine is None:
-            kw = dict(steps=steps, warm_up=warm_up, seed=self._seed)
+            # no optimizer known yet (train.py:505-509 calls the model before compile): the module-level mixed_precision
+            # decides about loss scaling, as it decides about the LossScaleOptimizer wrapper in train.py:82-83
+            kw = dict(steps=steps, warm_up=warm_up, seed=self._seed, loss_scaling=bool(mixed_precision))
             kw.update(engine_kw)
             self.engine = UNetEngine(self.topology, self.dtype_code, self._device, **kw)
             A = self.engine.arena
@@ -397,7 +404,7 @@ class Trainer(Layer):
         x = x.to(eng.device, torch.float32).contiguous()
         b = eng.buffers(*x.shape[:3])
         eng.sample_noise(b)
-        eng.noise_into_r0(b, x)
+        eng.noise_into_r0(b, x, unfused_head=True)     # forward(head=True) reads the image channels from R_0 itself
         eng.forward(b)
         return eng.loss_and_dpred(b, x).clone()[0]
 
@@ -411,17 +418,25 @@ class Trainer(Layer):
                 eng.base_lr, eng.warm_up = lr.base, lr.warmup_steps
             elif not callable(lr):
                 eng.base_lr, eng.warm_up = float(lr), 0
-            if bool(inner.loss_scaling) != (eng.ls_state is not None):
-                raise _lib.Gct2Error("loss scaling must be chosen before the first call builds the engine")
+            if inner.loss_scaling and eng.ls_state is None:
+                eng.enable_loss_scaling()                 # train.py:505-514: the model is called before compile
+            elif not inner.loss_scaling and eng.ls_state is not None:
+                if eng.iterations != 0:
+                    raise _lib.Gct2Error("the engine has already stepped with dynamic loss scaling; it cannot be dropped now")
+                eng.ls_state, eng.loss_scaling = None, False
         self.optimizer, self.loss_fn = optimizer, loss
+        inner = getattr(optimizer, "inner", optimizer)
+        if inner is not None:
+            inner._engine = self.denoiser.engine
 
     def train_step(self, data):
         """one Keras train_step on a (x, y) batch with y == x (train.py:293): returns {'loss': tensor}."""
         x = data[0] if isinstance(data, (tuple, list)) else data
-        loss = self._engine().train_step(x)
+        eng = self._engine()
+        loss = eng.train_step(x)
         inner = getattr(self.optimizer, "inner", self.optimizer)
         if inner is not None:
-            inner.iterations = self._engine().iterations
+            inner._engine = eng
         return {"loss": loss}
 
     def fit(self, dataset: Iterable, steps_per_epoch: int = 1000, epochs: int = 1, callbacks: Seq = (), verbose: int = 1):

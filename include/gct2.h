@@ -40,29 +40,37 @@ enum {
 int gct2_abi_version(void);                 /* bumps when a signature below changes */
 const char* gct2_last_error(void);          /* host string describing the last non-OK return */
 int gct2_device_check(void);                /* GCT2_OK iff the current device is gfx950 */
-/* test hook: non-zero routes every convolution through the direct (non-MFMA) kernels */
-void gct2_debug_force_direct(int on);
-/* tuning hook (same results for every value; tests cover each tile, bench.py --variant does A/B timing).
+/* ---- call context: caller-owned scratch + tuning, re-entrant across streams -------------------------------------------
+ * The library keeps NO process-wide mutable state (ABI v11).  A gct2_ctx is a small host object created by the caller; it
+ * carries (a) the caller's device scratch for split reductions / partial rows and (b) the tile-selection knobs.  Calls that
+ * share one ctx must be enqueued on ONE stream at a time per scratch area (forward / input-gradient / head calls use the
+ * main workspace, *_wgrad calls the weight-gradient workspace when one is set); calls with DIFFERENT ctx objects (two
+ * engines, two host threads, two streams) are fully independent.  ctx = NULL is allowed everywhere: no scratch (split-K and
+ * partial-row reductions are off: same results, slower small layers, fp32 atomics for the bias sums), automatic tiles. */
+typedef struct gct2_ctx gct2_ctx;
+int gct2_ctx_create(gct2_ctx** ctx);
+int gct2_ctx_destroy(gct2_ctx* ctx);
+/* device scratch (16-byte aligned) for the split-K partial sums of layers whose output is too small to fill the chip (the
+ * U-Net's bottleneck levels), the partial rows of the fused bias gradients and the Dense head.  ws = NULL removes it. */
+int gct2_ctx_set_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
+/* optional second scratch used by the weight-gradient entry points only (their partial-tile slabs): with it *_wgrad calls
+ * may run on a second stream concurrently with the forward/dgrad calls of the same ctx (the engine's reverse pass does). */
+int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
+/* tuning (same results for every value; tests cover each tile, scripts/bench_layer.py does A/B timing).
  * bits 0-7: dgrad/forward tile, 0 = automatic, 1/2 = 128x128 with 1/2 LDS buffers, 3 = 256x128 8 waves 3 buffers,
- * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles);  bits 8-9: timing-only ablation (results invalid);
+ * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles), 7 = 256x256 pipelined;
  * bits 16-19: weight-gradient tile, 0 = automatic, 1/3 = 128x128 with 1/2 buffers, 2 = 256x256, 7 = atomics;
  * bit 22: 256x256 weight-gradient tile with two 64-row buffers instead of the four-stage pipeline;
  * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D dgrad), 0 = automatic, 1 = never, 2 = wherever the shape allows. */
-void gct2_debug_tapgemm_variant(int v);
-/* optional caller-owned device scratch (16-byte aligned) for the split-K partial sums of layers whose output
- * is too small to fill the chip (the U-Net's bottleneck levels).  Process-wide; kernels that use it must be
- * enqueued on ONE stream at a time.  ws = NULL disables split-K (same results, slower small layers). */
-int gct2_set_workspace(void* ws, size_t bytes);
-/* optional second scratch used by the weight-gradient entry points only (their partial-tile slabs).  With it
- * registered, *_wgrad calls may be enqueued on a second stream concurrently with the forward/dgrad entry points
- * (the engine's backward pass does that); without it they share the scratch above and the one-stream rule holds. */
-int gct2_set_wgrad_workspace(void* ws, size_t bytes);
+int gct2_ctx_set_tuning(gct2_ctx* ctx, int v);
+/* test hook: non-zero routes every convolution of this ctx through the direct (non-MFMA) kernels */
+int gct2_ctx_force_direct(gct2_ctx* ctx, int on);
 
 /* ---- DownShuffle = Conv2D(f, 4, 2, 'same', relu)   train.py:158-169 ------------------------- */
 /* y[b,oh,ow,o] = act(bias[o] + sum_{kh,kw,i} x[b,2oh+kh-1,2ow+kw-1,i] * w[kh,kw,i,o])
  * x: [B,H,W,Cin] view, H and W even;  w: Keras kernel (4,4,Cin,Cout) of `dtype`;
  * bias: fp32[Cout] or NULL;  y: [B,H/2,W/2,Cout] view;  relu != 0 applies max(.,0). */
-int gct2_conv4s2_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias,
+int gct2_conv4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias,
                      void* y, int ldy, int B, int H, int W, int Cin, int Cout, int relu,
                      void* stream);
 
@@ -74,18 +82,21 @@ int gct2_conv4s2_fwd(int dtype, const void* x, int ldx, const void* w, const flo
  * train.py:114-119), else dx = result.
  * Fused bias gradients (optional): since dx is the gradient w.r.t. the PRE-activation of the layer(s) that produced
  * `act`, its column sums are those layers' bias gradients.  db (+)= sums of THIS call's masked result over channels
- * [0, db_split), db2 (+)= over channels [db_split, Cin) (a concat buffer spans two layers); NULL = not wanted. */
-int gct2_conv4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act,
+ * [0, db_split), db2 (+)= over channels [db_split, Cin) (a concat buffer spans two layers); NULL = not wanted.
+ * db_accumulate: bit 0 set -> db is added to, clear -> db is overwritten; bit 1 the same for db2.  (The skip slice of a
+ * concat buffer receives two gradient contributions, train.py:114-119: the first launch overwrites, the second adds, so the
+ * caller never has to zero a bias gradient.) */
+int gct2_conv4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act,
                        int ldact, void* dx, int lddx, int B, int H, int W, int Cin, int Cout,
-                       int accumulate, float* db, int db_split, float* db2, void* stream);
+                       int accumulate, float* db, int db_split, float* db2, int db_accumulate, void* stream);
 
 /* optional optimizer step fused behind a weight-gradient call (single-replica training without loss scaling): Keras Adam
  * (as gct2_adam_keras_multi) over the layer's contiguous parameter range [kernel | padding | bias ...] of the caller's
  * arenas, enqueued on the same stream right after the gradient.  p, m, v: fp32, start of the kernel's slice; n: elements of
  * the whole range (>= the kernel's 16*Cin*Cout); dw (the call's gradient pointer) must be the matching start of the gradient
  * arena.  The kernel gradient is consumed straight from the launch's partial sums where it has them (it is then never
- * written to dw) or from dw; gradients behind the kernel in the range (the bias, accumulated by the dgrad calls) are read
- * from the gradient arena and zeroed.  Needs accumulate = 0. */
+ * written to dw) or from dw; gradients behind the kernel in the range (the bias, written by the dgrad calls) are read
+ * from the gradient arena.  Nothing is zeroed.  Needs accumulate = 0. */
 typedef struct gct2_adam_args {
   float* p; float* m; float* v;
   void* shadow; int shadow_dtype;      /* compute-dtype copy of p over the same range, or NULL */
@@ -95,56 +106,61 @@ typedef struct gct2_adam_args {
 
 /* weight + bias gradient: dw[kh,kw,i,o] += sum_{b,oh,ow} x[b,2oh+kh-1,2ow+kw-1,i]*dz[b,oh,ow,o],
  * db[o] += sum dz[..,o].  dw: fp32 (4,4,Cin,Cout), db: fp32[Cout] or NULL.  accumulate != 0: dw is a running (or
- * zeroed) buffer and is added to; accumulate == 0: dw is overwritten (saves reading it).  db always accumulates. */
-int gct2_conv4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
+ * zeroed) buffer and is added to; accumulate == 0: dw is overwritten (saves reading it).  db follows the same flag. */
+int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
                        float* db, int B, int H, int W, int Cin, int Cout, int accumulate,
                        const gct2_adam_args* adam /* or NULL */, void* stream);
 
 /* ---- UpShuffle = Conv2DTranspose(f, 4, 2, 'same', relu)   train.py:145-156 ------------------ */
 /* y[b,2ih+kh-1,2iw+kw-1,o] += x[b,ih,iw,i] * w[kh,kw,o,i]; then bias, relu.
  * x: [B,H,W,Cin] view;  w: Keras kernel (4,4,Cout,Cin);  y: [B,2H,2W,Cout] view. */
-int gct2_convT4s2_fwd(int dtype, const void* x, int ldx, const void* w, const float* bias,
+int gct2_convT4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias,
                       void* y, int ldy, int B, int H, int W, int Cin, int Cout, int relu,
                       void* stream);
 
 /* dx[b,ih,iw,i] (+)= mask * sum_{kh,kw,o} dz[b,2ih+kh-1,2iw+kw-1,o] * w[kh,kw,o,i]
  * dz: [B,2H,2W,Cout];  dx/act: [B,H,W,Cin] views;  mask/accumulate as for conv4s2_dgrad. */
-int gct2_convT4s2_dgrad(int dtype, const void* dz, int lddz, const void* w, const void* act,
+int gct2_convT4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act,
                         int ldact, void* dx, int lddx, int B, int H, int W, int Cin, int Cout,
-                        int accumulate, float* db, int db_split, float* db2, void* stream);
+                        int accumulate, float* db, int db_split, float* db2, int db_accumulate, void* stream);
 
 /* dw[kh,kw,o,i] (+)= sum_{b,ih,iw} x[b,ih,iw,i] * dz[b,2ih+kh-1,2iw+kw-1,o]; db[o] += sum dz; accumulate as for
  * conv4s2_wgrad. */
-int gct2_convT4s2_wgrad(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
+int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
                         float* db, int B, int H, int W, int Cin, int Cout, int accumulate,
                         const gct2_adam_args* adam /* or NULL */, void* stream);
 
 /* ---- Dense(3) head on a rank-4 input   train.py:198-202 ------------------------------------- */
 /* y[m,o] = b[o] + sum_i x[m,i] * w[i,o];  x: [M,Cin] view of `dtype`; w fp32 (Cin,Cout), Cout <= 4;
- * y: fp32 [M,Cout] contiguous (the loss is taken in fp32, train.py:262-263). */
+ * y: fp32 [M,Cout] contiguous (the loss is taken in fp32, train.py:262-263).  GCT2_F16: the values are rounded to fp16
+ * first (mixed_float16 Dense output, cast to fp32 at train.py:263). */
 int gct2_dense_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* y,
                    int M, int Cin, int Cout, void* stream);
 
 /* dx[m,i] = mask * sum_o dy[m,o] w[i,o] for i < Cmask (channels >= Cmask get no gradient written);
- * dw[i,o] += sum_m x[m,i] dy[m,o];  db[o] += sum_m dy[m,o].   dy fp32 [M,Cout].
- * mask = x[m,i] > 0 (x is the ReLU output feeding the head; train.py:188,198). */
+ * dw[i,o] (+)= sum_m x[m,i] dy[m,o];  db[o] (+)= sum_m dy[m,o]  (accumulate != 0 adds, else overwrites).   dy fp32 [M,Cout].
+ * mask = x[m,i] > 0 (x is the ReLU output feeding the head; train.py:188,198).  GCT2_F16: dy is rounded to fp16 on read
+ * (the gradient entering a mixed_float16 Dense output is fp16). */
 int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float* dy, void* dx,
                    int lddx, float* dw, float* db, int M, int Cin, int Cout, int Cmask,
-                   void* stream);
+                   int accumulate, void* stream);
 
 /* fused train-step head (16-bit dtypes): dense_fwd + mse_fwd_bwd + dense_bwd in ONE pass over x (= R_0):
  *   pred = x w + b;  loss = mean((pred - target)^2);  dpred = loss_scale * 2 (pred - target) / (M Cout);
- *   dx[m, i < Cmask] = (x > 0) * dpred w^T;  dw += x^T dpred;  db += sum dpred.
+ *   dx[m, i < Cmask] = (x > 0) * dpred w^T;  dw (+)= x^T dpred;  db (+)= sum dpred.
+ * GCT2_F16 follows Keras' mixed_float16 rounding points (train.py:43-45): the Dense output and the gradient entering it are
+ * rounded to fp16 (pred is stored as fp32 of the fp16 value); GCT2_BF16 keeps both in fp32.
  * target: fp32 [M,Cout]; pred: fp32 [M,Cout] or NULL; loss: 1 float; partials: >= 1024 floats scratch.
  * x2 (may be NULL): the input channels [Cmask, Cin) come from this second view (ldx2 elements per pixel, at most 4
  * channels, 8-byte aligned rows) instead of x - the concat [UpShuffle_0 output, image] is then never assembled at all
  * (the image lives in its packed copy only).  Needs Cmask = 64, Cout <= 3 and a registered workspace.
  * Replaces train.py:198-202 + 262-272 and their autodiff inside Keras fit (train.py:516). */
-int gct2_dense_head_train(int dtype, const void* x, int ldx, const float* w, const float* b,
+int gct2_dense_head_train(gct2_ctx* ctx, int dtype, const void* x, int ldx, const float* w, const float* b,
                           const float* target, float* pred, void* dx, int lddx, float* dw, float* db,
                           float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
-                          const float* loss_scale_ptr, float* db_dx /* += column sums of dx, or NULL */,
-                          const void* x2, int ldx2, void* stream);
+                          const float* loss_scale_ptr, float* db_dx /* column sums of dx, or NULL */,
+                          const void* x2, int ldx2, int accumulate /* dw, db, db_dx: 0 = overwrite, else add */,
+                          void* stream);
 
 /* ---- Trainer.call pieces   train.py:223-272 -------------------------------------------------- */
 /* t_int[b] ~ U{1..steps} (train.py:224-226) and eps ~ N(0,1) (train.py:227) from a counter-based
@@ -156,6 +172,8 @@ int gct2_rng_normal(uint64_t seed, uint64_t stream_id, uint64_t offset, float* o
 
 /* noised = x*sqrt(a_b) + eps*sqrt(1-a_b), a_b = 0.25*(1 - t_b/(steps+1))^2  (train.py:85-93,229-234)
  * x, eps: fp32 [B, HW, C] contiguous; t_int: int32[B]; out: view [B*HW, C] of `dtype` with ldout.
+ * GCT2_F32 / GCT2_BF16: fp32 arithmetic, one rounding at the store.  GCT2_F16: every operation is rounded to fp16 as under
+ * Keras' mixed_float16 policy, where x, eps and t are fp16 tensors (train.py:38, 227-234, 292).
  * out2 (may be NULL): a second view [B*HW, C] with ldout2 that receives the same values - the engine keeps a packed
  * copy of the image (ld 4) for DownShuffle_0 beside the slice of the concat buffer that Dense(3) reads. */
 int gct2_noise_image(int dtype, const float* x, const int32_t* t_int, const float* eps, void* out,
@@ -197,31 +215,41 @@ int gct2_image_prepare(const uint8_t* src, const int64_t* offsets, const int32_t
 int gct2_mse_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss,
                      float* partials, size_t n, const float* loss_scale_ptr, void* stream);
 
+/* ---- mixed precision (train.py:34,43-45,82-83) ------------------------------------------------ */
+/* device-resident state of Keras' LossScaleOptimizer [TF] plus the optimizer step counter it gates: a skipped step (inf/nan
+ * gradients) does not run the inner apply_gradients, so optimizer.iterations - and with it the WarmUp step and Adam's bias
+ * correction - only advance on APPLIED steps.  32 bytes, 16-byte aligned. */
+typedef struct {
+  float scale; float inv_scale; int32_t good_steps; int32_t found_inf;
+  int32_t applied_steps;   /* optimizer.iterations */
+  float alpha;             /* lr(applied_steps) * sqrt(1-b2^t)/(1-b1^t), t = applied_steps+1: written by loss_scale_begin */
+  int32_t reserved[2];
+} gct2_loss_scale_state;
+int gct2_loss_scale_init(gct2_loss_scale_state* state, float initial_scale, void* stream);
+/* start of a step: found_inf = 0 and alpha for THIS step from the WarmUp schedule (train.py:57-65: float32
+ * base * (step+1) / (warmup_steps+1) while step < warmup_steps, else base) and Adam's bias correction. */
+int gct2_loss_scale_begin(gct2_loss_scale_state* state, float base_lr, int warmup_steps, float beta1, float beta2,
+                          void* stream);
+/* found_inf |= any(!isfinite(g)) */
+int gct2_scale_check_finite(const float* g, size_t n, gct2_loss_scale_state* state, void* stream);
+/* dynamic update [TF]: finite -> applied_steps++, good_steps++, scale x2 every growth_interval; non-finite -> scale /2, reset. */
+int gct2_loss_scale_update(gct2_loss_scale_state* state, int growth_interval, void* stream);
+
 /* ---- optimizer   train.py:50-65, 75 (Keras Adam + WarmUp) ------------------------------------ */
 /* Keras ResourceApplyAdam over a flat fp32 arena of n parameters:
- *   g' = g * grad_mul * (*inv_scale_ptr or 1);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
- *   p -= alpha * m / (sqrt(v) + eps),  alpha = lr_k * sqrt(1-b2^t)/(1-b1^t) computed by the host
- *   (lr_k from the WarmUp schedule).  grad_mul: host scalar (1/world_size turns the all-reduced SUM into the
- *   data-parallel mean).  Skipped entirely when *found_inf != 0 (LossScaleOptimizer, train.py:82-83).
+ *   g' = g * grad_mul * (ls ? ls->inv_scale : 1);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+ *   p -= alpha * m / (sqrt(v) + eps),  alpha = lr_k * sqrt(1-b2^t)/(1-b1^t) computed by the host (lr_k from the WarmUp
+ *   schedule) - or, with ls != NULL, taken from ls->alpha (the device-side step counter decides) and the whole update is
+ *   skipped when ls->found_inf != 0 (LossScaleOptimizer, train.py:82-83).
+ *   grad_mul: host scalar (1/world_size turns the all-reduced SUM into the data-parallel mean).
  *   shadow (may be NULL): low-precision copy of p in `shadow_dtype` written in the same pass.
- *   zero_grad != 0: g is zeroed after use (the wgrad kernels accumulate). */
+ *   zero_grad != 0: g is zeroed after use (for callers that accumulate gradients; the engine never needs it). */
 int gct2_adam_keras_multi(float* p, float* m, float* v, float* g, void* shadow, int shadow_dtype,
                           size_t n, float alpha, float beta1, float beta2, float eps, float grad_mul,
-                          const float* inv_scale_ptr, const int32_t* found_inf, int zero_grad,
-                          void* stream);
+                          const gct2_loss_scale_state* ls, int zero_grad, void* stream);
 
 /* fp32 -> dtype cast of a flat array (initial weight shadows). */
 int gct2_cast_from_f32(int dtype, const float* src, void* dst, size_t n, void* stream);
-
-/* ---- mixed precision (train.py:34,43-45,82-83) ------------------------------------------------ */
-/* state = {float scale; float inv_scale; int32 good_steps; int32 found_inf} on the device.
- * scale_check_finite: found_inf |= any(!isfinite(g)).  (found_inf must be zeroed by loss_scale_begin) */
-typedef struct { float scale; float inv_scale; int32_t good_steps; int32_t found_inf; } gct2_loss_scale_state;
-int gct2_loss_scale_init(gct2_loss_scale_state* state, float initial_scale, void* stream);
-int gct2_loss_scale_begin(gct2_loss_scale_state* state, void* stream);          /* found_inf = 0 */
-int gct2_scale_check_finite(const float* g, size_t n, gct2_loss_scale_state* state, void* stream);
-/* dynamic update [TF]: finite -> good_steps++, x2 every growth_interval; non-finite -> /2, reset. */
-int gct2_loss_scale_update(gct2_loss_scale_state* state, int growth_interval, void* stream);
 
 #ifdef __cplusplus
 }

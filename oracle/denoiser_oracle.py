@@ -282,6 +282,21 @@ def noise_image(x, t_int, eps, steps=200):
     return x * np.sqrt(a) + eps * np.sqrt(1.0 - a)
 
 
+def noise_image_f16(x, t_int, eps, steps=200):
+    """train.py:229-234 under `mixed_precision = True` (train.py:34,38,43-45): x (train.py:292), epsilon (train.py:227) and
+    t = cast(t_int, x.dtype) (train.py:229) are float16 tensors, so alpha_dash and the mix run in float16 - every operation
+    rounds to fp16 [TF]: t /= steps+1; 1 - t; (.)**2; * 0.25; **0.5; 1 - alpha; **0.5; the two products; the sum.
+    numpy's float16 arithmetic rounds each operation the same way.  Returns a float16 array."""
+    h = np.float16
+    t = np.asarray(t_int).astype(h) / h(steps + 1)
+    om = h(1.0) - t
+    a = (om * om).astype(h) * h(0.25)
+    sa = np.sqrt(a.astype(np.float32)).astype(h).reshape(-1, 1, 1, 1)
+    sb = np.sqrt((h(1.0) - a).astype(np.float32)).astype(h).reshape(-1, 1, 1, 1)
+    x16, e16 = np.asarray(x).astype(h), np.asarray(eps).astype(h)
+    return (x16 * sa).astype(h) + (e16 * sb).astype(h)
+
+
 def unet_forward(params, x0, cfg: OracleConfig, operand_round: Optional[str] = None):
     """Denoiser.call (train.py:206-215): `t` is ignored; returns (prediction, cache).
 
@@ -342,16 +357,28 @@ def unet_backward(params, cache, dpred, cfg: OracleConfig, operand_round: Option
     return g
 
 
-def trainer_step(params, x, t_int, eps, cfg: OracleConfig, operand_round: Optional[str] = None):
-    """Trainer.call default branch (predict_x=True): returns (loss, pred, grads).
+def trainer_step(params, x, t_int, eps, cfg: OracleConfig, operand_round: Optional[str] = None, loss_scale: float = 1.0):
+    """Trainer.call default branch (predict_x=True): returns (loss, pred, grads, noised).
     loss = mean((x - pred)^2) in the working dtype (train.py:262-272);
-    identity(...) then takes reduce_mean of that scalar (train.py:171-173) = same scalar."""
-    noised = noise_image(x, t_int, eps, cfg.steps)
+    identity(...) then takes reduce_mean of that scalar (train.py:171-173) = same scalar.
+
+    operand_round == "f16" is the reference's `mixed_precision = True` mode (Keras mixed_float16, train.py:43-45) with its
+    rounding points [TF]: the noising runs in fp16 arithmetic (noise_image_f16), the Dense(3) output is an fp16 tensor that
+    train.py:263 casts to fp32 for the loss, and the gradient that enters it is fp16 as well - which is why the
+    LossScaleOptimizer (train.py:82-83) multiplies the loss by `loss_scale` first; the returned gradients are the SCALED ones.
+    (Known deviation kept out of this model and of the HIP path, DESIGN.md section 4: Keras also rounds every variable gradient
+    and the conv output before the bias add to fp16.)"""
+    f16 = operand_round == "f16"
+    noised = noise_image_f16(x, t_int, eps, cfg.steps).astype(x.dtype) if f16 else noise_image(x, t_int, eps, cfg.steps)
     pred, cache = unet_forward(params, noised, cfg, operand_round)
+    if f16:
+        pred = round_f16(pred)
     diff = pred - x
     nel = diff.size
     loss = float(np.sum(diff.astype(np.float64) ** 2) / nel)
-    dpred = (2.0 / nel) * diff
+    dpred = (2.0 * loss_scale / nel) * diff
+    if f16:
+        dpred = round_f16(dpred)
     grads = unet_backward(params, cache, dpred, cfg, operand_round)
     return loss, pred, grads, noised
 
@@ -366,7 +393,7 @@ def keras_adam_step(p, g, m, v, k: int, cfg: OracleConfig, dtype=np.float32):
     eps = 1e-7 added to sqrt(v), NOT to sqrt(v_hat)."""
     t = k + 1
     lr = warmup_lr(k, cfg.base_lr, cfg.warm_up)
-    b1, b2 = cfg.beta_1, cfg.beta_2
+    b1, b2 = float(np.float32(cfg.beta_1)), float(np.float32(cfg.beta_2))   # Keras holds the hyper-parameters as float32 [TF]
     alpha = dtype(lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t))
     p = p.astype(dtype); g = g.astype(dtype); m = m.astype(dtype); v = v.astype(dtype)
     m = dtype(b1) * m + dtype(1.0 - b1) * g
@@ -405,6 +432,7 @@ class OracleTrainer:
     iterations: int = 0
     m: Dict[str, np.ndarray] = field(default_factory=dict)
     v: Dict[str, np.ndarray] = field(default_factory=dict)
+    loss_scale: Optional[LossScaleState] = None     # LossScaleOptimizer (train.py:82-83); None = plain Adam
 
     def __post_init__(self):
         for k_, p in self.params.items():
@@ -412,7 +440,16 @@ class OracleTrainer:
             self.v.setdefault(k_, np.zeros_like(p, dtype=np.float32))
 
     def train_step(self, x, t_int, eps):
-        loss, pred, grads, _ = trainer_step(self.params, x, t_int, eps, self.cfg, self.operand_round)
+        scale = self.loss_scale.scale if self.loss_scale is not None else 1.0
+        loss, pred, grads, _ = trainer_step(self.params, x, t_int, eps, self.cfg, self.operand_round, loss_scale=scale)
+        if self.loss_scale is not None:
+            # LossScaleOptimizer [TF]: unscale; inf/nan anywhere -> halve the scale and skip the inner apply_gradients, so
+            # optimizer.iterations (and with it the WarmUp step and Adam's bias correction) does not advance
+            with np.errstate(invalid="ignore", over="ignore"):
+                grads = {k_: g / scale for k_, g in grads.items()}
+            finite = all(bool(np.isfinite(g).all()) for g in grads.values())
+            if not self.loss_scale.update(finite):
+                return loss, pred, grads
         for name in self.params:
             p, m, v = keras_adam_step(self.params[name], grads[name], self.m[name], self.v[name],
                                       self.iterations, self.cfg)

@@ -6,7 +6,7 @@ import gan_class_transfer2_amd as g
 L = g._lib
 dev = torch.device("cuda", 0)
 ws = torch.empty(64 << 18, dtype=torch.float32, device=dev)
-L.call("gct2_set_workspace", ws.data_ptr(), ws.numel() * 4)
+CTX = L.Context(); CTX.set_workspace(ws)
 B, H, W = 64, 128, 128
 M = B * H * W
 bf = torch.bfloat16
@@ -30,16 +30,16 @@ w = (torch.randn(67, 3, device=dev) * 0.3); b = torch.zeros(3, device=dev)
 pred = torch.zeros(M, 3, device=dev); dx = torch.zeros(M, 72, dtype=bf, device=dev)
 dw = torch.zeros(67, 3, device=dev); db = torch.zeros(3, device=dev); loss = torch.zeros(1, device=dev); part = torch.zeros(1024, device=dev)
 dbx = torch.zeros(64, device=dev)
-us = timeit(lambda: L.call("gct2_dense_head_train", 1, r0.data_ptr(), 72, w.data_ptr(), b.data_ptr(), x.data_ptr(), pred.data_ptr(),
-      dx.data_ptr(), 72, dw.data_ptr(), db.data_ptr(), loss.data_ptr(), part.data_ptr(), M, 67, 3, 64, None, dbx.data_ptr(), img.data_ptr(), 4, s))
+us = timeit(lambda: L.call("gct2_dense_head_train", CTX.handle, 1, r0.data_ptr(), 72, w.data_ptr(), b.data_ptr(), x.data_ptr(), pred.data_ptr(),
+      dx.data_ptr(), 72, dw.data_ptr(), db.data_ptr(), loss.data_ptr(), part.data_ptr(), M, 67, 3, 64, None, dbx.data_ptr(), img.data_ptr(), 4, 0, s))
 print("dense_head_train  %7.1f us  (%.2f TB/s of 151+134+12.6+12.6 MB)" % (us, (M * (144 + 128 + 12 + 12)) / us / 1e6))
 
 # the 3-channel layer (DownShuffle_0) on the packed image: forward and weight gradient
 img.copy_(torch.randn(M, 4, device=dev).to(bf)); img[:, 3] = 0
 w0 = (torch.randn(4, 4, 3, 128, device=dev) * 0.1).to(bf); b0 = torch.zeros(128, device=dev)
 y1 = torch.zeros(B, H // 2, W // 2, 256, dtype=bf, device=dev)
-print("D0 forward        %7.1f us" % timeit(lambda: L.call("gct2_conv4s2_fwd", 1, img.data_ptr(), 4, w0.data_ptr(), b0.data_ptr(),
+print("D0 forward        %7.1f us" % timeit(lambda: L.call("gct2_conv4s2_fwd", CTX.handle, 1, img.data_ptr(), 4, w0.data_ptr(), b0.data_ptr(),
       y1.data_ptr() + 2 * 128, 256, B, H, W, 3, 128, 1, s)))
 dz1 = torch.randn(B, H // 2, W // 2, 256, device=dev).to(bf); dw0 = torch.zeros(4, 4, 3, 128, device=dev)
-print("D0 weight grad    %7.1f us" % timeit(lambda: L.call("gct2_conv4s2_wgrad", 1, img.data_ptr(), 4, dz1.data_ptr() + 2 * 128, 256,
+print("D0 weight grad    %7.1f us" % timeit(lambda: L.call("gct2_conv4s2_wgrad", CTX.handle, 1, img.data_ptr(), 4, dz1.data_ptr() + 2 * 128, 256,
       dw0.data_ptr(), None, B, H, W, 3, 128, 1, None, s)))

@@ -1,5 +1,5 @@
 """time single weight-gradient layers through the C ABI (diagnostic).
-usage: python scripts/bench_wgrad.py [code ...]   code = variant (0/1) + 256*ablate bits (1 no DMA, 2 no MFMA, 4 no atomics)"""
+usage: python scripts/bench_wgrad.py [code ...]   code = weight-gradient tile variant (bits 16-23 of gct2_ctx_set_tuning)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ L = g._lib
 dev = torch.device("cuda", 0)
 B = 64
 ws = torch.empty(64 << 18, dtype=torch.float32, device=dev)
-L.call("gct2_set_workspace", ws.data_ptr(), ws.numel() * 4)   # code 7 = keep atomics although a workspace is registered
+CTX = L.Context(); CTX.set_workspace(ws)   # code 7 = keep atomics although a workspace is registered
 LAYERS = {  # name: (kind, H, W, Cin, Cout) with H, W = spatial size of the layer INPUT
     "U0.wgrad": ("convT", 64, 64, 256, 64), "U1.wgrad": ("convT", 32, 32, 512, 128), "U2.wgrad": ("convT", 16, 16, 1024, 256),
     "U3.wgrad": ("convT", 8, 8, 1024, 512), "D1.wgrad": ("conv", 64, 64, 128, 256), "D2.wgrad": ("conv", 32, 32, 256, 512),
@@ -16,18 +16,18 @@ LAYERS = {  # name: (kind, H, W, Cin, Cout) with H, W = spatial size of the laye
 }
 def run(name, code, iters=20):
     kind, H, W, Cin, Cout = LAYERS[name]
-    L.load().gct2_debug_tapgemm_variant(code << 16)
+    CTX.set_tuning(code << 16)
     bf = torch.bfloat16
     s = torch.cuda.current_stream().cuda_stream
     if kind == "conv":
         x = torch.randn(B, H, W, Cin, device=dev).to(bf); dz = torch.randn(B, H // 2, W // 2, Cout, device=dev).to(bf)
         dw = torch.zeros(4, 4, Cin, Cout, device=dev)
-        f = lambda: L.call("gct2_conv4s2_wgrad", 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, s)
+        f = lambda: L.call("gct2_conv4s2_wgrad", CTX.handle, 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, s)
         flops = 2.0 * B * (H // 2) * (W // 2) * Cout * 16 * Cin
     else:
         x = torch.randn(B, H, W, Cin, device=dev).to(bf); dz = torch.randn(B, 2 * H, 2 * W, Cout, device=dev).to(bf)
         dw = torch.zeros(4, 4, Cout, Cin, device=dev)
-        f = lambda: L.call("gct2_convT4s2_wgrad", 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, s)
+        f = lambda: L.call("gct2_convT4s2_wgrad", CTX.handle, 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, s)
         flops = 2.0 * B * H * W * Cout * 16 * Cin
     for _ in range(3): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,8 +36,8 @@ def run(name, code, iters=20):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     return us, flops / us / 1e6
-codes = [int(v) for v in sys.argv[1:]] or [0, 7, 0 + 256, 0 + 512, 0 + 1024]
-print("layer      " + "".join(f"{'v%d/a%d' % (v & 255, v >> 8):>16s}" for v in codes))
+codes = [int(v) for v in sys.argv[1:]] or [0, 7]
+print("layer      " + "".join(f"{'v%d' % v:>16s}" for v in codes))
 for name in LAYERS:
     print(f"{name:10s} " + "".join("%8.1fus %4.0fTF" % run(name, v) for v in codes))
-L.load().gct2_debug_tapgemm_variant(0)
+CTX.set_tuning(0)

@@ -41,9 +41,14 @@ def main():
     for k, v in params.items():
         out["param/" + k] = v
         out["grad/" + k] = grads[k]
-        out["param2/" + k] = tr.params[k]
-        out["m2/" + k] = tr.m[k]
-        out["v2/" + k] = tr.v[k]
+        out["param2/" + k] = tr.params[k].copy()
+        out["m2/" + k] = tr.m[k].copy()
+        out["v2/" + k] = tr.v[k].copy()
+    # a third step from the state after two: what a run resumed from (param2, m2, v2, iterations = 2) must reproduce
+    xs, ts, es = O.synthetic_batch(cfg, seed=2)
+    out["loss3"] = np.float64(tr.train_step(xs, ts, es)[0])
+    for k in params:
+        out["param3/" + k] = tr.params[k].copy()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tiny_step.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

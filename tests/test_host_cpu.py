@@ -28,21 +28,37 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gct2.h but not exported"
     # and the ctypes table binds exactly the declared entry points (minus last_error, bound separately)
     assert sorted(set(g._lib.SIGNATURES) | {"gct2_last_error"}) == names
-    assert g._lib.load().gct2_abi_version() == 10
+    assert g._lib.load().gct2_abi_version() == 11
 
 
 def test_argument_validation_needs_no_gpu():
     import gan_class_transfer2_amd as g
     L = g._lib.load()
     # odd height: the reference's concat would fail (train.py:114-119); nothing is launched
-    rc = L.gct2_conv4s2_fwd(0, 16, 8, 16, None, 16, 8, 1, 5, 4, 8, 8, 1, None)
+    rc = L.gct2_conv4s2_fwd(None, 0, 16, 8, 16, None, 16, 8, 1, 5, 4, 8, 8, 1, None)
     assert rc == 1 and b"even" in L.gct2_last_error()
-    assert L.gct2_conv4s2_fwd(7, 16, 8, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1      # bad dtype
-    assert L.gct2_conv4s2_fwd(0, None, 8, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1    # null pointer
-    assert L.gct2_convT4s2_fwd(0, 16, 4, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1     # ld < channels
+    assert L.gct2_conv4s2_fwd(None, 7, 16, 8, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1      # bad dtype
+    assert L.gct2_conv4s2_fwd(None, 0, None, 8, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1    # null pointer
+    assert L.gct2_convT4s2_fwd(None, 0, 16, 4, 16, None, 16, 8, 1, 4, 4, 8, 8, 1, None) == 1     # ld < channels
     assert L.gct2_dense_fwd(0, 16, 67, 16, None, 16, 10, 67, 5, None) == 1                 # Cout > 4
     with pytest.raises(g.Gct2Error):
-        g._lib.call("gct2_adam_keras_multi", 4, 16, 16, 16, None, 0, 8, 1e-3, 0.9, 0.999, 1e-7, 1.0, None, None, 0, None)  # misaligned
+        g._lib.call("gct2_adam_keras_multi", 4, 16, 16, 16, None, 0, 8, 1e-3, 0.9, 0.999, 1e-7, 1.0, None, 0, None)  # misaligned
+
+
+def test_call_context_is_host_only_and_independent():
+    """gct2_ctx (ABI v11): created, configured and destroyed without a GPU; the library keeps no process-wide scratch, so two
+    contexts are independent objects and a bad scratch pointer is rejected per context."""
+    import gan_class_transfer2_amd as g
+    L = g._lib.load()
+    a, b = g._lib.Context(), g._lib.Context()
+    assert a.handle and b.handle and a.handle != b.handle
+    assert L.gct2_ctx_set_workspace(a.handle, 24, 1 << 20) == 1 and b"16-byte" in L.gct2_last_error()      # misaligned
+    assert L.gct2_ctx_set_workspace(a.handle, 4096, 1 << 20) == 0 and L.gct2_ctx_set_workspace(a.handle, None, 0) == 0
+    assert L.gct2_ctx_set_tuning(b.handle, 2 | (3 << 16) | (1 << 24)) == 0 and L.gct2_ctx_force_direct(b.handle, 1) == 0
+    assert L.gct2_ctx_set_workspace(None, None, 0) == 1                                                    # null ctx
+    for name in ("gct2_set_workspace", "gct2_set_wgrad_workspace", "gct2_debug_tapgemm_variant", "gct2_debug_force_direct"):
+        assert not hasattr(L, name), name                           # the process-wide hooks of ABI v10 are gone
+    del a, b
 
 
 def test_product_path_fails_loudly_without_device_or_library(monkeypatch):

@@ -68,24 +68,32 @@ def test_golden_tiny_step_fp32(gpu):
 
 
 @pytest.mark.parametrize("dtype,rounding", [(1, "bf16"), (2, "f16")])
-def test_medium_step_lowp_vs_rounded_oracle(gpu, dtype, rounding):
-    """MFMA-eligible channel counts (64..128) on a small grid: exercises tapgemm + wgrad MFMA inside the plan."""
+def test_medium_step_lowp_vs_rounded_oracle(gpu, dtype, rounding, parity_log):
+    """MFMA-eligible channel counts (64..128) on a small grid: exercises tapgemm + wgrad MFMA inside the plan.
+    fp16 = the reference's mixed_precision mode: with its LossScaleOptimizer (the gradient entering the fp16 Dense output would
+    underflow otherwise), both sides at the initial scale 2^15; gradients are compared scaled."""
     cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
     params = O.init_params(cfg, seed=5)
     x, t_int, eps = O.synthetic_batch(cfg, seed=3)
-    loss_ref, pred_ref, grads_ref, _ = O.trainer_step(params, x, t_int, eps, cfg, operand_round=rounding)
-    eng = make_engine(cfg, dtype, gpu)
+    f16 = rounding == "f16"
+    loss_ref, pred_ref, grads_ref, _ = O.trainer_step(params, x, t_int, eps, cfg, operand_round=rounding,
+                                                      loss_scale=2.0 ** 15 if f16 else 1.0)
+    eng = make_engine(cfg, dtype, gpu, loss_scaling=f16)
     eng.set_params(params)
     loss = eng.train_step(torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int),
                           torch.tensor(eps, dtype=torch.float32), apply=False)
     torch.cuda.synchronize()
     b = eng.buffers(4, 32, 32)
     tol = {"bf16": (2e-3, 1e-2, 3e-2), "f16": (3e-4, 2e-3, 5e-3)}[rounding]
+    grads = eng.get_grads()
+    errs = {k: rel_l2(grads[k], grads_ref[k]) for k in grads}
+    parity_log("medium_step_" + rounding, loss_rel=abs(float(loss[0]) - loss_ref) / loss_ref,
+               pred_rel_l2=rel_l2(b.pred.cpu().numpy(), pred_ref), worst_grad_rel_l2=max(errs.values()),
+               worst_grad=max(errs, key=errs.get))
     assert abs(float(loss[0]) - loss_ref) <= tol[0] * loss_ref
     assert rel_l2(b.pred.cpu().numpy(), pred_ref) <= tol[1]
-    grads = eng.get_grads()
     for k in grads:
-        assert rel_l2(grads[k], grads_ref[k]) <= tol[2], k
+        assert errs[k] <= tol[2], (k, errs[k])
 
 
 def test_config2_bf16_vs_fp32_cpu_oracle(gpu):
@@ -218,34 +226,51 @@ def test_data_parallel_exchange_streams_single_rank(gpu):
 
 
 def test_fp16_loss_scaling_step(gpu):
-    """mixed_precision=True path (train.py:34,43-45,82-83): fp16 operands, dynamic loss scale, finite grads applied."""
-    cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
+    """mixed_precision=True path (train.py:34,43-45,82-83): fp16 operands, dynamic loss scale, finite grads applied; a skipped
+    step halves the scale and advances NEITHER the parameters NOR optimizer.iterations (so the WarmUp step and Adam's bias
+    correction of the next applied step are those of step index 1, not 2) - checked against OracleTrainer with the same skip."""
+    cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4, warm_up=3)
     params = O.init_params(cfg, seed=5)
     x, t_int, eps = O.synthetic_batch(cfg, seed=3)
-    _, _, grads_ref, _ = O.trainer_step(params, x, t_int, eps, cfg, operand_round="f16")
+    ref = O.OracleTrainer(cfg, {k: v.copy() for k, v in params.items()}, operand_round="f16", loss_scale=O.LossScaleState())
+    _, _, grads_ref, _ = O.trainer_step(params, x, t_int, eps, cfg, operand_round="f16", loss_scale=2.0 ** 15)
     eng = make_engine(cfg, 2, gpu, loss_scaling=True)
     eng.set_params(params)
     p0 = eng.get_params()
-    eng.train_step(torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32), apply=False)
+    X, T, E = torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32)
+    eng.train_step(X, T, E, apply=False)
     torch.cuda.synchronize()
     grads = eng.get_grads()
     scale, _ = eng.loss_scale()
     assert scale == 2.0 ** 15
     for k in grads:                                             # gradients are the scaled ones
-        assert rel_l2(grads[k] / scale, grads_ref[k]) <= 1e-2, k
+        assert rel_l2(grads[k], grads_ref[k]) <= 1e-2, k
     eng.check_finite(); eng.apply_adam(); eng.finish_step()
+    ref.train_step(x, t_int, eps)
     torch.cuda.synchronize()
     p1 = eng.get_params()
-    assert eng.loss_scale() == (2.0 ** 15, 1)
+    assert eng.loss_scale() == (2.0 ** 15, 1) and eng.iterations == 1 == ref.iterations
     assert any(np.abs(p1[k] - p0[k]).max() > 0 for k in p0)
-    # poison one gradient: the step must be skipped and the scale halved
-    eng.train_step(torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32), apply=False)
+    # poison one gradient: the step must be skipped, the scale halved, iterations unchanged
+    eng.train_step(X, T, E, apply=False)
     eng.arena.g[5] = float("inf")
     eng.check_finite(); eng.apply_adam(); eng.finish_step()
+    ref.loss_scale.update(False)
     torch.cuda.synchronize()
     p2 = eng.get_params()
     assert all(np.array_equal(p2[k], p1[k]) for k in p1)
-    assert eng.loss_scale() == (2.0 ** 14, 0)
+    assert eng.loss_scale() == (2.0 ** 14, 0) and eng.iterations == 1
+    # the next applied step is optimizer step index 1 on both sides (scale 2^14 now)
+    eng.train_step(X, T, E)
+    ref.train_step(x, t_int, eps)
+    torch.cuda.synchronize()
+    p3 = eng.get_params()
+    assert eng.iterations == 2 == ref.iterations and eng.loss_scale() == (2.0 ** 14, 1) and ref.loss_scale.scale == 2.0 ** 14
+    for k in p3:
+        upd, upd_ref = p3[k].astype(np.float64) - p1[k], ref.params[k].astype(np.float64) - p1[k]
+        # Adam's first updates are +-alpha-sized whatever the gradient: a wrong step index (alpha of k = 2) would be off by
+        # (3/4 lr_max vs 2/4 lr_max) x the bias-correction ratio ~ 40 %; fp16 noise flips a few signs of tiny gradients
+        assert abs(np.abs(upd).mean() / np.abs(upd_ref).mean() - 1) <= 0.05, k
 
 
 def test_checkpoint_roundtrip_continues(gpu, tmp_path):
@@ -367,20 +392,240 @@ def test_dispatch_sweep_default_vs_plain_kernels(gpu, size, batch):
     x = (torch.randint(0, 256, (batch, size, size, 3), generator=gen).float() / 128 - 1).to(gpu)
     t_int = torch.randint(1, 201, (batch,), generator=gen, dtype=torch.int32)
     eps = torch.randn(batch, size, size, 3, generator=gen)
-    L = g._lib.load()
     res = []
     for plain in (False, True):
-        L.gct2_debug_tapgemm_variant((2 | (3 << 16) | (1 << 24)) if plain else 0)
-        try:
-            eng = g.UNetEngine(topo, g.BF16, gpu, seed=5)
-            eng.overlap = not plain
-            loss = eng.train_step(x, t_int, eps, apply=False)
-            torch.cuda.synchronize()
-            res.append((float(loss[0]), eng.arena.g.clone(), eng.arena.layer_ranges))
-        finally:
-            L.gct2_debug_tapgemm_variant(0)
+        eng = g.UNetEngine(topo, g.BF16, gpu, seed=5)
+        eng.ctx.set_tuning((2 | (3 << 16) | (1 << 24)) if plain else 0)      # tile knobs are per engine (gct2_ctx)
+        eng.overlap = not plain
+        loss = eng.train_step(x, t_int, eps, apply=False)
+        torch.cuda.synchronize()
+        res.append((float(loss[0]), eng.arena.g.clone(), eng.arena.layer_ranges))
     (l0, g0, ranges), (l1, g1, _) = res
     assert np.isfinite(l0) and abs(l0 - l1) <= 2e-3 * abs(l1)
     assert bool(torch.isfinite(g0).all()) and bool(torch.isfinite(g1).all())
     errs = {k: rel_l2(g0[a:b].cpu().numpy(), g1[a:b].cpu().numpy()) for k, (a, b) in ranges.items()}
     assert rel_l2(g0.cpu().numpy(), g1.cpu().numpy()) <= 5e-2 and max(errs.values()) <= 0.15, errs
+
+
+def test_trainer_call_bf16_reference_width(gpu, parity_log):
+    """Trainer.call (train.py:223-272, the warm-up call of train.py:505-509) in the headline mode: bf16 at pixel_size 128, where
+    UpShuffle_0 has its reference width (64) and the TRAIN step reads the image through the packed copy only.  The non-training
+    call must still see the image channels of R_0 (r01 bug: they were never written there): its loss matches the rounded oracle
+    on the t_int / eps the call drew, and train_step's loss on the same draws."""
+    import gan_class_transfer2_amd as g
+    g.configure(size=32, pixel_size=128, max_size=512, octaves=3, compute_dtype="bfloat16")
+    try:
+        cfg = O.OracleConfig(size=32, pixel_size=128, max_size=512, octaves=3, batch_size=2)
+        den = g.Denoiser(seed=21)
+        tr = g.Trainer(den)
+        x = torch.tensor(O.synthetic_batch(cfg, seed=9)[0], dtype=torch.float32, device=gpu)
+        eng = tr._engine()
+        assert eng.fused_head_ok()                                 # the branch the bug lived in
+        b = eng.buffers(2, 32, 32)
+        b.R[0].fill_(float("nan"))                                 # whatever an earlier call left there must not matter
+        loss = tr(x)                                               # identity(example, trainer(example)) of train.py:507
+        torch.cuda.synchronize()
+        t_int, eps = b.t_int.cpu().numpy().astype(np.int64), b.eps.cpu().numpy().astype(np.float64)
+        params = {k: v.astype(np.float64) for k, v in eng.get_params().items()}
+        loss_ref = O.trainer_step(params, x.cpu().numpy().astype(np.float64), t_int, eps, cfg, operand_round="bf16")[0]
+        loss_step = eng.train_step(x, torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32), apply=False)
+        torch.cuda.synchronize()
+        parity_log("trainer_call_bf16_refwidth", loss_rel_vs_oracle=abs(float(loss) - loss_ref) / loss_ref,
+                   loss_rel_vs_train_step=abs(float(loss) - float(loss_step[0])) / float(loss_step[0]))
+        assert np.isfinite(float(loss)) and abs(float(loss) - loss_ref) <= 2e-3 * loss_ref
+        assert abs(float(loss) - float(loss_step[0])) <= 1e-4 * float(loss_step[0])
+    finally:
+        g.configure(size=256, pixel_size=128, max_size=512, octaves=6, compute_dtype=None)
+
+
+def test_reference_call_order_with_mixed_precision(gpu):
+    """train.py:505-517 with mixed_precision = True: trainer(example) BEFORE compile(LossScaleOptimizer(Adam(WarmUp))), then fit.
+    The engine built by the first call already carries the loss-scale state (train.py:82-83 wraps the optimizer whenever
+    mixed_precision is set), compile adopts the hyper-parameters, fit steps with fp16 operands at scale 2^15."""
+    import gan_class_transfer2_amd as g
+    from gan_class_transfer2_amd import model as M
+    g.configure(size=32, pixel_size=64, max_size=128, octaves=3, mixed_precision=True)
+    try:
+        den = g.Denoiser(seed=4)
+        tr = g.Trainer(den)
+        gen = torch.Generator().manual_seed(1)
+        ex = (torch.randint(0, 256, (4, 32, 32, 3), generator=gen).float() / 128 - 1).to(gpu)
+        l0 = g.identity(ex, tr(ex))
+        assert np.isfinite(float(l0)) and den.engine.dtype == g.F16 and den.engine.ls_state is not None
+        opt = M.default_optimizer()
+        assert isinstance(opt, g.LossScaleOptimizer)
+        tr.compile(opt, g.identity)
+        hist = tr.fit(iter([(ex, ex)] * 4), steps_per_epoch=4, epochs=1, verbose=0)
+        assert np.isfinite(hist["loss"][0]) and den.engine.loss_scale()[0] == 2.0 ** 15
+        assert den.engine.iterations == 4 == opt.iterations
+        # and the other way round: a plain Adam after a mixed-precision warm-up call drops the (still unused) loss scaling
+        den2 = g.Denoiser(seed=4); tr2 = g.Trainer(den2)
+        tr2(ex)
+        tr2.compile(g.Adam(g.WarmUp(2e-5, 10)), g.identity)
+        assert den2.engine.ls_state is None
+    finally:
+        g.configure(size=256, pixel_size=128, max_size=512, octaves=6, mixed_precision=False)
+
+
+def test_config1_shape_reference_width_vs_rounded_oracle(gpu, parity_log):
+    """BASELINE config 1's shape (3x32x32, bs 8, octaves 5) on the REFERENCE widths (pixel_size 128, max_size 512: 512-channel
+    layers, split-K bottleneck, fused bias gradients, matrix-core head) in bf16 against the oracle with the same rounding model:
+    loss 2e-3, prediction 1e-2, EVERY gradient tensor 3e-2 (bias gradients included); then two optimizer steps against
+    OracleTrainer: Adam slots m (linear in the gradients) per tensor, and the parameters."""
+    cfg = O.OracleConfig(size=32, pixel_size=128, max_size=512, octaves=5, batch_size=8)
+    params = O.init_params(cfg, seed=31)
+    rng = np.random.default_rng(5)
+    for k in params:                                              # non-zero biases: the bias path carries signal
+        if k.endswith(".b"):
+            params[k] = (rng.standard_normal(params[k].shape) * 0.02).astype(np.float32).astype(np.float64)
+    x, t_int, eps = O.synthetic_batch(cfg, seed=3)
+    loss_ref, pred_ref, grads_ref, _ = O.trainer_step(params, x, t_int, eps, cfg, operand_round="bf16")
+    eng = make_engine(cfg, 1, gpu)
+    eng.set_params(params)
+    X, T, E = torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32)
+    loss = eng.train_step(X, T, E, apply=False)
+    torch.cuda.synchronize()
+    b = eng.buffers(8, 32, 32)
+    grads = eng.get_grads()
+    errs = {k: rel_l2(grads[k], grads_ref[k]) for k in grads}
+    rec = dict(loss_rel=abs(float(loss[0]) - loss_ref) / loss_ref, pred_rel_l2=rel_l2(b.pred.cpu().numpy(), pred_ref))
+    rec.update({"grad_rel_l2/" + k: v for k, v in errs.items()})
+    assert rec["loss_rel"] <= 2e-3 and rec["pred_rel_l2"] <= 1e-2
+    # two optimizer steps (fused per-layer Adam, slab gradients) vs the oracle's trainer
+    ref = O.OracleTrainer(cfg, {k: v.copy() for k, v in params.items()}, operand_round="bf16")
+    eng.set_params(params)
+    for step in range(2):
+        xs, ts, es = O.synthetic_batch(cfg, seed=10 + step)
+        ref.train_step(xs, ts, es)
+        eng.train_step(torch.tensor(xs, dtype=torch.float32, device=gpu), torch.tensor(ts), torch.tensor(es, dtype=torch.float32))
+    torch.cuda.synchronize()
+    assert eng.iterations == 2
+    m_err = {k: rel_l2(eng.arena.slot_m(k).cpu().numpy(), ref.m[k]) for k in grads}
+    p_err = {k: rel_l2(eng.arena.param(k).cpu().numpy(), ref.params[k]) for k in grads}
+    rec.update({"adam_m_rel_l2_after_2_steps/" + k: v for k, v in m_err.items()})
+    rec["param_rel_l2_after_2_steps_max"] = max(p_err.values())
+    parity_log("config1_shape_reference_width_bf16", **rec)
+    for k in grads:
+        assert errs[k] <= 3e-2, (k, errs[k])
+        assert m_err[k] <= 3e-2, (k, m_err[k])
+        assert p_err[k] <= 2e-6, (k, p_err[k])                    # |update| <= 2 alpha ~ 2e-8 per element on O(1e-2) weights
+
+
+def test_config5_fp16_loss_scaling_at_size(gpu, parity_log):
+    """BASELINE config 5: 3x256x256, bs 16, fp16 + dynamic loss scaling, reference topology.
+    (a) full batch: finite loss, no overflow at the initial scale 2^15 (scale and step counter as after an applied step);
+    (b) default dispatch vs the plainest kernels on the full batch: scaled gradients agree to the fp16 noise level;
+    (c) a 2-image slice at 256^2 against the f16-rounded oracle (mixed_float16 rounding points, loss scale 2^15):
+        loss, prediction, every scaled gradient."""
+    import gan_class_transfer2_amd as g
+    topo = g.Topology(128, 512, 6)
+    cfg = O.OracleConfig(size=256, batch_size=16, octaves=6)
+    gen = torch.Generator().manual_seed(55)
+    x = (torch.randint(0, 256, (16, 256, 256, 3), generator=gen).float() / 128 - 1).to(gpu)
+    t_int = torch.randint(1, 201, (16,), generator=gen, dtype=torch.int32)
+    eps = torch.randn(16, 256, 256, 3, generator=gen)
+    res = []
+    for plain in (False, True):
+        eng = g.UNetEngine(topo, g.F16, gpu, seed=7, loss_scaling=True)
+        if plain:
+            eng.ctx.set_tuning(2 | (3 << 16) | (1 << 24))
+            eng.overlap = False
+        loss = eng.train_step(x, t_int, eps, apply=False)
+        torch.cuda.synchronize()
+        res.append((float(loss[0]), eng.arena.g.clone(), eng))
+    (l0, g0, eng), (l1, g1, _) = res
+    assert np.isfinite(l0) and l0 > 0 and bool(torch.isfinite(g0).all()) and bool(torch.isfinite(g1).all())      # (a)
+    assert abs(l0 - l1) <= 1e-3 * l1
+    errs = {k: rel_l2(g0[a:b].cpu().numpy(), g1[a:b].cpu().numpy()) for k, (a, b) in eng.arena.layer_ranges.items()}
+    whole = rel_l2(g0.cpu().numpy(), g1.cpu().numpy())
+    eng.check_finite(); eng.apply_adam(); eng.finish_step()
+    torch.cuda.synchronize()
+    assert eng.loss_scale() == (2.0 ** 15, 1) and eng.iterations == 1                                              # (a)
+    assert whole <= 2e-2 and max(errs.values()) <= 0.1, (whole, errs)                                               # (b)
+    # (c) 2-image slice against the oracle
+    cfg2 = O.OracleConfig(size=256, batch_size=2, octaves=6)
+    params = {k: v.astype(np.float64) for k, v in eng.get_params().items()}     # the parameters after the step above
+    xs, ts, es = x[:2].cpu().numpy().astype(np.float64), t_int[:2].numpy().astype(np.int64), eps[:2].numpy().astype(np.float64)
+    loss_ref, pred_ref, grads_ref, _ = O.trainer_step(params, xs, ts, es, cfg2, operand_round="f16", loss_scale=2.0 ** 15)
+    loss2 = eng.train_step(x[:2].contiguous(), t_int[:2].contiguous(), eps[:2].contiguous(), apply=False)
+    torch.cuda.synchronize()
+    b = eng.buffers(2, 256, 256)
+    grads = eng.get_grads()
+    gerr = {k: rel_l2(grads[k], grads_ref[k]) for k in grads}
+    rec = dict(loss_full_batch=l0, default_vs_plain_whole_grad_rel_l2=whole, default_vs_plain_worst_layer=max(errs.values()),
+               slice_loss_rel=abs(float(loss2[0]) - loss_ref) / loss_ref, slice_pred_rel_l2=rel_l2(b.pred.cpu().numpy(), pred_ref),
+               slice_worst_grad_rel_l2=max(gerr.values()), slice_worst_grad=max(gerr, key=gerr.get))
+    parity_log("config5_fp16_256x256", **rec)
+    assert rec["slice_loss_rel"] <= 1e-3 and rec["slice_pred_rel_l2"] <= 3e-3
+    for k in grads:
+        assert gerr[k] <= 2e-2, (k, gerr[k])
+
+
+def test_two_engines_on_two_streams_are_independent(gpu):
+    """ABI v11: scratch and tile knobs live in a caller-owned gct2_ctx per engine, the library has no process-wide state.  Two
+    engines step concurrently on two streams (their launches interleave on the host and overlap on the device, each with its
+    own split-K slabs / partial rows); each ends bit-identical to the same engine stepping alone."""
+    import gan_class_transfer2_amd as g
+    topo = g.Topology(128, 512, 4)                               # 512-channel bottleneck: split-K slabs and slab-fed Adam in use
+    gen = torch.Generator().manual_seed(12)
+    data = [[(torch.randint(0, 256, (8, 32, 32, 3), generator=gen).float() / 128 - 1).to(gpu) for _ in range(3)] for _ in range(2)]
+    ts = [[torch.randint(1, 201, (8,), generator=gen, dtype=torch.int32) for _ in range(3)] for _ in range(2)]
+    es = [[torch.randn(8, 32, 32, 3, generator=gen) for _ in range(3)] for _ in range(2)]
+
+    def fresh(i):
+        eng = g.UNetEngine(topo, g.BF16, gpu, seed=100 + i)
+        if i == 1:
+            eng.ctx.set_tuning(2 | (3 << 16))                    # the second engine even uses other tiles: knobs are per ctx
+        return eng
+
+    alone = []
+    for i in range(2):
+        eng = fresh(i)
+        for k in range(3):
+            eng.train_step(data[i][k], ts[i][k], es[i][k])
+        torch.cuda.synchronize()
+        alone.append({n: getattr(eng.arena, n).clone() for n in ("p", "m", "v")})
+    engines = [fresh(0), fresh(1)]
+    streams = [torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)]
+    torch.cuda.synchronize()
+    for k in range(3):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                engines[i].train_step(data[i][k], ts[i][k], es[i][k])
+    torch.cuda.synchronize()
+    for i in range(2):
+        lo, hi = engines[i].arena.layer_ranges["D0"]             # the 3-channel layer's weight gradient adds with fp32 atomics
+        det = torch.ones(engines[i].arena.total, dtype=torch.bool, device=gpu)
+        det[lo:hi] = False
+        for n in ("p", "m", "v"):
+            assert torch.equal(getattr(engines[i].arena, n)[det], alone[i][n][det]), (i, n)
+
+
+def test_checkpoint_format_is_pinned_to_the_oracle_fixture(gpu):
+    """state_dict layout against oracle-produced state: parameters, Adam slots and the step counter after TWO oracle steps
+    (tests/golden/tiny_step.npz: param2 / m2 / v2, iterations = 2) are loaded through load_state_dict; step 3 on the engine
+    must be the oracle's step 3 (loss3 / param3) - i.e. names, arena offsets, slot order and the counter mean what the
+    oracle means by them."""
+    z = np.load(GOLDEN)
+    cfg = O.OracleConfig(size=16, pixel_size=8, max_size=16, octaves=2, batch_size=2)
+    eng = make_engine(cfg, 0, gpu)
+    A = eng.arena
+    sd = eng.state_dict()
+    for arena, tag in (("arena.p", "param2/"), ("arena.m", "m2/"), ("arena.v", "v2/")):
+        flat = torch.zeros(A.total, dtype=torch.float32)
+        for name in A.shapes:
+            o = A.offsets[name]
+            flat[o:o + A.numel(name)] = torch.tensor(z[tag + name], dtype=torch.float32).reshape(-1)
+        sd[arena] = flat
+    sd["counters"] = torch.tensor([2, eng.rng_seed, 0, 0], dtype=torch.int64)
+    eng.load_state_dict(sd)
+    assert eng.iterations == 2
+    xs, ts, es = O.synthetic_batch(cfg, seed=2)
+    loss = eng.train_step(torch.tensor(xs, dtype=torch.float32, device=gpu), torch.tensor(ts), torch.tensor(es, dtype=torch.float32))
+    torch.cuda.synchronize()
+    assert eng.iterations == 3 and abs(float(loss[0]) - float(z["loss3"])) <= 1e-5 * float(z["loss3"])
+    for k in A.shapes:
+        upd = eng.arena.param(k).cpu().numpy().astype(np.float64) - z["param2/" + k]
+        upd_ref = z["param3/" + k].astype(np.float64) - z["param2/" + k]
+        assert rel_l2(eng.arena.param(k).cpu().numpy(), z["param3/" + k]) <= 1e-6, k
+        assert rel_l2(upd, upd_ref) <= 5e-3, k                   # the step-3 update itself (a wrong counter changes alpha by 20 %)
