@@ -68,6 +68,7 @@ __global__ void rng_normal_kernel(uint64_t seed, uint64_t stream_id, uint64_t of
 template <typename T> struct NoiseCoef {
   float sa, sb;
   __device__ __forceinline__ NoiseCoef(int t_int, int steps1) {
+#pragma clang fp contract(off)      // every fp16 operation rounds on its own (no fused multiply-add): that IS the model
     if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) {
       const _Float16 t = (_Float16)((_Float16)(float)t_int / (_Float16)(float)steps1);
       const _Float16 om = (_Float16)1.0f - t;
@@ -81,6 +82,7 @@ template <typename T> struct NoiseCoef {
     }
   }
   __device__ __forceinline__ T mix(float x, float eps) const {
+#pragma clang fp contract(off)
     if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) {
       const _Float16 xs = (_Float16)x * (_Float16)sa, es = (_Float16)eps * (_Float16)sb;     // x is exact in fp16 (u8/128 - 1)
       return (T)(xs + es);

@@ -201,13 +201,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
         for (int j = 0; j < MF; j++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
     }
   };
+  // `live` is always true (ksplit >= 1) but opaque to hipcc: a code-generation fence.  With the multiplies unconditional the
+  // unrolled steps of a trip are merged into one scheduling region and the register allocator spills (wgrad256p_kernel: 440
+  // spilled registers, 10x slower; here: the 256 x 256 and three-buffer variants); behind the guard each step stays its own region.
+  const bool live = p.ksplit > 0;
   if constexpr (NBUF == 1) {
     // one LDS buffer (32 KiB): no overlap inside a work-group; 4 work-groups per CU cover each other instead
     for (int it = it_lo; it < it_hi; it++) {
       issue(it, lds0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      compute(lds0);
+      if (live) compute(lds0);
       __syncthreads();
     }
   } else if constexpr (NBUF == 2) {
@@ -216,12 +220,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     __syncthreads();
     for (int it = it_lo; it < it_hi; it += 2) {    // two steps per trip: buffer roles are compile-time
       if (it + 1 < it_hi) issue(it + 1, lds1);
-      compute(lds0);
+      if (live) compute(lds0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (it + 1 >= it_hi) break;
       if (it + 2 < it_hi) issue(it + 2, lds0);
-      compute(lds1);
+      if (live) compute(lds1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -232,7 +236,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     auto step = [&](int it, const char* cur, char* tgt) {
       const bool more = it + 2 < it_hi;
       if (more) issue(it + 2, tgt);
-      compute(cur);
+      if (live) compute(cur);
       if (more) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(NDMA));   // the builtin (not asm) so hipcc's own vmcnt bookkeeping sees it
       else __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(0));
       __builtin_amdgcn_s_barrier();

@@ -158,13 +158,17 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
   //   otherwise          : fp32 atomics
   float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
+  // an opaque copy of the lane id: keeps hipcc from hoisting the output addresses of all tiles above the reduction loop, where
+  // they would occupy registers for the whole kernel
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int row = gc0 + wm * 64 + i * 16 + (lane & 15);
+    const int row = gc0 + wm * 64 + i * 16 + (elane & 15);
     if (row >= GC) continue;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int col = cs0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      const int col = cs0 + wn * 64 + j * 16 + 4 * (elane >> 4);
       if (col >= Cs) continue;                         // Cs is a multiple of 8: a 4-column group is inside or outside as a whole
       float* q = out + (size_t)row * Cs + col;
       if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
@@ -294,13 +298,17 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(WgradParams p) {
   }
   float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
+  // an opaque copy of the lane id: keeps hipcc from hoisting the 32 tiles' output addresses above the reduction loop (they would
+  // occupy ~64 registers for the whole kernel: 440 spilled registers and a 10x slower kernel, measured r02)
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const int row = gc0 + wm * 128 + i * 16 + (lane & 15);
+    const int row = gc0 + wm * 128 + i * 16 + (elane & 15);
     if (row >= GC) continue;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int col = cs0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      const int col = cs0 + wn * 64 + j * 16 + 4 * (elane >> 4);
       if (col >= Cs) continue;
       float* q = out + (size_t)row * Cs + col;
       if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
@@ -410,21 +418,28 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
   auto compute = [&](const char* base) {
     const char* bimg = base + wm * IMG;
     const char* simg = base + (2 + (wn >> 1)) * IMG;
+    // an opaque copy of the lane id: otherwise the fragment addresses of all four unrolled stages (4 buffers x 12 fragments) are
+    // loop-invariant, get hoisted above the pipeline loop and spill (462 VGPRs of scratch, 10x slower: measured r02)
+    int ql = lane;
+    asm volatile("" : "+v"(ql));
     u32x4_t sf[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) sf[j] = timg_frag(simg, (wn & 1) * 64 + j * 16, 0, lane);
+    for (int j = 0; j < 4; j++) sf[j] = timg_frag(simg, (wn & 1) * 64 + j * 16, 0, ql);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      const u32x4_t bf = timg_frag(bimg, i * 16, 0, lane);
+      const u32x4_t bf = timg_frag(bimg, i * 16, 0, ql);
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(sf[j], bf, acc[i][j]);
     }
   };
 
-  // stage s: issue s+3, multiply s, wait until only the DMAs of the stages beyond s+1 are outstanding, barrier
+  // stage s: issue s+3, multiply s, wait until only the DMAs of the stages beyond s+1 are outstanding, barrier.
+  // `live` is always true (rsplit >= 1) but opaque to hipcc: with the multiply unconditional the four unrolled stages are merged
+  // into one region whose live ranges no longer fit (256 VGPRs + 440 spilled, 10x slower; behind the guard: 176 VGPRs, no spill).
+  const bool live = p.rsplit > 0;
   auto stage = [&](int st, const char* cur, char* tgt) {
     if (st + 3 < st_hi) issue(st + 3, tgt);
-    compute(cur);
+    if (live) compute(cur);
     if (st + 3 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
     else if (st + 2 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
     else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
@@ -448,13 +463,17 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
   }
   float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
+  // an opaque copy of the lane id: keeps hipcc from hoisting the 32 tiles' output addresses above the reduction loop (they would
+  // occupy ~64 registers for the whole kernel: 440 spilled registers and a 10x slower kernel, measured r02)
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const int row = gc0 + wm * 128 + i * 16 + (lane & 15);
+    const int row = gc0 + wm * 128 + i * 16 + (elane & 15);
     if (row >= GC) continue;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int col = cs0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      const int col = cs0 + wn * 64 + j * 16 + 4 * (elane >> 4);
       if (col >= Cs) continue;
       float* q = out + (size_t)row * Cs + col;
       if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
