@@ -11,6 +11,8 @@ int tapgemm_direct(int dtype, int form, int epi, const TapGemmParams& p, hipStre
 bool wgrad_mfma_supported(int dtype, const WgradParams& p);
 int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer);
 int wgrad_direct(int dtype, const WgradParams& p, hipStream_t s);
+bool halo_head_supported(const gct2_ctx& c, int dtype, const TapGemmParams& p);
+int halo_head(const gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, float* loss, float* db_up, int accumulate, hipStream_t s);
 bool rgb_fwd_supported(int dtype, const TapGemmParams& p);
 int rgb_fwd(int dtype, const TapGemmParams& p, hipStream_t s);
 bool rgb_wgrad_supported(int dtype, const WgradParams& p);
@@ -212,6 +214,26 @@ int gct2_convT4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const vo
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_fwd: ld smaller than channel count");
   TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H, W, Cin, Cout, relu, 0};
   return run_tapgemm(C(ctx), dtype, FORM_CONVT, EPI_BIAS_ACT, p, stream);
+}
+
+int gct2_convT4s2_fwd_head_train(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, const float* head_w,
+                                 const float* head_b, const float* target, float* pred, void* dy, int lddy, float* head_dw, float* head_db,
+                                 float* loss, int B, int H, int W, int Cin, int Cout, int head_Cin, int head_Cout,
+                                 const float* loss_scale_ptr, float* db, const void* x2, int ldx2, int accumulate, void* stream) {
+  if (int e = check_conv_args("convT4s2_fwd_head_train", dtype, x, w, dy, B, 2 * H, 2 * W, Cin, Cout)) return e;
+  if (!head_w || !target || !head_dw || !loss) return gct2_fail(GCT2_EINVAL, "convT4s2_fwd_head_train: null pointer");
+  if (ldx < Cin || lddy < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_fwd_head_train: ld smaller than channel count");
+  const int nimg = head_Cin - Cout;
+  if (head_Cout < 1 || head_Cout > 3 || nimg < 0 || nimg > 3 || (nimg > 0 && (!x2 || ldx2 < 4 || ldx2 % 4 || (uintptr_t)x2 % 8)))
+    return gct2_fail(GCT2_EINVAL, "convT4s2_fwd_head_train: head needs <= 3 outputs and <= 3 image channels in a packed x2 (8-byte rows)");
+  const gct2_ctx& c = C(ctx);
+  TapGemmParams p{x, ldx, w, bias, nullptr, 0, dy, lddy, B, H, W, Cin, Cout, 1, 0};
+  p.head = HeadFuse{head_w, head_b, target, pred, x2, ldx2, nullptr, loss_scale_ptr, head_Cin, head_Cout,
+                    (float)((double)B * 2 * H * 2 * W * head_Cout)};
+  if (c.force_direct || !halo_head_supported(c, dtype, p))
+    return gct2_fail(GCT2_EINVAL, "convT4s2_fwd_head_train: needs a 16-bit dtype, Cout = 64, H and W multiples of 16, 16-byte aligned views "
+                                  "and a ctx workspace of B*(H/16)*(W/16)*288 floats");
+  return halo_head(c, dtype, p, head_dw, head_db, loss, db, accumulate, S(stream));
 }
 
 int gct2_convT4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,

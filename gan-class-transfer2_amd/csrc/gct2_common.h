@@ -108,7 +108,29 @@ template <typename T> __device__ __forceinline__ float unpack_hi(uint32_t u) {
 // FORM_CONVT: out on the BIG grid, one launch-z per output parity phase, source on the SMALL grid,
 //             4 taps per phase, weights [tap][n][k]   (Conv2DTranspose forward, Conv2D input-gradient)
 enum { FORM_CONV = 0, FORM_CONVT = 1 };
-enum { EPI_BIAS_ACT = 0, EPI_MASK = 1 };
+enum { EPI_BIAS_ACT = 0, EPI_MASK = 1, EPI_HEAD = 2 };
+
+// Keras' mixed_float16 policy (train.py:43-45) makes the Dense output and the gradient entering it fp16 tensors; the loss is
+// taken on the fp16 values cast to fp32 (train.py:262-263).  GCT2_F16 reproduces those two rounding points; fp32 / bf16 keep fp32.
+template <typename T> __device__ __forceinline__ float keras_f16_point(float v) {
+  if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) return (float)(_Float16)v;
+  else return v;
+}
+
+// EPI_HEAD (halo kernel, UpShuffle_0 forward of the train step): the Dense(3) head + fp32 MSE + both of their gradients are
+// evaluated in the epilogue on the activations the work-group has just produced (train.py:198-202, 262-272), which are then
+// never written to HBM; the output view receives the pre-activation gradient of the layer instead.
+constexpr int HEAD_ROW = 288;       // partial row: [0,216) dW (c*Cout+o) | [216,219) db | 219 loss | [224,288) db of the layer below
+struct HeadFuse {
+  const float* w; const float* b;   // Dense kernel (Cin x Cout) and bias, fp32
+  const float* target;              // fp32 [pixels][Cout]
+  float* pred;                      // fp32 [pixels][Cout] or null
+  const void* x2; int ldx2;         // input channels [N, Cin) of the head (the packed image), compute dtype
+  float* part;                      // [work-groups][HEAD_ROW] partial rows
+  const float* loss_scale;          // device scalar or null
+  int Cin, Cout;                    // head input channels (N + image channels), outputs (<= 3)
+  float count;                      // pixels * Cout (the mean of the loss)
+};
 
 struct TapGemmParams {
   const void* x; int ldx;        // source activations / gradients
@@ -125,6 +147,7 @@ struct TapGemmParams {
   float* db; int db_split; float* db2;   // EPI_MASK: bias-gradient targets (column sums of the masked result), may be null
   int db_acc;                            // bit 0: db is added to (else overwritten); bit 1: the same for db2
   float* dbws;                           // partial bias-gradient rows [m_tiles*phases | finalize rows][N] in the workspace, or null (atomics)
+  HeadFuse head;                         // EPI_HEAD only
 };
 
 // XCD-aware work-group -> tile map.  The dispatcher deals consecutive work-group ids round-robin over the 8

@@ -185,6 +185,169 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   int elane = lane;
   asm volatile("" : "+v"(elane));                              // keeps the output addresses out of the K loop
   const int eq = elane & 15, eg = elane >> 4;
+  if constexpr (EPI == EPI_HEAD) {
+    // ---- UpShuffle_0 forward + Dense(3) head + fp32 MSE + both gradients (train.py:188, 198-202, 262-272) ------------------
+    // A wave holds ALL N = 64 channels of its 128 pixels (the 4 lane groups g of a pixel column q carry 16 channels each), so the
+    // head runs on the accumulators: y = relu(acc + bias) rounded to the storage type (the value the unfused path would have
+    // written to R_0), pred = [y, image] Wd + bd, d = pred - target, the loss, and dR_0 = (y > 0) * dpred Wd^T - the only tensor
+    // this epilogue stores.  Dense kernel / bias gradients, the loss and UpShuffle_0's bias gradient leave as ONE partial row
+    // per work-group (HEAD_ROW floats) for the ordered finish kernel of the head.
+    const HeadFuse& hd = p.head;
+    const int Cout = hd.Cout;
+    // Register budget: 128 accumulators + 64 gradient sums of the head do not fit 256 registers.  The head only needs the
+    // ACTIVATIONS (16-bit after rounding): all of them are parked in LDS first - idle after the K loop - as sixteen 8-KiB slots
+    // (slot (j, ip) = 512 lanes x 16 bytes = 8 channels of patch row j, conflict-free), which frees every accumulator; the head
+    // then walks the rows in a real loop, each lane reading back exactly what it wrote.
+    auto park = [&](int slot) -> char* {
+      return slot < 5 ? halo0 + slot * 8192 : slot < 10 ? halo1 + (slot - 5) * 8192 : slot < 14 ? wb0 + (slot - 10) * 8192
+                                                                                               : wb1 + (slot - 14) * 8192;
+    };
+    float* hw = reinterpret_cast<float*>(wb1 + 16384);    // [68][4] Dense kernel (column 3 zero), then [64] layer bias
+    float* hbias = hw + 68 * 4;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+      for (int ip = 0; ip < 2; ip++) {
+        const f32x4_t b0 = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + 32 * ip + 8 * eg) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const f32x4_t b1 = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + 32 * ip + 8 * eg + 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const f32x4_t v0 = acc[2 * ip][j] + b0, v1 = acc[2 * ip + 1][j] + b1;
+        const u32x4_t o = {pack2<T>(fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f)), pack2<T>(fmaxf(v0[2], 0.f), fmaxf(v0[3], 0.f)),
+                           pack2<T>(fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f)), pack2<T>(fmaxf(v1[2], 0.f), fmaxf(v1[3], 0.f))};
+        *reinterpret_cast<u32x4_t*>(park(2 * j + ip) + tid * 16) = o;           // what R_0 would hold
+      }
+    for (int i = tid; i < 68 * 4; i += 512) {
+      const int c = i >> 2, o = i & 3;
+      hw[i] = (c < hd.Cin && o < Cout) ? hd.w[c * Cout + o] : 0.f;
+    }
+    __syncthreads();
+    const float gscale = (hd.loss_scale ? *hd.loss_scale : 1.f) * 2.0f / hd.count;
+    float bd[3];
+#pragma unroll
+    for (int o = 0; o < 3; o++) bd[o] = (hd.b && o < Cout) ? hd.b[o] : 0.f;
+    const T* __restrict__ x2 = reinterpret_cast<const T*>(hd.x2);
+    float wacc[16][3];                                     // dW[this lane's channel c][o] over its pixels
+    float bacc[16];                                        // column sums of dR_0 (UpShuffle_0's bias gradient)
+    // wx: lane group 0 sums dpred (the Dense bias gradient), lane groups 1..3 the Dense kernel gradient of image channel g-1
+    float wx[3] = {0.f, 0.f, 0.f}, lacc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; c++) { bacc[c] = 0.f; wacc[c][0] = wacc[c][1] = wacc[c][2] = 0.f; }
+    const int imc = eg - 1;                                // this lane group's image channel (-1: none)
+    const bool im_ok = imc >= 0 && 64 + imc < hd.Cin && x2 != nullptr;
+    // lane-local channel c = 8 ip + k  <->  channel 32 ip + 8 eg + k of the layer
+    // the per-pixel inputs of row j + 1 (target, packed image) are loaded while row j is processed: with two waves per SIMD a
+    // dependent global load in every row would be most of the epilogue
+    auto row_pix = [&](int j) {
+      const int sh = sh0 + mhalf * 8 + j, sw = sw0 + eq;
+      return ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
+    };
+    float tg_n[3] = {0.f, 0.f, 0.f};
+    u32x2_t im_n = {0u, 0u};
+    auto prefetch = [&](int j) {
+      const size_t px = row_pix(j);
+#pragma unroll
+      for (int o = 0; o < 3; o++) tg_n[o] = o < Cout ? hd.target[px * Cout + o] : 0.f;
+      if (im_ok) im_n = *reinterpret_cast<const u32x2_t*>(x2 + px * hd.ldx2);
+    };
+    prefetch(0);
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+      const size_t opix = row_pix(j);
+      const float tg[3] = {tg_n[0], tg_n[1], tg_n[2]};
+      const u32x2_t v2 = im_n;
+      if (j < 7) prefetch(j + 1);
+      float yq[16];
+#pragma unroll
+      for (int ip = 0; ip < 2; ip++) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(park(2 * j + ip) + tid * 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { yq[8 * ip + 2 * k] = unpack_lo<T>(v[k]); yq[8 * ip + 2 * k + 1] = unpack_hi<T>(v[k]); }
+      }
+      float s3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(hw + 4 * (32 * (c >> 3) + 8 * eg + (c & 7)));
+        s3[0] = fmaf(yq[c], w4[0], s3[0]); s3[1] = fmaf(yq[c], w4[1], s3[1]); s3[2] = fmaf(yq[c], w4[2], s3[2]);
+      }
+      float mult = eg == 0 ? 1.f : 0.f;                    // multiplier of dsc in wx
+      if (im_ok) {                                         // image channel N + imc from the packed copy
+        mult = imc == 0 ? unpack_lo<T>(v2[0]) : (imc == 1 ? unpack_hi<T>(v2[0]) : unpack_lo<T>(v2[1]));
+        const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(hw + 4 * (64 + imc));
+        s3[0] = fmaf(mult, w4[0], s3[0]); s3[1] = fmaf(mult, w4[1], s3[1]); s3[2] = fmaf(mult, w4[2], s3[2]);
+      }
+      float dsc[3];
+#pragma unroll
+      for (int o = 0; o < 3; o++) {
+        float t = s3[o];
+        t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);      // the pixel's four lane groups
+        const float pr = keras_f16_point<T>(t + bd[o]);
+        const float d = o < Cout ? pr - tg[o] : 0.f;
+        if (eg == 0 && o < Cout) {
+          if (hd.pred) hd.pred[opix * Cout + o] = pr;
+          lacc = fmaf(d, d, lacc);
+        }
+        dsc[o] = keras_f16_point<T>(d * gscale);
+        wx[o] = fmaf(mult, dsc[o], wx[o]);
+      }
+#pragma unroll
+      for (int ip = 0; ip < 2; ip++) {
+        float gv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int c = 8 * ip + k;
+          const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(hw + 4 * (32 * ip + 8 * eg + k));
+          float gch = dsc[0] * w4[0] + dsc[1] * w4[1] + dsc[2] * w4[2];
+          if (!(yq[c] > 0.f)) gch = 0.f;
+          gv[k] = gch;
+          bacc[c] += gch;
+          wacc[c][0] = fmaf(yq[c], dsc[0], wacc[c][0]);
+          wacc[c][1] = fmaf(yq[c], dsc[1], wacc[c][1]);
+          wacc[c][2] = fmaf(yq[c], dsc[2], wacc[c][2]);
+        }
+        const u32x4_t o = {pack2<T>(gv[0], gv[1]), pack2<T>(gv[2], gv[3]), pack2<T>(gv[4], gv[5]), pack2<T>(gv[6], gv[7])};
+        *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + 32 * ip + 8 * eg) = o;
+      }
+    }
+    __syncthreads();                                       // every wave is done with its parked rows
+    float* red = reinterpret_cast<float*>(halo0);          // [8][HEAD_ROW]
+    for (int i = tid; i < 8 * HEAD_ROW; i += 512) red[i] = 0.f;
+    __syncthreads();
+    auto bfly = [](float t) {
+      t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+      return t;
+    };
+    float* rw = red + wave * HEAD_ROW;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const int ch = 32 * (c >> 3) + 8 * eg + (c & 7);
+#pragma unroll
+      for (int o = 0; o < 3; o++) {
+        const float t = bfly(wacc[c][o]);
+        if (eq == 0 && o < Cout) rw[ch * Cout + o] = t;
+      }
+      const float tb = bfly(bacc[c]);
+      if (eq == 0) rw[224 + ch] = tb;
+    }
+#pragma unroll
+    for (int o = 0; o < 3; o++) {
+      const float t = bfly(wx[o]);
+      if (eq == 0 && o < Cout) {
+        if (eg == 0) rw[216 + o] = t;
+        else if (im_ok) rw[(64 + imc) * Cout + o] = t;
+      }
+    }
+    {
+      const float t = bfly(lacc);
+      if (elane == 0) rw[219] = t;
+    }
+    __syncthreads();
+    if (tid < HEAD_ROW) {
+      float t = red[tid];
+#pragma unroll
+      for (int k = 1; k < 8; k++) t += red[k * HEAD_ROW + tid];
+      hd.part[(size_t)m_tile * HEAD_ROW + tid] = t;
+    }
+    return;
+  }
   f32x4_t bsum[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) bsum[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -281,6 +444,33 @@ bool halo_convT_wanted(const gct2_ctx& c, int epi, const TapGemmParams& p) {
   // automatic: layers whose source-tile traffic dominates (few output channels per pixel) and that fill the chip
   const int tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4) * ((p.N + 63) / 64);
   return p.N <= 256 && tiles >= 256;          // measured vs tapgemm: U0 fwd 177 -> 136 us, U1 fwd 126 -> 120, U2 fwd 124 -> 122, D1 dgrad 88 -> 81, D2 dgrad 70 -> 66
+}
+
+int pw_head_finish(const float* part, int rows, float* dw, float* db, float* loss, float* db_dx, int ndw, int Cout, float inv_n,
+                   int accumulate, hipStream_t s);     // pointwise.hip
+
+// UpShuffle_0 forward with the train-step head in its epilogue (EPI_HEAD): needs N = 64 (one n-tile: a wave owns every channel
+// of its pixels), the shape constraints of the halo kernel and room for one partial row per work-group in the workspace.
+bool halo_head_supported(const gct2_ctx& c, int dtype, const TapGemmParams& p) {
+  if (dtype != GCT2_BF16 && dtype != GCT2_F16) return false;
+  if (p.N != 64 || (p.Hs & 15) || (p.Ws & 15) || p.K % 8 || p.ldx % 8) return false;
+  if ((uintptr_t)p.y % 16 || p.ldy % 8 || (uintptr_t)p.x % 16 || (uintptr_t)p.w % 16) return false;
+  const size_t rows = (size_t)p.B * (p.Hs >> 4) * (p.Ws >> 4);
+  return c.ws && c.ws_bytes >= rows * HEAD_ROW * sizeof(float);
+}
+int halo_head(const gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, float* loss, float* db_up, int accumulate,
+              hipStream_t s) {
+  p.m_tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4);
+  p.n_tiles = 1;
+  p.xcd_chunk = (p.m_tiles + 7) / 8;
+  p.ksplit = 1;
+  p.dbws = nullptr;
+  p.head.part = c.ws;
+  dim3 grid(8 * p.xcd_chunk);
+  if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_HEAD>), grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_HEAD>), grid, dim3(512), 0, s, p);
+  if (int e = gct2_check_launch("halo_head")) return e;
+  return pw_head_finish(c.ws, p.m_tiles, dw, db, loss, db_up, p.head.Cin * p.head.Cout, p.head.Cout, 1.0f / p.head.count, accumulate, s);
 }
 
 int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) {

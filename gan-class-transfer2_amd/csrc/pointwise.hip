@@ -157,13 +157,7 @@ __global__ void noise_kernel(const float* __restrict__ x, const int32_t* __restr
 }
 
 // ---- Dense(3) head -------------------------------------------------------------------------------------
-// Keras' mixed_float16 policy (train.py:43-45) makes the Dense output and the gradient entering it fp16 tensors; the loss is
-// taken on the fp16 values cast to fp32 (train.py:262-263).  GCT2_F16 reproduces those two rounding points; fp32 / bf16 keep fp32.
-template <typename T> __device__ __forceinline__ float keras_f16_point(float v) {
-  if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) return (float)(_Float16)v;
-  else return v;
-}
-
+// (keras_f16_point, the mixed_float16 rounding points of the head: gct2_common.h)
 template <typename T>
 __global__ void dense_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
                                  float* __restrict__ y, int M, int Cin, int Cout) {
@@ -392,7 +386,7 @@ __global__ __launch_bounds__(256) void dense_head_train_kernel(const T* __restri
 // this lane already holds as its forward B fragments, so the ReLU mask and the 16-byte gradient store need no shuffle.
 // dW / db / db_dx / loss are accumulated per lane and leave as one partial row per work-group (HEAD_ROW floats) for
 // dense_head_finish_kernel: no atomics, fixed summation order.
-constexpr int HEAD_ROW = 288;       // [0,216) dW (c*Cout+o) | [216,219) db | 219 loss | [224,288) db of the layer below
+// partial row layout HEAD_ROW: gct2_common.h
 template <typename T>
 __global__ __launch_bounds__(256, 2) void dense_head_mfma_kernel(const T* __restrict__ x, int ld, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, const float* __restrict__ target,
@@ -932,6 +926,14 @@ int pw_dense_bwd(int dtype, const void* x, int ldx, const float* w, const float*
   if (dtype == GCT2_BF16) return dense_bwd_t<__bf16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, accumulate, s);
   return dense_bwd_t<_Float16>(x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, accumulate, s);
 }
+// the ordered finish of the head's partial rows, also used by the UpShuffle_0 forward that carries the head in its epilogue
+int pw_head_finish(const float* part, int rows, float* dw, float* db, float* loss, float* db_dx, int ndw, int Cout, float inv_n,
+                   int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(dense_head_finish_kernel, dim3(HEAD_ROW / 32), dim3(1024), 0, s, part, rows, dw, db, loss, db_dx, ndw, Cout, inv_n,
+                     accumulate);
+  return gct2_check_launch("dense_head_finish");
+}
+
 template <typename T>
 static int dense_head_train_t(const gct2_ctx& c, const void* x, int ld, const float* w, const float* b, const float* target, float* pred,
                               void* dx, int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,

@@ -162,6 +162,8 @@ class UNetEngine:
         self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
         self.loss_scaling = loss_scaling
         self.use_fused_head = True     # False: dense_fwd + mse_fwd_bwd + dense_bwd as three kernels
+        self.fuse_u0_head = True       # train step: the head runs in UpShuffle_0's forward epilogue (R_0 is never written)
+        self.keep_pred = False         # train step: also store the prediction (buffers().pred); the loss does not need it
         self.arena = ParamArena(topo, dtype, self.device)
         self.arena.glorot_init(seed)
         self.arena.refresh_shadow(self._stream())
@@ -317,9 +319,10 @@ class UNetEngine:
         b.R[0][..., t.fu(0):t.fu(0) + 3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
         b.img[..., :3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
 
-    def forward(self, b: _Buffers, head: bool = True) -> torch.Tensor:
+    def forward(self, b: _Buffers, head: bool = True, stop_before_u0: bool = False) -> torch.Tensor:
         """Denoiser.call (train.py:206-215): R_0's image slice must already hold the network input.
-        head=False stops before Dense(3) (the train step runs the fused head kernel instead)."""
+        head=False stops before Dense(3) (the train step runs the fused head kernel instead); stop_before_u0 also leaves
+        UpShuffle_0 to the caller (u0_head_train: its forward carries the head in its epilogue)."""
         t, n, s, dt, A, cx = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena, self.ctx.handle
         for i in range(n):                                      # DownShuffle_i  (train.py:184)
             H, W = b.hw[i]
@@ -335,6 +338,8 @@ class UNetEngine:
                 x, ldx = b.R[i + 1].data_ptr(), b.ld[i + 1]
             else:
                 x, ldx = b.Dlast.data_ptr(), t.fd(i)
+            if i == 0 and stop_before_u0:
+                return b.pred
             call("gct2_convT4s2_fwd", cx, dt, x, ldx, A.wptr(f"U{i}.w"), A.pptr(f"U{i}.b"), b.R[i].data_ptr(), b.ld[i],
                  b.B, Hi, Wi, t.up_in(i), t.fu(i), 1, s)
         if not head:
@@ -361,9 +366,31 @@ class UNetEngine:
         t, A = self.topo, self.arena
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
         call("gct2_dense_head_train", self.ctx.handle, self.dtype, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"),
-             target.data_ptr(), b.pred.data_ptr(), b.dR[0].data_ptr(), b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"),
+             target.data_ptr(), b.pred.data_ptr() if self.keep_pred else None, b.dR[0].data_ptr(), b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"),
              b.loss.data_ptr(), b.partials.data_ptr(), b.B * b.H * b.W, t.fu(0) + 3, 3, t.fu(0), ls_ptr, A.gptr("U0.b"),
              b.img.data_ptr(), 4, 0, self._stream())
+        return b.loss
+
+    def fused_u0_head_ok(self, b: _Buffers) -> bool:
+        """UpShuffle_0's forward with the head in its epilogue (gct2_convT4s2_fwd_head_train): the fused head's conditions plus
+        UpShuffle_0's source grid tiling into 16 x 16 patches and one partial row per patch in the workspace."""
+        if not (self.fuse_u0_head and self.fused_head_ok() and self.topo.octaves >= 1):
+            return False
+        Hs, Ws = b.hw[1]
+        return Hs % 16 == 0 and Ws % 16 == 0 and self.workspace.numel() >= b.B * (Hs // 16) * (Ws // 16) * 288
+
+    def u0_head_train(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
+        """UpShuffle_0 forward + Dense(3) + fp32 MSE + both gradients in one launch: R_0 is never written, dR_0 receives the
+        gradient w.r.t. UpShuffle_0's pre-activation (train.py:188, 198-202, 262-272)."""
+        t, A, n = self.topo, self.arena, self.topo.octaves
+        Hi, Wi = b.hw[1]
+        x, ldx = (b.R[1].data_ptr(), b.ld[1]) if n > 1 else (b.Dlast.data_ptr(), t.fd(0))
+        ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
+        call("gct2_convT4s2_fwd_head_train", self.ctx.handle, self.dtype, x, ldx, A.wptr("U0.w"), A.pptr("U0.b"),
+             A.pptr("dense.w"), A.pptr("dense.b"), target.data_ptr(), b.pred.data_ptr() if self.keep_pred else None,
+             b.dR[0].data_ptr(), b.ld[0],
+             A.gptr("dense.w"), A.gptr("dense.b"), b.loss.data_ptr(), b.B, Hi, Wi, t.up_in(0), t.fu(0), t.fu(0) + 3, 3, ls_ptr,
+             A.gptr("U0.b"), b.img.data_ptr(), 4, 0, self._stream())
         return b.loss
 
     def _ready(self, layer: str) -> None:
@@ -537,8 +564,12 @@ class UNetEngine:
                 b.eps.copy_(eps.to(self.device, torch.float32))
             self.noise_into_r0(b, x)
         fused = self.fused_head_ok()
-        self.forward(b, head=not fused)
-        loss = self.head_train(b, x) if fused else self.loss_and_dpred(b, x)
+        if self.fused_u0_head_ok(b):
+            self.forward(b, head=False, stop_before_u0=True)
+            loss = self.u0_head_train(b, x)
+        else:
+            self.forward(b, head=not fused)
+            loss = self.head_train(b, x) if fused else self.loss_and_dpred(b, x)
         # single GPU without loss scaling: Adam rides the side stream inside backward(); the loss-scaled step has to see
         # every gradient (finite check) before any update
         inline = apply and self.fuse_adam and self.ls_state is None

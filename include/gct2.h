@@ -162,6 +162,20 @@ int gct2_dense_head_train(gct2_ctx* ctx, int dtype, const void* x, int ldx, cons
                           const void* x2, int ldx2, int accumulate /* dw, db, db_dx: 0 = overwrite, else add */,
                           void* stream);
 
+/* UpShuffle_0's forward WITH the train-step head in its epilogue (16-bit dtypes): y = relu(convT(x) + bias) is consumed where
+ * it is produced - Dense(3) + fp32 MSE + both of their gradients, exactly as gct2_dense_head_train computes them on the stored
+ * activations (y is rounded to `dtype` first, like the tensor the separate call would have read) - and never written: dy
+ * ([B,2H,2W,Cout] view) receives the gradient w.r.t. the layer's pre-activation, db its column sums (this layer's bias
+ * gradient), head_dw / head_db the Dense gradients, loss the scalar.  Saves one write and one read of the largest activation
+ * of the network plus the head launch (train.py:188, 198-202, 262-272 and their autodiff).
+ * Needs Cout = 64, H and W multiples of 16, head_Cin - Cout <= 3 image channels in x2 (packed, ldx2 multiple of 4), head_Cout <= 3
+ * and a ctx workspace of B*(H/16)*(W/16)*288 floats; GCT2_EINVAL otherwise (use convT4s2_fwd + dense_head_train). */
+int gct2_convT4s2_fwd_head_train(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias,
+                                 const float* head_w, const float* head_b, const float* target, float* pred, void* dy,
+                                 int lddy, float* head_dw, float* head_db, float* loss, int B, int H, int W, int Cin,
+                                 int Cout, int head_Cin, int head_Cout, const float* loss_scale_ptr, float* db,
+                                 const void* x2, int ldx2, int accumulate, void* stream);
+
 /* ---- Trainer.call pieces   train.py:223-272 -------------------------------------------------- */
 /* t_int[b] ~ U{1..steps} (train.py:224-226) and eps ~ N(0,1) (train.py:227) from a counter-based
  * Philox4x32-10 stream keyed by (seed, stream_id); `offset` = elements already drawn. */

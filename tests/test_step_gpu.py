@@ -27,7 +27,9 @@ def rel_l2(a, b):
 def make_engine(cfg, dtype, gpu, **kw):
     import gan_class_transfer2_amd as g
     topo = g.Topology(cfg.pixel_size, cfg.max_size, cfg.octaves)
-    return g.UNetEngine(topo, dtype, gpu, steps=cfg.steps, base_lr=cfg.base_lr, warm_up=cfg.warm_up, **kw)
+    eng = g.UNetEngine(topo, dtype, gpu, steps=cfg.steps, base_lr=cfg.base_lr, warm_up=cfg.warm_up, **kw)
+    eng.keep_pred = True            # the tests compare the prediction too (a training run does not store it)
+    return eng
 
 
 def test_golden_tiny_step_fp32(gpu):
@@ -547,6 +549,7 @@ def test_config5_fp16_loss_scaling_at_size(gpu, parity_log):
     params = {k: v.astype(np.float64) for k, v in eng.get_params().items()}     # the parameters after the step above
     xs, ts, es = x[:2].cpu().numpy().astype(np.float64), t_int[:2].numpy().astype(np.int64), eps[:2].numpy().astype(np.float64)
     loss_ref, pred_ref, grads_ref, _ = O.trainer_step(params, xs, ts, es, cfg2, operand_round="f16", loss_scale=2.0 ** 15)
+    eng.keep_pred = True
     loss2 = eng.train_step(x[:2].contiguous(), t_int[:2].contiguous(), eps[:2].contiguous(), apply=False)
     torch.cuda.synchronize()
     b = eng.buffers(2, 256, 256)
@@ -634,3 +637,46 @@ def test_checkpoint_format_is_pinned_to_the_oracle_fixture(gpu):
         upd_ref = z["param3/" + k].astype(np.float64) - z["param2/" + k]
         assert rel_l2(eng.arena.param(k).cpu().numpy(), z["param3/" + k]) <= 1e-6, k
         assert rel_l2(upd, upd_ref) <= 5e-3, k                   # the step-3 update itself (a wrong counter changes alpha by 20 %)
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+def test_u0_forward_with_head_epilogue_equals_separate_head(gpu, dtype, parity_log):
+    """gct2_convT4s2_fwd_head_train (UpShuffle_0's forward carrying Dense(3) + MSE + both gradients in its epilogue, R_0 never
+    written) against the separate path (convT forward -> R_0 -> gct2_dense_head_train): same rounding points, so the loss, the
+    prediction, dR_0 and every gradient agree to summation-order noise; and against the rounded oracle like the other steps."""
+    import gan_class_transfer2_amd as g
+    rounding = {1: "bf16", 2: "f16"}[dtype]
+    cfg = O.OracleConfig(size=64, pixel_size=128, max_size=256, octaves=2, batch_size=3)
+    params = O.init_params(cfg, seed=17)
+    rng = np.random.default_rng(2)
+    for k in params:
+        if k.endswith(".b"):
+            params[k] = (rng.standard_normal(params[k].shape) * 0.05).astype(np.float32).astype(np.float64)
+    x, t_int, eps = O.synthetic_batch(cfg, seed=6)
+    f16 = dtype == 2
+    loss_ref, pred_ref, grads_ref, _ = O.trainer_step(params, x, t_int, eps, cfg, operand_round=rounding, loss_scale=2.0 ** 15 if f16 else 1.0)
+    X, T, E = torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32)
+    res = []
+    for fuse in (True, False):
+        eng = make_engine(cfg, dtype, gpu, loss_scaling=f16)
+        eng.set_params(params)
+        eng.fuse_u0_head = fuse
+        b = eng.buffers(3, 64, 64)
+        assert eng.fused_u0_head_ok(b) == fuse
+        loss = eng.train_step(X, T, E, apply=False)
+        torch.cuda.synchronize()
+        res.append((float(loss[0]), b.pred.clone(), b.dR[0][..., :64].float().clone(), eng.get_grads()))
+    (l1, p1, d1, g1), (l0, p0, d0, g0) = res
+    errs = {k: rel_l2(g1[k], g0[k]) for k in g1}
+    oerr = {k: rel_l2(g1[k], grads_ref[k]) for k in g1}
+    parity_log("u0_head_epilogue_" + rounding, loss_rel_vs_separate=abs(l1 - l0) / l0, pred_rel_l2_vs_separate=rel_l2(p1.cpu().numpy(), p0.cpu().numpy()),
+               dR0_rel_l2_vs_separate=rel_l2(d1.cpu().numpy(), d0.cpu().numpy()), worst_grad_vs_separate=max(errs.values()),
+               loss_rel_vs_oracle=abs(l1 - loss_ref) / loss_ref, worst_grad_vs_oracle=max(oerr.values()), worst_grad=max(oerr, key=oerr.get))
+    assert abs(l1 - l0) <= 1e-5 * l0 and rel_l2(p1.cpu().numpy(), p0.cpu().numpy()) <= 1e-4
+    assert rel_l2(d1.cpu().numpy(), d0.cpu().numpy()) <= 4e-3          # one storage rounding on each side
+    for k in errs:
+        assert errs[k] <= 3e-3, (k, errs[k])
+    tol = {"bf16": (2e-3, 3e-2), "f16": (3e-4, 5e-3)}[rounding]
+    assert abs(l1 - loss_ref) <= tol[0] * loss_ref and rel_l2(p1.cpu().numpy(), pred_ref) <= 1e-2
+    for k in oerr:
+        assert oerr[k] <= tol[1], (k, oerr[k])
