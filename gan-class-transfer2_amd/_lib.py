@@ -56,6 +56,12 @@ SIGNATURES = {
                                      _vp, _vp, _vp, _i, _i, _vp],
     "gct2_convT4s2_dgrad": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp],
     "gct2_convT4s2_wgrad": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "gct2_conv2d_s1_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_conv2d_s1_dgrad": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_conv2d_s1_wgrad": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gct2_relu_mask": [_i, _vp, _i, _vp, _i, _sz, _i, _vp],
+    "gct2_add": [_i, _vp, _i, _vp, _i, _sz, _i, _vp],
+    "gct2_mix_per_image": [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp],
     "gct2_dense_fwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gct2_dense_bwd": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gct2_dense_head_train": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],

@@ -27,6 +27,13 @@ int pw_mse(const float*, const float*, float*, float*, float*, size_t, const flo
 int pw_dense_head_train(const gct2_ctx&, int, const void*, int, const float*, const float*, const float*, float*, void*, int, float*, float*,
                         float*, float*, int, int, int, int, const float*, float*, const void*, int, int, hipStream_t);
 int pw_colsum(int, const void*, int, float*, size_t, int, float, hipStream_t);
+int pw_relu_mask(int, const void*, int, void*, int, size_t, int, hipStream_t);
+int pw_add(int, void*, int, const void*, int, size_t, int, hipStream_t);
+int pw_mix_per_image(const float*, const float*, const float*, const float*, float*, int, size_t, hipStream_t);
+int conv_s1_direct(int dtype, bool dgrad, const void* x, int ldx, const void* w, const float* bias, const void* act, int ldact, void* y, int ldy,
+                   int B, int H, int W, int K, int N, int KS, int relu, int accumulate, hipStream_t s);
+int conv_s1_wgrad_direct(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, int B, int H, int W, int Cin, int Cout, int KS,
+                         int accumulate, hipStream_t s);
 int pw_diffusion_mix(int, const float*, const float*, float, float*, void*, int, void*, int, size_t, int, hipStream_t);
 int pw_diffusion_update(const float*, const float*, float, float*, float*, size_t, hipStream_t);
 int pw_noise_edits(const float*, const float*, int, float*, int, int, int, hipStream_t);
@@ -259,6 +266,50 @@ int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const 
   return GCT2_OK;
 }
 
+// ---- off-by-default model variants (train.py:20 block_depth, train.py:26 residual, train.py:29-32 targets) ----------------------
+static int check_s1(const char* fn, int dtype, const void* a, const void* b, const void* c, int B, int H, int W, int Cin, int Cout, int KS) {
+  if (int e = check_conv_args(fn, dtype, a, b, c, B, H, W, Cin, Cout)) return e;
+  if (KS < 1 || KS > 7 || !(KS & 1)) return gct2_fail(GCT2_EINVAL, "%s: kernel size %d (odd, 1..7: 'same' padding is symmetric then)", fn, KS);
+  return GCT2_OK;
+}
+int gct2_conv2d_s1_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
+                       int Cin, int Cout, int KS, int relu, void* stream) {
+  (void)ctx;
+  if (int e = check_s1("conv2d_s1_fwd", dtype, x, w, y, B, H, W, Cin, Cout, KS)) return e;
+  if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "conv2d_s1_fwd: ld smaller than channel count");
+  return conv_s1_direct(dtype, false, x, ldx, w, bias, nullptr, 0, y, ldy, B, H, W, Cin, Cout, KS, relu, 0, S(stream));
+}
+int gct2_conv2d_s1_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
+                         int H, int W, int Cin, int Cout, int KS, int accumulate, void* stream) {
+  (void)ctx;
+  if (int e = check_s1("conv2d_s1_dgrad", dtype, dz, w, dx, B, H, W, Cin, Cout, KS)) return e;
+  if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "conv2d_s1_dgrad: ld smaller than channel count");
+  return conv_s1_direct(dtype, true, dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H, W, Cout, Cin, KS, 0, accumulate, S(stream));
+}
+int gct2_conv2d_s1_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
+                         int Cin, int Cout, int KS, int accumulate, void* stream) {
+  (void)ctx;
+  if (int e = check_s1("conv2d_s1_wgrad", dtype, x, dz, dw, B, H, W, Cin, Cout, KS)) return e;
+  if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "conv2d_s1_wgrad: ld smaller than channel count");
+  if (int e = conv_s1_wgrad_direct(dtype, x, ldx, dz, lddz, dw, B, H, W, Cin, Cout, KS, accumulate, S(stream))) return e;
+  if (db) return wgrad_db(dtype, dz, lddz, db, (size_t)B * H * W, Cout, accumulate, stream);
+  return GCT2_OK;
+}
+int gct2_relu_mask(int dtype, const void* act, int ldact, void* d, int ldd, size_t npix, int C, void* stream) {
+  if (!dtype_ok(dtype) || !act || !d || C <= 0 || ldact < C || ldd < C) return gct2_fail(GCT2_EINVAL, "relu_mask: bad dtype, null pointer or ld < C");
+  if (npix == 0) return GCT2_OK;
+  return pw_relu_mask(dtype, act, ldact, d, ldd, npix, C, S(stream));
+}
+int gct2_add(int dtype, void* dst, int lddst, const void* src, int ldsrc, size_t npix, int C, void* stream) {
+  if (!dtype_ok(dtype) || !dst || !src || C <= 0 || lddst < C || ldsrc < C) return gct2_fail(GCT2_EINVAL, "add: bad dtype, null pointer or ld < C");
+  if (npix == 0) return GCT2_OK;
+  return pw_add(dtype, dst, lddst, src, ldsrc, npix, C, S(stream));
+}
+int gct2_mix_per_image(const float* x, const float* eps, const float* a, const float* c, float* out, int B, size_t per_image, void* stream) {
+  if (!x || !a || !out || (eps && !c) || B <= 0 || per_image == 0) return gct2_fail(GCT2_EINVAL, "mix_per_image: null pointer or empty batch");
+  return pw_mix_per_image(x, eps, a, c, out, B, per_image, S(stream));
+}
+
 int gct2_dense_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, float* y, int M, int Cin, int Cout, void* stream) {
   if (!dtype_ok(dtype) || !x || !w || !y) return gct2_fail(GCT2_EINVAL, "dense_fwd: bad dtype or null pointer");
   if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout > 4 || ldx < Cin) return gct2_fail(GCT2_EINVAL, "dense_fwd: bad shape (Cout must be 1..4)");
@@ -270,7 +321,7 @@ int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const floa
   if (!dtype_ok(dtype) || !x || !w || !dy || !dx || !dw) return gct2_fail(GCT2_EINVAL, "dense_bwd: bad dtype or null pointer");
   if (M <= 0 || Cin <= 0 || Cout <= 0 || Cout > 4 || ldx < Cin || Cmask < 0 || Cmask > Cin || lddx < Cmask)
     return gct2_fail(GCT2_EINVAL, "dense_bwd: bad shape");
-  if ((Cin + 1) * Cout > 256) return gct2_fail(GCT2_EINVAL, "dense_bwd: (Cin+1)*Cout = %d exceeds 256", (Cin + 1) * Cout);
+  if ((Cin + 1) * Cout > 2048) return gct2_fail(GCT2_EINVAL, "dense_bwd: (Cin+1)*Cout = %d exceeds 2048", (Cin + 1) * Cout);
   if ((size_t)Cin * 16 + 128 * 16 + (size_t)128 * Cin * esize(dtype) > 160 * 1024)
     return gct2_fail(GCT2_EINVAL, "dense_bwd: Cin=%d too large for the LDS tile", Cin);
   return pw_dense_bwd(dtype, x, ldx, w, dy, dx, lddx, dw, db, M, Cin, Cout, Cmask, accumulate, S(stream));

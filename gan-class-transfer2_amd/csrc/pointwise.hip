@@ -196,9 +196,11 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const T* __restrict__ x,
     const int o = i & 3, k = i >> 2;
     wsm[i] = (o < Cout) ? w[k * Cout + o] : 0.f;
   }
-  const int nout = (Cin + 1) * Cout;                        // dw entries + db entries owned by threads
-  const int my_i = tid / Cout, my_o = tid - my_i * Cout;    // valid when tid < nout
-  float wacc = 0.f;
+  const int nout = (Cin + 1) * Cout;                        // dw entries + db entries: entry e = tid + 256 k belongs to thread tid
+  constexpr int ENT = 8;                                    // (Cin + 1) * Cout <= 2048
+  float wacc[ENT];
+#pragma unroll
+  for (int k = 0; k < ENT; k++) wacc[k] = 0.f;
   const int ntiles = (M + PIX - 1) / PIX;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int mbase = tile * PIX;
@@ -220,17 +222,27 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const T* __restrict__ x,
       if (!(to_f32(xs[pm * Cin + k]) > 0.f)) g = 0.f;
       dx[(size_t)(mbase + pm) * lddx + k] = from_f32<T>(g);
     }
-    if (tid < nout) {
+#pragma unroll
+    for (int k = 0; k < ENT; k++) {
+      const int e = tid + 256 * k;
+      if (e >= nout) break;
+      const int my_i = e / Cout, my_o = e - my_i * Cout;
+      float a = wacc[k];
       if (my_i < Cin) {
-        for (int pm = 0; pm < PIX; pm++) wacc = fmaf(to_f32(xs[pm * Cin + my_i]), dys[4 * pm + my_o], wacc);
+        for (int pm = 0; pm < PIX; pm++) a = fmaf(to_f32(xs[pm * Cin + my_i]), dys[4 * pm + my_o], a);
       } else {
-        for (int pm = 0; pm < PIX; pm++) wacc += dys[4 * pm + my_o];
+        for (int pm = 0; pm < PIX; pm++) a += dys[4 * pm + my_o];
       }
+      wacc[k] = a;
     }
   }
-  if (tid < nout) {
-    if (my_i < Cin) atomicAdd(dw + my_i * Cout + my_o, wacc);
-    else if (db) atomicAdd(db + my_o, wacc);
+#pragma unroll
+  for (int k = 0; k < ENT; k++) {
+    const int e = tid + 256 * k;
+    if (e >= nout) break;
+    const int my_i = e / Cout, my_o = e - my_i * Cout;
+    if (my_i < Cin) atomicAdd(dw + my_i * Cout + my_o, wacc[k]);
+    else if (db) atomicAdd(db + my_o, wacc[k]);
   }
 }
 
@@ -691,6 +703,36 @@ __global__ void image_prepare_kernel(const uint8_t* __restrict__ src, const int6
   }
 }
 
+// ---- small helpers of the off-by-default model variants (train.py:106-112 residual add, autodiff of the fused ReLUs,
+// train.py:238-252 targets): elementwise, views with a pixel stride ----------------------------------------------------------
+template <typename T>
+__global__ void relu_mask_kernel(const T* __restrict__ act, int ldact, T* __restrict__ d, int ldd, size_t n, int C) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    if (!(to_f32(act[pix * ldact + c]) > 0.f)) d[pix * ldd + c] = from_f32<T>(0.f);
+  }
+}
+template <typename T>
+__global__ void add_kernel(T* __restrict__ dst, int lddst, const T* __restrict__ src, int ldsrc, size_t n, int C) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    dst[pix * lddst + c] = from_f32<T>(to_f32(dst[pix * lddst + c]) + to_f32(src[pix * ldsrc + c]));
+  }
+}
+// out = a[b] * x + c[b] * eps (eps may be null: out = a[b] * x), fp32, per-image coefficients
+__global__ void mix_per_image_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ a,
+                                     const float* __restrict__ c, float* __restrict__ out, size_t n, size_t per_image) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t b = i / per_image;
+    out[i] = a[b] * x[i] + (eps ? c[b] * eps[i] : 0.f);
+  }
+}
+
 // ---- bias gradient: db[c] += sum_m dz[m][c] --------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dz, int ld, float* __restrict__ db, size_t M, int C,
@@ -1014,6 +1056,33 @@ int pw_mse(const float* pred, const float* target, float* dpred, float* loss, fl
   hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, s, pred, target, dpred, partials, n, ls);
   hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, s, partials, nb, loss, 1.0f / (float)n);
   return gct2_check_launch("mse_fwd_bwd");
+}
+template <typename T>
+static int relu_mask_t(const void* act, int ldact, void* d, int ldd, size_t npix, int C, hipStream_t s) {
+  hipLaunchKernelGGL(relu_mask_kernel<T>, dim3(blocks_for(npix * C, 256)), dim3(256), 0, s, reinterpret_cast<const T*>(act), ldact,
+                     reinterpret_cast<T*>(d), ldd, npix * C, C);
+  return gct2_check_launch("relu_mask");
+}
+int pw_relu_mask(int dtype, const void* act, int ldact, void* d, int ldd, size_t npix, int C, hipStream_t s) {
+  if (dtype == GCT2_F32) return relu_mask_t<float>(act, ldact, d, ldd, npix, C, s);
+  if (dtype == GCT2_BF16) return relu_mask_t<__bf16>(act, ldact, d, ldd, npix, C, s);
+  return relu_mask_t<_Float16>(act, ldact, d, ldd, npix, C, s);
+}
+template <typename T>
+static int add_t(void* dst, int lddst, const void* src, int ldsrc, size_t npix, int C, hipStream_t s) {
+  hipLaunchKernelGGL(add_kernel<T>, dim3(blocks_for(npix * C, 256)), dim3(256), 0, s, reinterpret_cast<T*>(dst), lddst,
+                     reinterpret_cast<const T*>(src), ldsrc, npix * C, C);
+  return gct2_check_launch("add");
+}
+int pw_add(int dtype, void* dst, int lddst, const void* src, int ldsrc, size_t npix, int C, hipStream_t s) {
+  if (dtype == GCT2_F32) return add_t<float>(dst, lddst, src, ldsrc, npix, C, s);
+  if (dtype == GCT2_BF16) return add_t<__bf16>(dst, lddst, src, ldsrc, npix, C, s);
+  return add_t<_Float16>(dst, lddst, src, ldsrc, npix, C, s);
+}
+int pw_mix_per_image(const float* x, const float* eps, const float* a, const float* c, float* out, int B, size_t per_image, hipStream_t s) {
+  const size_t n = (size_t)B * per_image;
+  hipLaunchKernelGGL(mix_per_image_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, x, eps, a, c, out, n, per_image);
+  return gct2_check_launch("mix_per_image");
 }
 template <typename T>
 static int colsum_t(const void* dz, int ld, float* db, size_t M, int C, float sign, hipStream_t s) {

@@ -151,7 +151,8 @@ class UNetEngine:
     def __init__(self, topo: Topology, dtype: int = BF16, device: Optional[torch.device] = None, steps: int = 200,
                  base_lr: float = 2e-5, warm_up: int = 2000, beta_1: float = 0.9, beta_2: float = 0.999,
                  epsilon: float = 1e-7, loss_scaling: bool = False, seed: int = 1234, rng_seed: int = 0,
-                 workspace_mb: int = 64):
+                 workspace_mb: int = 64, predict_x: bool = True, predict_scaled_epsilon: bool = False,
+                 prediction_weighting: bool = False, ordinary_differential_equation: bool = False):
         self.lib = _lib.load()
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         if self.device.type != "cuda":
@@ -161,6 +162,9 @@ class UNetEngine:
         self.base_lr, self.warm_up = base_lr, warm_up
         self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
         self.loss_scaling = loss_scaling
+        # the objective switches of train.py:29-32 (defaults = the reference's: the network predicts the clean image)
+        self.predict_x, self.predict_scaled_epsilon = predict_x, predict_scaled_epsilon
+        self.prediction_weighting, self.ordinary_differential_equation = prediction_weighting, ordinary_differential_equation
         self.use_fused_head = True     # False: dense_fwd + mse_fwd_bwd + dense_bwd as three kernels
         self.fuse_u0_head = True       # train step: the head runs in UpShuffle_0's forward epilogue (R_0 is never written)
         self.keep_pred = False         # train step: also store the prediction (buffers().pred); the loss does not need it
@@ -248,6 +252,7 @@ class UNetEngine:
         b.pred = z(B, H, W, 3, dtype=torch.float32)
         b.dpred = z(B, H, W, 3, dtype=torch.float32)
         b.eps = z(B, H, W, 3, dtype=torch.float32)
+        b.target = None                 # fp32 [B,H,W,3], allocated by the non-default objectives (train.py:238-252)
         b.t_int = z(B, dtype=torch.int32)
         b.loss = z(1, dtype=torch.float32)
         b.partials = z(1024, dtype=torch.float32)
@@ -356,10 +361,53 @@ class UNetEngine:
              b.partials.data_ptr(), b.pred.numel(), ls_ptr, self._stream())
         return b.loss
 
+    # ---- objectives other than the default (train.py:238-252) ----------------------------------------------------------
+    def default_objective(self) -> bool:
+        return self.predict_x and not self.ordinary_differential_equation
+
+    def objective_weighted(self) -> bool:
+        """train.py:250-252: prediction and target both scaled by sqrt(1 - alpha_dash(t)) (epsilon branch only)."""
+        return (not self.default_objective()) and (not self.ordinary_differential_equation) and self.prediction_weighting
+
+    def objective_coefficients(self, b: _Buffers) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """per-image (a, c, w): target = a x + c eps, prediction weight w - B-element vectors from t_int."""
+        t = b.t_int.to(torch.float32)
+        ad = lambda u: 0.25 * (1.0 - u / (self.steps + 1)) ** 2          # alpha_dash, train.py:85-93
+        one, zero = torch.ones_like(t), torch.zeros_like(t)
+        if self.ordinary_differential_equation:                           # train.py:238-242
+            a1 = ad(t - 1)
+            return a1.sqrt().contiguous(), (1 - a1).sqrt().contiguous(), one
+        if self.predict_x:                                                # train.py:243-244
+            return one, zero, one
+        s = (1 - ad(t)).sqrt()
+        c = s if self.predict_scaled_epsilon else one                     # train.py:245-248
+        if self.prediction_weighting:                                     # train.py:250-252
+            return zero, (c * s).contiguous(), s.contiguous()
+        return zero, c.contiguous(), one
+
+    def make_target(self, b: _Buffers, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """the regression target of train.py:238-252 as an fp32 [B,H,W,3] tensor (needs b.eps) and the prediction weights."""
+        if b.target is None:
+            b.target = torch.zeros_like(b.eps)
+        a, c, w = self.objective_coefficients(b)
+        b._coef = (a, c, w)                                               # keep the vectors alive until the kernels ran
+        call("gct2_mix_per_image", x.data_ptr(), b.eps.data_ptr(), a.data_ptr(), c.data_ptr(), b.target.data_ptr(), b.B,
+             b.H * b.W * 3, self._stream())
+        return b.target, w
+
+    def weighted_loss_and_dpred(self, b: _Buffers, target: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """prediction_weighting (train.py:250-252): loss = mean((w_b pred - target)^2); dpred = w_b * dloss/d(w_b pred)."""
+        n = b.H * b.W * 3
+        call("gct2_mix_per_image", b.pred.data_ptr(), None, w.data_ptr(), None, b.pred.data_ptr(), b.B, n, self._stream())
+        loss = self.loss_and_dpred(b, target)
+        call("gct2_mix_per_image", b.dpred.data_ptr(), None, w.data_ptr(), None, b.dpred.data_ptr(), b.B, n, self._stream())
+        return loss
+
     def fused_head_ok(self) -> bool:
         """the matrix-core head with the split input (R_0's UpShuffle_0 channels + the packed image): the reference topology
         (Fu_0 = 64) in a 16-bit mode with a workspace; anything else runs dense_fwd + mse_fwd_bwd + dense_bwd."""
-        return self.use_fused_head and self.dtype != F32 and self.topo.fu(0) == 64 and self.workspace is not None
+        return (self.use_fused_head and self.dtype != F32 and self.topo.fu(0) == 64 and self.workspace is not None
+                and not self.objective_weighted())
 
     def head_train(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
         """Dense(3) + fp32 MSE + both of their gradients in one pass over R_0 (gct2_dense_head_train)."""
@@ -553,8 +601,10 @@ class UNetEngine:
         B, H, W, _ = x.shape
         b = self.buffers(B, H, W)
         self.begin_step()
+        default_obj = self.default_objective()
         if t_int is None and eps is None:
-            self.sample_and_noise_into_r0(b, x)                 # the normal training path: eps never touches HBM
+            # the normal training path: eps never touches HBM (unless the target is built from it, train.py:238-252)
+            self.sample_and_noise_into_r0(b, x, keep_eps=not default_obj)
         else:
             if t_int is None or eps is None:
                 self.sample_noise(b)
@@ -563,13 +613,18 @@ class UNetEngine:
             if eps is not None:
                 b.eps.copy_(eps.to(self.device, torch.float32))
             self.noise_into_r0(b, x)
+        target, w = (x, None) if default_obj else self.make_target(b, x)
+        weighted = self.objective_weighted()
         fused = self.fused_head_ok()
-        if self.fused_u0_head_ok(b):
+        if fused and self.fused_u0_head_ok(b):
             self.forward(b, head=False, stop_before_u0=True)
-            loss = self.u0_head_train(b, x)
+            loss = self.u0_head_train(b, target)
         else:
             self.forward(b, head=not fused)
-            loss = self.head_train(b, x) if fused else self.loss_and_dpred(b, x)
+            if weighted:
+                loss = self.weighted_loss_and_dpred(b, target, w)
+            else:
+                loss = self.head_train(b, target) if fused else self.loss_and_dpred(b, target)
         # single GPU without loss scaling: Adam rides the side stream inside backward(); the loss-scaled step has to see
         # every gradient (finite check) before any update
         inline = apply and self.fuse_adam and self.ls_state is None

@@ -139,6 +139,10 @@ def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _code_of(t: torch.Tensor) -> int:
+    return {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[t.dtype]
+
+
 def _as_compute(x: torch.Tensor, code: int) -> torch.Tensor:
     if not x.is_cuda:
         raise _lib.Gct2Error("layers run on the HIP device only (there is no CPU path)")
@@ -172,29 +176,39 @@ class Sequential(Layer):
 
 
 class Residual(Layer):
-    """train.py:97-121 (concat mode)."""
+    """train.py:97-121: residual (input + Dense(module(input))), concat (the default) or plain module."""
 
     def __init__(self, module, highway=lambda x: x):
         self.module = module
         self.highway = highway
-        if residual:
-            _unsupported("residual=True", "train.py:26")
+        self.dense = None
+
+    def build(self, input_shape):
+        if residual:                                             # train.py:104-108
+            self.dense = Dense(input_shape[-1], use_bias=False)
 
     def call(self, input):
+        if residual:                                             # train.py:111-112
+            out = input.contiguous().clone()
+            proj = self.dense(self.module(input)).to(out.dtype)
+            C = out.shape[-1]
+            call("gct2_add", _code_of(out), out.data_ptr(), C, proj.data_ptr(), C, out.numel() // C, C, _stream(out))
+            return out
         if concat:
             return torch.cat([self.module(input).to(input.dtype), self.highway(input)], -1)
         return self.module(input)
 
 
 class Block(Layer):
-    """train.py:123-143: block_depth x [Conv2D 3x3/s1 + ReLU]; identity at block_depth = 0."""
+    """train.py:123-143: block_depth x [Conv2D(filters, 3, 1, 'same', relu)]; identity at block_depth = 0."""
 
     def __init__(self, filters):
         self.filters = filters
-        if block_depth != 0:
-            _unsupported("block_depth > 0", "train.py:20")
+        self.convs = [Conv3x3(filters) for _ in range(block_depth)]
 
     def call(self, input):
+        for conv in self.convs:
+            input = conv(input)
         return input
 
 
@@ -225,6 +239,32 @@ class _ConvLayer(Layer):
 
     def _operand_tensor(self) -> torch.Tensor:
         return self.kernel if self.dtype_code == F32 else self.kernel.to(TORCH_DTYPE[self.dtype_code])
+
+
+class Conv3x3(_ConvLayer):
+    """the Conv2D(filters, 3, 1, 'same', relu) of Block (train.py:131-139)."""
+
+    def _kernel_shape(self, cin):
+        return (3, 3, cin, self.filters)
+
+    def build(self, input_shape):
+        if self.kernel is not None:
+            return
+        import math
+        cin = input_shape[-1]
+        lim = math.sqrt(6.0 / (9 * cin + 9 * self.filters))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.kernel = ((torch.rand(3, 3, cin, self.filters) * 2 - 1) * lim).to(dev)
+        self.bias = torch.zeros(self.filters, device=dev)
+
+    def call(self, input):
+        x = _as_compute(input, self.dtype_code)
+        B, H, W, C = x.shape
+        y = torch.empty(B, H, W, self.filters, dtype=x.dtype, device=x.device)
+        w = self._operand_tensor()
+        call("gct2_conv2d_s1_fwd", None, self.dtype_code, x.data_ptr(), C, w.data_ptr(), self.bias.data_ptr(), y.data_ptr(), self.filters,
+             B, H, W, C, self.filters, 3, 1, _stream(x))
+        return y
 
 
 class UpShuffle(_ConvLayer):
@@ -262,10 +302,12 @@ class DownShuffle(_ConvLayer):
 
 
 class Dense(Layer):
-    """tf.keras.layers.Dense(units) on a rank-4 input (train.py:198-202); fp32 output."""
+    """tf.keras.layers.Dense(units) on a rank-4 input: the Dense(3) head (train.py:198-202; fp32 output for the fp32 loss) and,
+    with use_bias=False, the projection of Residual's residual=True mode (train.py:106; a 1 x 1 convolution in the compute dtype)."""
 
-    def __init__(self, units):
+    def __init__(self, units, use_bias=True):
         self.units = units
+        self.use_bias = use_bias
         self.kernel = None
         self.bias = None
         self.dtype_code = preferred_dtype_code()
@@ -278,15 +320,21 @@ class Dense(Layer):
         lim = math.sqrt(6.0 / (cin + self.units))
         dev = torch.device("cuda", torch.cuda.current_device())
         self.kernel = ((torch.rand(cin, self.units) * 2 - 1) * lim).to(dev)
-        self.bias = torch.zeros(self.units, device=dev)
+        self.bias = torch.zeros(self.units, device=dev) if self.use_bias else None
 
     def call(self, input):
         x = _as_compute(input, self.dtype_code)
         C = x.shape[-1]
         M = x.numel() // C
-        y = torch.empty(*x.shape[:-1], self.units, dtype=torch.float32, device=x.device)
-        call("gct2_dense_fwd", self.dtype_code, x.data_ptr(), C, self.kernel.data_ptr(), self.bias.data_ptr(), y.data_ptr(),
-             M, C, self.units, _stream(x))
+        if self.use_bias and self.units <= 4:
+            y = torch.empty(*x.shape[:-1], self.units, dtype=torch.float32, device=x.device)
+            call("gct2_dense_fwd", self.dtype_code, x.data_ptr(), C, self.kernel.data_ptr(), self.bias.data_ptr(), y.data_ptr(),
+                 M, C, self.units, _stream(x))
+            return y
+        w = self.kernel if self.dtype_code == F32 else self.kernel.to(TORCH_DTYPE[self.dtype_code])
+        y = torch.empty(*x.shape[:-1], self.units, dtype=x.dtype, device=x.device)
+        call("gct2_conv2d_s1_fwd", None, self.dtype_code, x.data_ptr(), C, w.data_ptr(), self.bias.data_ptr() if self.bias is not None else None,
+             y.data_ptr(), self.units, M, 1, 1, C, self.units, 1, 0, _stream(x))
         return y
 
 
@@ -326,7 +374,17 @@ class Denoiser(Layer):
         ])
         self.engine: Optional[UNetEngine] = None
 
-    def ensure_engine(self, **engine_kw) -> UNetEngine:
+    def variant(self) -> bool:
+        """any switch that leaves the default topology (train.py:20, 26, 27): those run on variants.VariantEngine."""
+        return block_depth != 0 or residual or not concat
+
+    def ensure_engine(self, **engine_kw):
+        if self.engine is None and self.variant():
+            from .variants import VariantEngine
+            kw = dict(steps=steps, warm_up=warm_up, seed=self._seed, loss_scaling=bool(mixed_precision))
+            kw.update(engine_kw)
+            self.engine = VariantEngine(pixel_size, max_size, octaves, block_depth, residual, concat, self.dtype_code, self._device, **kw)
+            self._bind_variant_parameters()
         if self.engine is None:
             # no optimizer known yet (train.py:505-509 calls the model before compile): the module-level mixed_precision
             # decides about loss scaling, as it decides about the LossScaleOptimizer wrapper in train.py:82-83
@@ -344,9 +402,45 @@ class Denoiser(Layer):
             self.head._built = True
         return self.engine
 
+    def _bind_variant_parameters(self) -> None:
+        """the nested eager layers of self.middle share the variant engine's parameters: both enumerate the layers in forward
+        order (train.py:183-204), so the k-th layer with a kernel is the k-th (kernel[, bias]) group of the engine."""
+        net = self.engine.net
+        groups: Dict[str, Dict[str, torch.Tensor]] = {}
+        for name, _ in net.specs:
+            groups.setdefault(name.rsplit(".", 1)[0], {})[name.rsplit(".", 1)[1]] = net.view(net.p, name)
+        order = list(groups)
+
+        def walk(layer):
+            if isinstance(layer, Sequential):
+                for sub in layer.layers:
+                    yield from walk(sub)
+            elif isinstance(layer, Residual):
+                yield from walk(layer.module)
+                if residual:
+                    layer.dense = Dense(0, use_bias=False)
+                    layer._built = True                          # build() would replace the bound projection
+                    yield layer.dense
+            elif isinstance(layer, Block):
+                yield from layer.convs
+            else:
+                yield layer
+
+        layers = list(walk(self.middle))
+        assert len(layers) == len(order), (len(layers), len(order))
+        for layer, key in zip(layers, order):
+            layer.kernel, layer.bias = groups[key]["w"], groups[key].get("b")
+            if isinstance(layer, Dense):
+                layer.units = layer.kernel.shape[-1]
+            layer.dtype_code = self.dtype_code
+            layer._built = True
+
     @property
     def trainable_variables(self) -> Dict[str, torch.Tensor]:
-        A = self.ensure_engine().arena
+        eng = self.ensure_engine()
+        if self.variant():
+            return {k: eng.net.view(eng.net.p, k) for k in eng.net.shapes}
+        A = eng.arena
         return {k: A.param(k) for k in A.shapes}
 
     def call(self, input):
@@ -376,17 +470,18 @@ class Trainer(Layer):
         self.denoiser = denoiser
         self.optimizer = None
         self.loss_fn = None
-        if ordinary_differential_equation:
-            _unsupported("ordinary_differential_equation=True", "train.py:32")
-        if not predict_x:
-            _unsupported("predict_x=False (epsilon prediction)", "train.py:29")
+        # the objective switches of train.py:29-32 are read when the engine is built (train.py reads them at call time, but
+        # they are module constants there as well)
+        self._objective = dict(predict_x=predict_x, predict_scaled_epsilon=predict_scaled_epsilon,
+                               prediction_weighting=prediction_weighting,
+                               ordinary_differential_equation=ordinary_differential_equation)
 
     def _engine(self) -> UNetEngine:
         opt = self.optimizer
-        kw = {}
+        kw = dict(self._objective)
         if opt is not None and self.denoiser.engine is None:
             inner = getattr(opt, "inner", opt)
-            kw = dict(beta_1=inner.beta_1, beta_2=inner.beta_2, epsilon=inner.epsilon,
+            kw.update(beta_1=inner.beta_1, beta_2=inner.beta_2, epsilon=inner.epsilon,
                       loss_scaling=bool(inner.loss_scaling))
             lr = inner.learning_rate
             if isinstance(lr, WarmUp):
@@ -402,11 +497,18 @@ class Trainer(Layer):
         """returns the scalar fp32 loss for a freshly noised batch (train.py:223-272); no gradients."""
         eng = self._engine()
         x = x.to(eng.device, torch.float32).contiguous()
+        if self.denoiser.variant():
+            return eng.train_step(x, backward=False).clone()[0]
         b = eng.buffers(*x.shape[:3])
         eng.sample_noise(b)
         eng.noise_into_r0(b, x, unfused_head=True)     # forward(head=True) reads the image channels from R_0 itself
         eng.forward(b)
-        return eng.loss_and_dpred(b, x).clone()[0]
+        if eng.default_objective():
+            return eng.loss_and_dpred(b, x).clone()[0]
+        target, w = eng.make_target(b, x)              # train.py:238-252
+        if eng.objective_weighted():
+            return eng.weighted_loss_and_dpred(b, target, w).clone()[0]
+        return eng.loss_and_dpred(b, target).clone()[0]
 
     def compile(self, optimizer, loss):
         """train.py:511-514"""

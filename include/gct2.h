@@ -130,6 +130,29 @@ int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const 
                         float* db, int B, int H, int W, int Cin, int Cout, int accumulate,
                         const gct2_adam_args* adam /* or NULL */, void* stream);
 
+/* ---- the reference's off-by-default model variants ------------------------------------------------------------------------
+ * Block = block_depth x Conv2D(filters, 3, 1, 'same', relu) (train.py:20, 123-143) and the bias-free projection
+ * Dense(input_channels) of Residual's residual=True mode (train.py:26, 104-112; a Dense on a rank-4 tensor is a 1 x 1 convolution,
+ * its (Cin, Cout) kernel the same memory as (1, 1, Cin, Cout)).  Stride-1 'same' convolution, KS odd (symmetric padding):
+ *   y[b,h,w,o] = act(bias[o] + sum_{kh,kw,i} x[b,h+kh-p,w+kw-p,i] w[kh,kw,i,o]),  p = (KS-1)/2;  w: (KS,KS,Cin,Cout) of `dtype`.
+ * dgrad: dx[b,h,w,i] (+)= mask * sum dz[b,h-kh+p,w-kw+p,o] w[kh,kw,i,o] (mask / accumulate as for conv4s2_dgrad);
+ * wgrad: dw (+)= sum x dz (fp32), db (+)= column sums of dz.  Direct kernels (one thread per output), every dtype: these layers are
+ * unreachable at the reference's defaults and are built for results, not for the roofline. */
+int gct2_conv2d_s1_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
+                       int B, int H, int W, int Cin, int Cout, int KS, int relu, void* stream);
+int gct2_conv2d_s1_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact,
+                         void* dx, int lddx, int B, int H, int W, int Cin, int Cout, int KS, int accumulate, void* stream);
+int gct2_conv2d_s1_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db,
+                         int B, int H, int W, int Cin, int Cout, int KS, int accumulate, void* stream);
+/* d[pix,c] = act[pix,c] > 0 ? d[pix,c] : 0 - the autodiff of a fused ReLU where no producing kernel applies the mask itself */
+int gct2_relu_mask(int dtype, const void* act, int ldact, void* d, int ldd, size_t npix, int C, void* stream);
+/* dst[pix,c] += src[pix,c] (train.py:112 `input + ...` and the gradient joins of the variants) */
+int gct2_add(int dtype, void* dst, int lddst, const void* src, int ldsrc, size_t npix, int C, void* stream);
+/* out = a[b] * x + c[b] * eps, fp32, per-image coefficients (eps = NULL: out = a[b] * x): the targets and prediction weights of
+ * train.py:238-252 (ODE target, epsilon / scaled-epsilon prediction, prediction_weighting) */
+int gct2_mix_per_image(const float* x, const float* eps, const float* a, const float* c, float* out, int B, size_t per_image,
+                       void* stream);
+
 /* ---- Dense(3) head on a rank-4 input   train.py:198-202 ------------------------------------- */
 /* y[m,o] = b[o] + sum_i x[m,i] * w[i,o];  x: [M,Cin] view of `dtype`; w fp32 (Cin,Cout), Cout <= 4;
  * y: fp32 [M,Cout] contiguous (the loss is taken in fp32, train.py:262-263).  GCT2_F16: the values are rounded to fp16

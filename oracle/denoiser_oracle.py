@@ -357,8 +357,35 @@ def unet_backward(params, cache, dpred, cfg: OracleConfig, operand_round: Option
     return g
 
 
-def trainer_step(params, x, t_int, eps, cfg: OracleConfig, operand_round: Optional[str] = None, loss_scale: float = 1.0):
-    """Trainer.call default branch (predict_x=True): returns (loss, pred, grads, noised).
+def objective_terms(x, t_int, eps, steps: int = 200, predict_x: bool = True, predict_scaled_epsilon: bool = False,
+                    prediction_weighting: bool = False, ordinary_differential_equation: bool = False):
+    """target and prediction weight of train.py:238-252 for the four mode switches of train.py:29-32:
+        ODE (train.py:238-242):   target = x sqrt(a(t-1)) + eps sqrt(1 - a(t-1))
+        predict_x (243-244):      target = x
+        else (245-252):           target = eps, * sqrt(1 - a(t)) if predict_scaled_epsilon;
+                                  if prediction_weighting: target and prediction both * sqrt(1 - a(t))
+    returns (target, w) with w the per-image factor on the prediction ([B,1,1,1], ones unless prediction_weighting)."""
+    t = np.asarray(t_int, dtype=np.float64).reshape(-1, 1, 1, 1)
+    w = np.ones_like(t)
+    if ordinary_differential_equation:
+        a1 = alpha_dash(t - 1, steps)
+        return x * np.sqrt(a1) + eps * np.sqrt(1.0 - a1), w
+    if predict_x:
+        return x, w
+    target = eps
+    s = np.sqrt(1.0 - alpha_dash(t, steps))
+    if predict_scaled_epsilon:
+        target = target * s
+    if prediction_weighting:
+        target = target * s
+        w = s
+    return target, w
+
+
+def trainer_step(params, x, t_int, eps, cfg: OracleConfig, operand_round: Optional[str] = None, loss_scale: float = 1.0,
+                 objective: Optional[dict] = None):
+    """Trainer.call (default branch predict_x=True; `objective` = keyword arguments of objective_terms selects the other
+    branches of train.py:238-252): returns (loss, pred, grads, noised).
     loss = mean((x - pred)^2) in the working dtype (train.py:262-272);
     identity(...) then takes reduce_mean of that scalar (train.py:171-173) = same scalar.
 
@@ -373,10 +400,11 @@ def trainer_step(params, x, t_int, eps, cfg: OracleConfig, operand_round: Option
     pred, cache = unet_forward(params, noised, cfg, operand_round)
     if f16:
         pred = round_f16(pred)
-    diff = pred - x
+    target, w = objective_terms(x, t_int, eps, cfg.steps, **(objective or {}))
+    diff = pred * w - target
     nel = diff.size
     loss = float(np.sum(diff.astype(np.float64) ** 2) / nel)
-    dpred = (2.0 * loss_scale / nel) * diff
+    dpred = (2.0 * loss_scale / nel) * diff * w
     if f16:
         dpred = round_f16(dpred)
     grads = unet_backward(params, cache, dpred, cfg, operand_round)

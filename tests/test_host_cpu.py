@@ -128,12 +128,14 @@ def test_reference_config_surface_and_schedules():
         M.configure(mixed_precision=False)
     with pytest.raises(AttributeError):
         M.configure(no_such_knob=1)
-    M.configure(block_depth=1)
+    M.configure(block_depth=2, residual=True)           # the off-by-default switches build their layers (train.py:104-143)
     try:
-        with pytest.raises(NotImplementedError):
-            M.Block(8)
+        blk = M.Block(8)
+        assert len(blk.convs) == 2 and all(isinstance(c, M.Conv3x3) and c.filters == 8 for c in blk.convs)
+        assert M.Denoiser.variant(None)
     finally:
-        M.configure(block_depth=0)
+        M.configure(block_depth=0, residual=False)
+    assert not M.Denoiser.variant(None) and M.Block(8).convs == []
 
 
 def test_bench_flop_model_matches_survey_appendix_b():

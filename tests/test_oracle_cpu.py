@@ -190,3 +190,69 @@ def test_sampler_identities_and_golden():
     pred_t = T.unet_forward(params, image, cfg) if hasattr(T, "unet_forward") else None
     if pred_t is not None:
         assert np.abs(pred_o - np.asarray(pred_t)).max() < 1e-10
+
+
+def test_variants_oracle_against_loops_and_torch_autograd():
+    """oracle/variants_oracle.py (block_depth, residual, concat switches of train.py:20-27 and the objectives of train.py:238-252):
+    the stride-1 'same' convolution against definition-level loops, and loss / every gradient of each variant against an
+    independent torch.nn.functional + autograd evaluation of the same structure."""
+    import torch.nn.functional as F
+    from oracle import variants_oracle as V
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 5, 4, 3)); w = rng.standard_normal((3, 3, 3, 4)) * 0.3; b = rng.standard_normal(4)
+    assert np.abs(V.conv_s1_fwd(x, w, b) - V.naive_conv_s1(x, w, b)).max() < 1e-12
+    w1 = rng.standard_normal((1, 1, 3, 5))
+    assert np.abs(V.conv_s1_fwd(x, w1) - x @ w1[0, 0]).max() < 1e-12           # a 1 x 1 convolution is a Dense on a rank-4 tensor
+    cfg = O.OracleConfig(size=8, pixel_size=4, max_size=8, octaves=2, batch_size=2)
+    xs, ts, es = O.synthetic_batch(cfg, seed=1)
+    cases = [dict(block_depth=1, residual=False, concat=True, objective=None),
+             dict(block_depth=0, residual=True, concat=True, objective=dict(predict_x=False)),
+             dict(block_depth=2, residual=False, concat=False, objective=dict(ordinary_differential_equation=True)),
+             dict(block_depth=1, residual=True, concat=False, objective=dict(predict_x=False, predict_scaled_epsilon=True, prediction_weighting=True))]
+    for case in cases:
+        bd, res, cat = case["block_depth"], case["residual"], case["concat"]
+        params = V.init_variant_params(cfg, bd, res, cat, seed=3)
+        loss, pred, grads = V.variant_trainer_step(params, xs, ts, es, cfg, bd, res, cat, case["objective"])
+        # torch: same structure, NCHW, autograd
+        P = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+        conv = lambda h, n: F.relu(F.conv2d(h, P[n + ".w"].permute(3, 2, 0, 1), P[n + ".b"], stride=2, padding=1))
+        convT = lambda h, n: F.relu(F.conv_transpose2d(h, P[n + ".w"].permute(3, 2, 0, 1), P[n + ".b"], stride=2, padding=1))
+        c3 = lambda h, n: F.relu(F.conv2d(h, P[n + ".w"].permute(3, 2, 0, 1), P[n + ".b"], stride=1, padding=1))
+
+        def block(h, name):
+            for d in range(bd):
+                h = c3(h, f"{name}.{d}")
+            return h
+
+        def level(i, v):
+            h = block(conv(v, f"D{i}"), f"blkA{i}")
+            h = level(i + 1, h) if i + 1 < cfg.octaves else block(h, "blkMid")
+            h = convT(block(h, f"blkB{i}"), f"U{i}")
+            if res:
+                return v + torch.einsum("bchw,cd->bdhw", h, P[f"res{i}.dense.w"])
+            return torch.cat([h, v], 1) if cat else h
+
+        noised = torch.tensor(O.noise_image(xs, ts, es, cfg.steps)).permute(0, 3, 1, 2)
+        h = block(level(0, block(noised, "blkTopA")), "blkTopB")
+        tp = torch.einsum("bchw,cd->bhwd", h, P["dense.w"]) + P["dense.b"]
+        target, wgt = O.objective_terms(xs, ts, es, cfg.steps, **(case["objective"] or {}))
+        tl = torch.mean((tp * torch.tensor(wgt) - torch.tensor(target)) ** 2)
+        tl.backward()
+        assert abs(loss - float(tl)) < 1e-12 and np.abs(pred - tp.detach().numpy()).max() < 1e-11
+        for k in grads:
+            assert np.abs(grads[k] - P[k].grad.numpy()).max() <= 1e-11 * max(1.0, np.abs(grads[k]).max()), (case, k)
+        assert set(grads) == set(params)
+
+
+def test_objective_terms_and_fp16_noise_model():
+    x, t, e = np.ones((2, 1, 1, 3)), np.array([1, 200]), np.full((2, 1, 1, 3), 2.0)
+    a = O.alpha_dash(np.array([1.0, 200.0]))
+    tg, w = O.objective_terms(x, t, e)
+    assert tg is x and np.all(w == 1)
+    tg, w = O.objective_terms(x, t, e, predict_x=False, predict_scaled_epsilon=True, prediction_weighting=True)
+    assert np.allclose(tg[:, 0, 0, 0], 2.0 * (1 - a)) and np.allclose(w[:, 0, 0, 0], np.sqrt(1 - a))
+    tg, w = O.objective_terms(x, t, e, ordinary_differential_equation=True)
+    a0 = O.alpha_dash(np.array([0.0, 199.0]))
+    assert np.allclose(tg[:, 0, 0, 0], np.sqrt(a0) + 2 * np.sqrt(1 - a0)) and np.all(w == 1)
+    n16 = O.noise_image_f16(x, t, e)
+    assert n16.dtype == np.float16 and np.abs(n16.astype(np.float64) - O.noise_image(x, t, e)).max() < 4e-3
