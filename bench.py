@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="tapgemm tile variant hook (0 auto, 2, 3): A/B timing only")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run the weight gradients and Adam on the main stream (no overlap): per-kernel profiling runs")
+    ap.add_argument("--dp-mode", default="sharded", choices=["sharded", "allreduce"],
+                    help="N > 1: reduce-scatter + sharded Adam + all-gather of the weights (default), or bucketed all-reduce")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,7 +175,7 @@ def main():
 
     import gan_class_transfer2_amd as g
     from gan_class_transfer2_amd import _lib, engine as engine_mod
-    from gan_class_transfer2_amd.distributed import DataParallelStep
+    from gan_class_transfer2_amd.distributed import DataParallelStep, ShardedDataParallelStep
 
     dtype = {"bf16": g.BF16, "f16": g.F16, "f32": g.F32}[args.dtype]
     topo = g.Topology(128, 512, 6)                      # reference defaults, train.py:18-21
@@ -181,7 +183,8 @@ def main():
     if args.variant:
         eng.ctx.set_tuning(args.variant)
     eng.overlap = not args.serial_streams
-    dp = DataParallelStep(eng)
+    sharded = world > 1 and args.dp_mode == "sharded"
+    dp = ShardedDataParallelStep(eng) if sharded else DataParallelStep(eng)
     dp.broadcast_parameters(0)
 
     B, S = args.batch, args.size
@@ -224,7 +227,20 @@ def main():
             iso_steps += 1
         barrier()
         timer.enabled, eng.overlap, eng.fuse_adam = False, overlap0, fuse0
+    comm = None
     if world > 1:
+        # evidence of what RCCL ran (rank 0): ranks it saw, the buckets of one extra step and the HIP-event time of every collective
+        buckets = dp.buckets if sharded else dp.reducer.buckets
+        esz = 4
+        comm = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "mode": args.dp_mode, "buckets": len(buckets),
+                "bytes_per_bucket": [int((hi - lo) * esz) for lo, hi in buckets]}
+        if sharded:
+            dp.time_collectives, dp.events = True, []
+            dp.train_step(x)
+            barrier()
+            dp.time_collectives = False
+            comm["collective_ms"] = [[k, round(ms, 4)] for k, ms in dp.collective_times_ms()]
+            comm["collectives"] = "per bucket: reduce_scatter (fp32 gradients), all_gather (compute-dtype weights)"
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
@@ -241,6 +257,7 @@ def main():
                                    f"pixel_size 128, max_size 512, {args.dtype} operands / fp32 accumulate, Keras Adam + WarmUp",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "loss": loss_val,
+            "comm": comm,
             "flops_per_image": f_img,
             "step_roofline_frac": round(imgs / world * f_img / MFMA_PEAK, 5),
         }

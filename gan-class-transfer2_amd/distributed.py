@@ -8,6 +8,13 @@ backward pass is still running; the 1/world_size of the mean is folded into Adam
 
 The reducer only needs a flat gradient tensor and the contiguous [lo, hi) range of every layer, so it runs
 unchanged on CPU tensors with the gloo backend (tests/test_distributed_cpu.py).
+
+Two exchange schemes (SURVEY.md App. D prices them on 7 xGMI links x ~153 GB/s per GPU):
+  DataParallelStep         all-reduce of every bucket, every rank runs the whole Adam step (2 (N-1)/N x 4 B per parameter on
+                           the wire, 30-38 B per parameter of optimizer traffic on every GPU);
+  ShardedDataParallelStep  reduce-scatter of every bucket, Adam on the rank's OWN shard only (optimizer state is sharded), then an
+                           all-gather of the updated compute-dtype weights: (N-1)/N x (4 + 2) B per parameter on the wire for
+                           bf16/fp16 and 1/N of the optimizer traffic per GPU.  Replicas end with bit-identical operand copies.
 """
 from __future__ import annotations
 
@@ -137,3 +144,159 @@ class DataParallelStep:
                 eng.apply_adam(lo, hi, grad_div=float(self.world))
         eng.finish_step()
         return loss
+
+
+class ShardedDataParallelStep:
+    """reduce-scatter -> Adam on the own shard -> all-gather of the updated weights (module docstring).
+
+    Buckets are fixed-size pieces of the gradient arena in backward-completion order (multiples of world x 64 elements, so every
+    rank's shard of a bucket is a 16-byte aligned equal part; a bucket is independent of layer boundaries).  A bucket's
+    reduce-scatter is enqueued on the communication stream as soon as the layer holding its last element is ready.  Its Adam
+    step and the all-gather overwrite weights, so they wait until a LATER layer is ready - UNetEngine.backward enqueues a
+    layer's input-gradient launch (the last reader of its weights) after the layer's ready hook and makes the side stream wait
+    for it before the next layer's hook - or until the end of the reverse pass.
+
+    The fp32 master parameters and Adam slots are only maintained for the rank's own shards (`gather_master()` assembles the full
+    arenas on every rank: checkpoints, tests).  With loss scaling every rank checks its shards and the found_inf flags are
+    combined with one 4-byte MAX all-reduce."""
+
+    def __init__(self, engine, bucket_elems: int = 4 << 20, group=None, force_exchange: bool = False):
+        self.engine, self.group = engine, group
+        A = engine.arena
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
+        unit = self.world * 64
+        if A.total % unit:
+            raise ValueError(f"arena of {A.total} elements is not a multiple of world x 64 = {unit}")
+        bsz = max(unit, (bucket_elems + unit - 1) // unit * unit)
+        self.buckets: List[Tuple[int, int]] = [(lo, min(lo + bsz, A.total)) for lo in range(0, A.total, bsz)]
+        order = engine.topo.layer_order()
+        self.layer_index = {name: i for i, name in enumerate(order)}
+        ends = [A.layer_ranges[name][1] for name in order]
+        # last_layer[k]: index of the layer that holds the last element of bucket k (the bucket is complete when it is ready)
+        self.last_layer = [next(i for i, e in enumerate(ends) if e >= hi) for _, hi in self.buckets]
+        self.on_cuda = A.g.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=A.g.device) if self.on_cuda else None
+        engine.grad_ready_hook = self._grad_ready
+        self.events: List[Tuple[int, object, object]] = []      # (bucket, start, end) of the collectives when timing is on
+        self.time_collectives = False
+        self._begin()
+
+    # ---- helpers ----------------------------------------------------------------------------------------------------------
+    def _begin(self) -> None:
+        self.next_rs = 0            # first bucket whose reduce-scatter has not been enqueued
+        self.next_opt = 0           # first bucket whose Adam + all-gather has not been enqueued
+        self.launched = 0
+
+    def shard(self, k: int) -> Tuple[int, int]:
+        lo, hi = self.buckets[k]
+        n = (hi - lo) // self.world
+        return lo + self.rank * n, lo + (self.rank + 1) * n
+
+    def _on_comm(self):
+        return torch.cuda.stream(self.comm_stream) if self.on_cuda else _NullCtx()
+
+    def _comm_waits_current(self) -> None:
+        if self.on_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.engine.device))
+            self.comm_stream.wait_event(ev)
+
+    def _timed(self, k: int, fn) -> None:
+        if self.time_collectives and self.on_cuda:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(self.comm_stream)
+            fn()
+            e.record(self.comm_stream)
+            self.events.append((k, s, e))
+        else:
+            fn()
+
+    def _reduce_scatter(self, k: int) -> None:
+        g = self.engine.arena.g
+        lo, hi = self.buckets[k]
+        slo, shi = self.shard(k)
+        with self._on_comm():
+            self._timed(k, lambda: dist.reduce_scatter_tensor(g[slo:shi], g[lo:hi], op=dist.ReduceOp.SUM, group=self.group))
+        self.launched += 1
+
+    def _optimize_and_gather(self, k: int) -> None:
+        eng, A = self.engine, self.engine.arena
+        lo, hi = self.buckets[k]
+        slo, shi = self.shard(k)
+        with self._on_comm():
+            stream = self.comm_stream.cuda_stream if self.on_cuda else None
+            eng.apply_adam(slo, shi, grad_div=float(self.world), stream=stream)
+            w = A.shadow if A.shadow is not None else A.p
+            self._timed(k, lambda: dist.all_gather_into_tensor(w[lo:hi], w[slo:shi], group=self.group))
+
+    def _grad_ready(self, layer: str) -> None:
+        if not self.exchange:
+            return
+        q = self.layer_index[layer]
+        rs_due = self.next_rs < len(self.buckets) and self.last_layer[self.next_rs] <= q
+        opt_due = self.engine.ls_state is None and self.next_opt < len(self.buckets) and self.last_layer[self.next_opt] < q
+        if rs_due or opt_due:
+            self._comm_waits_current()          # the hook runs in the stream context that produced the layer's gradients
+        while self.next_rs < len(self.buckets) and self.last_layer[self.next_rs] <= q:
+            self._reduce_scatter(self.next_rs)
+            self.next_rs += 1
+        if self.engine.ls_state is None:
+            # buckets that end in an EARLIER layer: every reader of their weights has been enqueued and waited for by now
+            while self.next_opt < self.next_rs and self.last_layer[self.next_opt] < q:
+                self._optimize_and_gather(self.next_opt)
+                self.next_opt += 1
+
+    # ---- public -----------------------------------------------------------------------------------------------------------
+    def broadcast_parameters(self, src: int = 0) -> None:
+        if self.world > 1:
+            A = self.engine.arena
+            for t in (A.p, A.m, A.v):
+                dist.broadcast(t, src, group=self.group)
+            A.refresh_shadow(self.engine._stream())
+
+    def train_step(self, x, t_int=None, eps=None):
+        eng = self.engine
+        if not self.exchange:
+            return eng.train_step(x, t_int, eps, apply=True)
+        self._begin()
+        loss = eng.train_step(x, t_int, eps, apply=False)       # backward fires _grad_ready per layer
+        assert self.next_rs == len(self.buckets)
+        self._comm_waits_current()                               # every input-gradient launch has been enqueued by now
+        if eng.ls_state is not None:
+            # fp16 + dynamic loss scale (train.py:82-83): each rank checks the shards it owns; one 4-byte MAX all-reduce makes
+            # the skip decision global before any update
+            with self._on_comm():
+                stream = self.comm_stream.cuda_stream if self.on_cuda else None
+                for k in range(len(self.buckets)):
+                    eng.check_finite(*self.shard(k), stream=stream)
+                dist.all_reduce(eng.ls_state[3:4], op=dist.ReduceOp.MAX, group=self.group)
+        while self.next_opt < len(self.buckets):
+            self._optimize_and_gather(self.next_opt)
+            self.next_opt += 1
+        if self.on_cuda:
+            torch.cuda.current_stream(eng.device).wait_stream(self.comm_stream)
+        eng.finish_step()
+        return loss
+
+    def gather_master(self) -> None:
+        """assemble the full fp32 parameter and Adam-slot arenas on every rank from the per-rank shards."""
+        if not self.exchange:
+            return
+        A = self.engine.arena
+        for t in (A.p, A.m, A.v):
+            for k, (lo, hi) in enumerate(self.buckets):
+                slo, shi = self.shard(k)
+                dist.all_gather_into_tensor(t[lo:hi], t[slo:shi].clone(), group=self.group)
+
+    def collective_times_ms(self) -> List[Tuple[int, float]]:
+        return [(k, s.elapsed_time(e)) for k, s, e in self.events]
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

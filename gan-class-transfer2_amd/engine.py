@@ -89,6 +89,8 @@ class ParamArena:
                 self.offsets[name] = off
                 off = _round_up(off + int(np.prod(self.shapes[name])), self.ALIGN)
             self.layer_ranges[layer] = (lo, off)
+        off = _round_up(off, 64 * self.ALIGN)       # the arena splits into equal 16-byte aligned shards for up to 64 ranks
+        self.layer_ranges[layer] = (self.layer_ranges[layer][0], off)
         self.total = off
         z = lambda dt: torch.zeros(self.total, dtype=dt, device=device)
         self.p, self.m, self.v, self.g = z(torch.float32), z(torch.float32), z(torch.float32), z(torch.float32)
@@ -585,9 +587,11 @@ class UNetEngine:
             call("gct2_loss_scale_begin", self.ls_state.data_ptr(), float(self.base_lr), int(self.warm_up), float(self.beta_1),
                  float(self.beta_2), self._stream())
 
-    def check_finite(self) -> None:
+    def check_finite(self, lo: int = 0, hi: Optional[int] = None, stream: Optional[int] = None) -> None:
         if self.ls_state is not None:
-            call("gct2_scale_check_finite", self.arena.g.data_ptr(), self.arena.total, self.ls_state.data_ptr(), self._stream())
+            hi = self.arena.total if hi is None else hi
+            call("gct2_scale_check_finite", self.arena.g.data_ptr() + 4 * lo, hi - lo, self.ls_state.data_ptr(),
+                 self._stream() if stream is None else stream)
 
     # ---- the whole step ---------------------------------------------------------------------------
     def train_step(self, x: torch.Tensor, t_int: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None,

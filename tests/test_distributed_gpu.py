@@ -37,33 +37,45 @@ def _run(eng_or_dp, cfg, nsteps, sl, dev):
     torch.cuda.synchronize()
 
 
-def _worker(rank, world, port, case, out_dir):
+def _worker(rank, world, port, case, out_dir, mode="allreduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import gan_class_transfer2_amd as g
-        from gan_class_transfer2_amd.distributed import DataParallelStep
+        from gan_class_transfer2_amd.distributed import DataParallelStep, ShardedDataParallelStep
         dt, topo_kw, nsteps, _, bucket = CASES[case]
         cfg = O.OracleConfig(batch_size=4, **topo_kw)
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         eng = g.UNetEngine(g.Topology(cfg.pixel_size, cfg.max_size, cfg.octaves), dt, dev)
         eng.set_params(O.init_params(cfg, seed=21))
-        dp = DataParallelStep(eng, bucket_elems=bucket)
-        assert dp.world == world and dp.reducer.exchange and len(dp.reducer.buckets) >= 2
         per = cfg.batch_size // world
-        _run(dp, cfg, nsteps, slice(rank * per, (rank + 1) * per), dev)
-        assert eng.iterations == nsteps and dp.reducer.launched == len(dp.reducer.buckets)
+        if mode == "sharded":
+            dp = ShardedDataParallelStep(eng, bucket_elems=bucket)
+            assert dp.world == world and dp.exchange and len(dp.buckets) >= 2
+            _run(dp, cfg, nsteps, slice(rank * per, (rank + 1) * per), dev)
+            assert eng.iterations == nsteps and dp.launched == len(dp.buckets)
+            if eng.arena.shadow is not None:       # what the replicas compute with: bit-identical operand copies
+                np.save(os.path.join(out_dir, f"shadow{rank}.npy"), eng.arena.shadow.float().cpu().numpy())
+            dp.gather_master()                     # the fp32 masters are sharded: assemble them for the comparison
+        else:
+            dp = DataParallelStep(eng, bucket_elems=bucket)
+            assert dp.world == world and dp.reducer.exchange and len(dp.reducer.buckets) >= 2
+            _run(dp, cfg, nsteps, slice(rank * per, (rank + 1) * per), dev)
+            assert eng.iterations == nsteps and dp.reducer.launched == len(dp.reducer.buckets)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **eng.get_params())
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["allreduce", "sharded"])
 @pytest.mark.parametrize("case", ["f32", "bf16"])
-def test_two_ranks_on_one_gpu_equal_global_batch(gpu, tmp_path, case):
+def test_two_ranks_on_one_gpu_equal_global_batch(gpu, tmp_path, case, mode):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path), mode), nprocs=world, join=True)
+    if mode == "sharded" and case == "bf16":
+        assert np.array_equal(np.load(tmp_path / "shadow0.npy"), np.load(tmp_path / "shadow1.npy"))
     import gan_class_transfer2_amd as g
     dt, topo_kw, nsteps, tol, _ = CASES[case]
     cfg = O.OracleConfig(batch_size=4, **topo_kw)
