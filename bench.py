@@ -165,13 +165,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # rehearsal of the N > 1 code path on a one-GPU box (never a measurement): GCT2_BENCH_REHEARSAL=1 puts every rank on device 0
+    # and exchanges through gloo (RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get("GCT2_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import gan_class_transfer2_amd as g
     from gan_class_transfer2_amd import _lib, engine as engine_mod
@@ -252,7 +260,8 @@ def main():
         out = {
             "metric": f"images/sec (train step) 3x{S}x{S} bs={B}/GPU", "value": round(imgs, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo - not a measurement)",
             "config": {"workload": f"BASELINE config {(5 if args.dtype == 'f16' else 3 if world == 1 else 4)}: Trainer step, 3x{S}x{S}, bs {B}/GPU, octaves 6, "
                                    f"pixel_size 128, max_size 512, {args.dtype} operands / fp32 accumulate, Keras Adam + WarmUp",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
