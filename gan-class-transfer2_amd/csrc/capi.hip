@@ -16,7 +16,7 @@ int halo_head(const gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* d
 bool rgb_fwd_supported(int dtype, const TapGemmParams& p);
 int rgb_fwd(int dtype, const TapGemmParams& p, hipStream_t s);
 bool rgb_wgrad_supported(int dtype, const WgradParams& p);
-int rgb_wgrad(int dtype, const WgradParams& p, hipStream_t s);
+int rgb_wgrad(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer);
 int pw_rng_uniform_int(uint64_t, uint64_t, uint64_t, int32_t*, size_t, int, int, hipStream_t);
 int pw_rng_normal(uint64_t, uint64_t, uint64_t, float*, size_t, hipStream_t);
 int pw_noise(int, const float*, const int32_t*, const float*, void*, int, void*, int, int, int, int, int, hipStream_t);
@@ -207,7 +207,7 @@ int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const v
   p.accumulate = accumulate ? 1 : 0;
   WgradSlabs sl{nullptr, 0, 0};
   if (!c.force_direct && rgb_wgrad_supported(dtype, p)) {
-    if (int e = rgb_wgrad(dtype, p, S(stream))) return e;
+    if (int e = rgb_wgrad(c, dtype, p, S(stream), adam ? &sl : nullptr)) return e;
   } else if (int e = run_wgrad(c, dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)
     if (int e = wgrad_db(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, accumulate, stream)) return e;

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(WgradParams p) {
   const int steps_total = (R + 63) / 64;
   const int steps_per = (steps_total + gridDim.x - 1) / gridDim.x;
   const int step_lo = blockIdx.x * steps_per, step_hi = min(steps_total, step_lo + steps_per);
+  // (the launcher sizes the grid so that every work-group row has steps: each one owns a slab)
   if (step_lo >= step_hi) return;
   const T* __restrict__ x = reinterpret_cast<const T*>(p.big);
   const T* __restrict__ dz = reinterpret_cast<const T*>(p.small);
@@ -220,7 +221,10 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(WgradParams p) {
     if (step + 1 < step_hi) sstore(buf ^ 1);
     __syncthreads();
   }
-  // lane holds dW'[k' = 16 i + 4 (lane>>4) + r][n = n0 + 32 wave + 16 j + (lane&15)]; channel slot = r
+  // lane holds dW'[k' = 16 i + 4 (lane>>4) + r][n = n0 + 32 wave + 16 j + (lane&15)]; channel slot = r.
+  // p.ws: every work-group row (blockIdx.x = its pixel range) stores its partial tensor into its own slab, summed in slab order by
+  // wgrad_reduce_kernel or by the fused optimizer step (bit-reproducible); without scratch: fp32 atomics into dw.
+  float* __restrict__ out = p.ws ? p.ws + (size_t)blockIdx.x * 16 * Cin * N : p.dw;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int tap = 4 * i + (lane >> 4);
@@ -230,7 +234,9 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int n = n0 + wave * 32 + j * 16 + (lane & 15);
-        if (n < N) atomicAdd(p.dw + (size_t)(tap * Cin + r) * N + n, acc[i][j][r]);
+        if (n >= N) continue;
+        if (p.ws) out[(size_t)(tap * Cin + r) * N + n] = acc[i][j][r];
+        else atomicAdd(out + (size_t)(tap * Cin + r) * N + n, acc[i][j][r]);
       }
     }
   }
@@ -258,16 +264,28 @@ bool rgb_wgrad_supported(int dtype, const WgradParams& p) {
   if (p.Cb > 4 || p.Cs % 8 || p.ldsmall % 8 || (uintptr_t)p.small % 16) return false;
   return true;
 }
-int rgb_wgrad(int dtype, const WgradParams& p, hipStream_t s) {
+int wgrad_reduce(const float* ws, float* dw, size_t n, int nsplit, int accumulate, hipStream_t s);   // wgrad_mfma.hip
+
+int rgb_wgrad(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer) {
+  if (defer) *defer = WgradSlabs{nullptr, 0, 0};
   const int R = p.B * p.Hs * p.Ws;
   const int steps_total = (R + 63) / 64;
   const int ntiles = (p.Cs + 127) / 128;
   // 512 work-groups (two per CU): measured 1024 -> 48 us (atomics of 1024 partial tiles), 512 -> 38 us, 256 -> 48 us
   int splits = max(1, min(512 / ntiles, steps_total / 4));
+  const int per = (steps_total + splits - 1) / splits;
+  splits = (steps_total + per - 1) / per;                       // every work-group row non-empty (each one owns a slab)
   dim3 grid(splits, ntiles);
-  if (!p.accumulate) (void)hipMemsetAsync(p.dw, 0, (size_t)16 * p.Cb * p.Cs * sizeof(float), s);   // the kernel adds with atomics
+  const size_t n = (size_t)16 * p.Cb * p.Cs;
+  size_t ws_bytes = 0;
+  float* ws = c.wgrad_scratch(&ws_bytes);
+  p.ws = (ws && n % 4 == 0 && (uintptr_t)p.dw % 16 == 0 && n * sizeof(float) * splits <= ws_bytes) ? ws : nullptr;
+  if (!p.ws && !p.accumulate) (void)hipMemsetAsync(p.dw, 0, n * sizeof(float), s);   // the atomic path adds into dw
   const size_t lds = 4 * 64 * 256;
   if (dtype == GCT2_BF16) hipLaunchKernelGGL(rgb_wgrad_kernel<__bf16>, grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL(rgb_wgrad_kernel<_Float16>, grid, dim3(256), lds, s, p);
-  return gct2_check_launch("rgb_wgrad");
+  if (int e = gct2_check_launch("rgb_wgrad")) return e;
+  if (p.ws && defer && !p.accumulate) { *defer = WgradSlabs{p.ws, splits, n}; return GCT2_OK; }   // the optimizer kernel sums the slabs
+  if (p.ws) return wgrad_reduce(p.ws, p.dw, n, splits, p.accumulate, s);
+  return GCT2_OK;
 }

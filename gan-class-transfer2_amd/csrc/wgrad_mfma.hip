@@ -569,3 +569,8 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   return gct2_check_launch("wgrad_mfma");
 }
 
+// dw (+)= sum of nsplit partial tensors of n elements each (n % 4 == 0), slab order: shared with the 3-channel layer (rgb_mfma.hip)
+int wgrad_reduce(const float* ws, float* dw, size_t n, int nsplit, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, ws, dw, n / 4, nsplit, accumulate);
+  return gct2_check_launch("wgrad_reduce");
+}
