@@ -24,6 +24,7 @@ struct gct2_ctx {
   int tap_variant = 0;                             // forward / input-gradient tile (0 = automatic)
   int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 24;
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
+  int xcd_order = 0;                               // tile -> XCD order: 0 = automatic, 1 = m-tile bands, 2 = weight slices
   int force_direct = 0;
   float* wgrad_scratch(size_t* bytes) const {
     if (wws) { *bytes = wws_bytes; return wws; }
@@ -143,6 +144,7 @@ struct TapGemmParams {
   int relu, accumulate;
   float* ws; int ksplit;         // split-K: fp32 partial slabs [ksplit][out pixels][N] in the registered workspace
   int m_tiles, n_tiles, xcd_chunk;   // launch geometry (filled by the launcher): see xcd_tile()
+  int wstat;                         // 1: weight-stationary tile -> XCD order (tapgemm_kernel)
   int wide;                          // output / mask views allow 16-byte accesses (filled by the launcher)
   float* db; int db_split; float* db2;   // EPI_MASK: bias-gradient targets (column sums of the masked result), may be null
   int db_acc;                            // bit 0: db is added to (else overwritten); bit 1: the same for db2

@@ -89,9 +89,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   // 1-D grid: [k-slice][XCD-aware (m-tile, n-tile, phase)]
   constexpr int PH = (FORM == FORM_CONVT) ? 4 : 1;
   const int inner = p.n_tiles * PH, per_slice = 8 * p.xcd_chunk * inner;
-  const int kslice = (int)blockIdx.x / per_slice;
-  int m_tile, in;
-  if (!xcd_tile((int)blockIdx.x - kslice * per_slice, p.m_tiles, inner, p.xcd_chunk, m_tile, in)) return;
+  int kslice, m_tile, in;
+  if (p.wstat) {
+    // weight-stationary order (layers whose weights outweigh their activations: the U-Net's bottleneck): a weight slice =
+    // (k-slice, n-tile, phase); the slices are dealt over the XCDs (ids with equal id % 8 share an L2) and an XCD runs ALL
+    // m-tiles of a slice back to back, so every XCD streams 1/8 of the weight tensor instead of all of it (measured before: 8-10x
+    // the algorithmic HBM traffic on these layers, profiles/r02_traffic_per_layer_before_wstat.json)
+    const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    const int slice = (j / p.m_tiles) * 8 + xcd;
+    if (slice >= inner * p.ksplit) return;
+    m_tile = j % p.m_tiles;
+    kslice = slice / inner;
+    in = slice - kslice * inner;
+  } else {
+    kslice = (int)blockIdx.x / per_slice;
+    if (!xcd_tile((int)blockIdx.x - kslice * per_slice, p.m_tiles, inner, p.xcd_chunk, m_tile, in)) return;
+  }
   const int phase = in % PH, n_tile = in / PH;
   const int m0 = m_tile * BM, n0 = n_tile * BN;
   const int ph = phase >> 1, pw = phase & 1;
@@ -565,7 +578,12 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
     }
   }
   p.xcd_chunk = (p.m_tiles + 7) / 8;
-  dim3 grid(8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
+  // tile -> XCD order: by default an XCD owns a band of m-tiles (the source pixels are re-read by every n-tile / phase / tap); when
+  // the weight tensor is the bigger operand and there are at least 8 weight slices, an XCD owns weight slices instead (p.wstat)
+  const size_t w_bytes = (size_t)16 * p.K * p.N * 2, src_bytes = (size_t)M * (FORM == FORM_CONV ? 4 : 1) * p.ldx * 2;
+  const int slices = p.n_tiles * PH * p.ksplit;
+  p.wstat = (c.xcd_order == 2 || (c.xcd_order == 0 && w_bytes >= 3 * src_bytes)) && slices >= 8 ? 1 : 0;   // measured per layer: profiles/r02_layers.txt
+  dim3 grid(p.wstat ? 8 * ((slices + 7) / 8) * p.m_tiles : 8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
   auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF, WM>;
   p.dbws = db_rows ? ws + (ws_bytes - dbws_bytes) / sizeof(float) / 4 * 4 : nullptr;
   if (want_db && !p.dbws) zero_overwritten_db(p, s);

@@ -262,13 +262,16 @@ def test_convT4s2_wgrad(gpu, dt, shape):
     assert rel_l2(db.cpu().numpy(), db_ref) <= TOL_F32OUT[dt]
 
 
+@pytest.mark.parametrize("order", [0, 1, 2])
 @pytest.mark.parametrize("dt", [BF16, F16])
-def test_splitk_bottleneck_layers(gpu, dt):
-    """small-M / deep-K layers (U-Net bottleneck) with a registered workspace: split-K slabs + finalize kernel."""
+def test_splitk_bottleneck_layers(gpu, dt, order):
+    """small-M / deep-K layers (U-Net bottleneck) with a registered workspace: split-K slabs + finalize kernel; with the tile ->
+    XCD order automatic (weight slices per XCD here: the weights are the bigger operand), forced to pixel bands, forced to slices."""
     L = lib()
     ws = torch.empty(32 << 18, dtype=torch.float32, device=gpu)        # 32 MiB, deliberately NOT zeroed
     ws.fill_(float("nan"))
     set_ws(ws)
+    set_tuning(order << 26)
     try:
         B, H, W, Cin, Cout = 4, 4, 4, 512, 256
         rng = np.random.default_rng(11)
