@@ -185,6 +185,11 @@ class UNetEngine:
         self.overlap = True
         self.fuse_adam = True          # per-layer Adam fused behind the weight-gradient calls (single replica, no loss scaling)
         self._side = torch.cuda.Stream(device=self.device)
+        # the dgrad chain (the only true dependency chain of the reverse pass, with its short split-K finalize / row-sum launches)
+        # runs on a HIGH-priority stream: its work-groups are dispatched ahead of the side stream's queued weight-gradient
+        # work-groups as CU slots free up, instead of waiting behind a whole full-chip grid
+        self.chain_priority = True
+        self._chain = torch.cuda.Stream(device=self.device, priority=-1)
         self.wgrad_workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
         self.ctx.set_workspace(self.workspace)
         self.ctx.set_wgrad_workspace(self.wgrad_workspace)
@@ -457,14 +462,18 @@ class UNetEngine:
         scaling): each layer's Adam step is fused behind its weight-gradient call (gct2_adam_args) once the layer's dgrad -
         the last reader of its weights - is done.  The current stream joins the side stream before returning."""
         t, n, dt, A, cx = self.topo, self.topo.octaves, self.dtype, self.arena, self.ctx.handle
-        main = torch.cuda.current_stream(self.device)
+        caller = torch.cuda.current_stream(self.device)
+        main = self._chain if (self.overlap and self.chain_priority) else caller
+        if main is not caller:
+            main.wait_stream(caller)
         side = self._side if self.overlap else main
         s, sw = main.cuda_stream, side.cuda_stream
         M = b.B * b.H * b.W
         if not head_done:
             call("gct2_dense_bwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), b.dpred.data_ptr(), b.dR[0].data_ptr(),
                  b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), 0, s)
-        self._ready("dense")
+        with torch.cuda.stream(main):                           # hooks record their events on the stream the gradients come from
+            self._ready("dense")
 
         def side_waits_main() -> None:                          # side stream: everything enqueued on main so far is visible
             if side is not main:
@@ -545,6 +554,8 @@ class UNetEngine:
                 dgrad_d()
         if side is not main:
             main.wait_stream(side)
+        if main is not caller:
+            caller.wait_stream(main)
 
     # ---- optimizer (train.py:50-65,75) -----------------------------------------------------------
     def learning_rate(self, k: Optional[int] = None) -> float:
