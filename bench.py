@@ -282,16 +282,22 @@ def main():
             dom = max(tot, key=tot.get)
             achieved = fl[dom] * iso_steps / tot[dom] / 1e12
             # achieved = algorithmic FLOPs of ALL launches of the dominant family in the serial-stream steps / their summed
-            # HIP-event time (= average FLOPs per launch / average launch duration).  traffic = HBM bytes per launch from the
-            # committed PMC passes (profiles/r01_traffic.json; scripts/collect_traffic.py), only for the default config.
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            # HIP-event time (= average FLOPs per launch / average launch duration).  traffic = HBM bytes per launch of that
+            # family, NOT measured in this run: the average over its launches in the committed per-layer PMC passes
+            # (profiles/r02_traffic_per_layer.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+            # scripts/traffic_layers.py, gfx950 corrections applied), only for the default config; `traffic_source` says so.
+            traffic, traffic_source = None, None
+            tname = "r02_traffic_per_layer.json"
+            tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and (S, B, args.dtype, world) == (128, 64, "bf16", 1):
                 with open(tpath) as f:
-                    traffic = json.load(f)["families"].get(dom, {}).get("hbm_bytes_per_launch")
+                    rows = [r for r in json.load(f)["layers"] if r["form"] == {"conv_form": "conv", "convT_form": "convT", "wgrad": "wgrad"}[dom]]
+                if rows:
+                    traffic = sum(r["read_MB"] + r["write_MB"] for r in rows) * 1e6 / len(rows)
+                    traffic_source = f"profiles/{tname}: mean of {len(rows)} standalone launches of this family (rocprofv3 --pmc, committed file - not this run)"
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_PEAK, 5),
-                               "traffic": None if traffic is None else round(traffic),
+                               "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_source,
                                "flops_per_launch": fl[dom] / (cnt[dom] // iso_steps), "event_steps": iso_steps,
                                "avg_launch_us": round(tot[dom] / cnt[dom] * 1e6, 2),
                                "mode": "one stream (4 extra steps after the timed region): isolated launch durations"}
