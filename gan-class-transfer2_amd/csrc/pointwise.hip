@@ -611,7 +611,15 @@ __global__ __launch_bounds__(1024) void dense_head_finish_kernel(const float* __
   const int tid = threadIdx.x, cx = tid & 31, rl = tid >> 5;
   const int c = blockIdx.x * 32 + cx;
   double acc = 0.0;
-  for (int r = rl; r < rows; r += 32) acc += (double)part[(size_t)r * HEAD_ROW + c];
+  int r = rl;
+  for (; r + 7 * 32 < rows; r += 8 * 32) {        // 8 independent loads in flight, added in row order (same sums as one at a time)
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = part[(size_t)(r + 32 * u) * HEAD_ROW + c];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += (double)t[u];
+  }
+  for (; r < rows; r += 32) acc += (double)part[(size_t)r * HEAD_ROW + c];
   __shared__ double red[32][33];
   red[rl][cx] = acc;
   __syncthreads();
@@ -800,22 +808,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     if (slabs && (i << 2) < n_slab) {
       const f32x4_t* src = reinterpret_cast<const f32x4_t*>(slabs) + i;
       const size_t st4 = slab_stride >> 2;
-      gv = src[0];
+      gv = __builtin_nontemporal_load(src);
       int sidx = 1;
       for (; sidx + 8 <= nslab; sidx += 8) {     // 8 independent slab loads in flight, added in slab order
         f32x4_t t[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) t[u] = src[(size_t)(sidx + u) * st4];
+        for (int u = 0; u < 8; u++) t[u] = __builtin_nontemporal_load(src + (size_t)(sidx + u) * st4);
 #pragma unroll
         for (int u = 0; u < 8; u++) gv += t[u];
       }
-      for (; sidx < nslab; sidx++) gv += src[(size_t)sidx * st4];
+      for (; sidx < nslab; sidx++) gv += __builtin_nontemporal_load(src + (size_t)sidx * st4);
     } else {
       gv = reinterpret_cast<f32x4_t*>(g)[i];
       if (zero_grad) reinterpret_cast<f32x4_t*>(g)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     if (skip) continue;
-    f32x4_t pv = reinterpret_cast<f32x4_t*>(p)[i], mv = reinterpret_cast<f32x4_t*>(m)[i], vv = reinterpret_cast<f32x4_t*>(v)[i];
+    // everything here is touched once per step: streaming (nt) accesses keep it from displacing the GEMM operands in the L2s
+    f32x4_t pv = __builtin_nontemporal_load(reinterpret_cast<f32x4_t*>(p) + i), mv = __builtin_nontemporal_load(reinterpret_cast<f32x4_t*>(m) + i),
+            vv = __builtin_nontemporal_load(reinterpret_cast<f32x4_t*>(v) + i);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const float gg = gv[k] * inv_scale;
@@ -823,7 +833,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
       vv[k] = b2 * vv[k] + ob2 * gg * gg;
       pv[k] = pv[k] - alpha * mv[k] / (sqrtf(vv[k]) + eps);
     }
-    reinterpret_cast<f32x4_t*>(p)[i] = pv; reinterpret_cast<f32x4_t*>(m)[i] = mv; reinterpret_cast<f32x4_t*>(v)[i] = vv;
+    __builtin_nontemporal_store(pv, reinterpret_cast<f32x4_t*>(p) + i);
+    __builtin_nontemporal_store(mv, reinterpret_cast<f32x4_t*>(m) + i);
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4_t*>(v) + i);
     if (HAS_SHADOW) {
       if constexpr (sizeof(S) == 2) {
         u32x2_t o = {pack2<S>(pv[0], pv[1]), pack2<S>(pv[2], pv[3])};

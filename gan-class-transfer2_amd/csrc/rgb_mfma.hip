@@ -285,7 +285,8 @@ int rgb_wgrad(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradS
   if (dtype == GCT2_BF16) hipLaunchKernelGGL(rgb_wgrad_kernel<__bf16>, grid, dim3(256), lds, s, p);
   else hipLaunchKernelGGL(rgb_wgrad_kernel<_Float16>, grid, dim3(256), lds, s, p);
   if (int e = gct2_check_launch("rgb_wgrad")) return e;
-  if (p.ws && defer && !p.accumulate) { *defer = WgradSlabs{p.ws, splits, n}; return GCT2_OK; }   // the optimizer kernel sums the slabs
+  // the slabs are never handed to the fused optimizer launch (`defer`): this tensor is tiny and the slabs are many, one thread per
+  // element walking 512 slabs is latency-bound (29 us at the very end of the step); wgrad_reduce's wide form sums them in ~5 us
   if (p.ws) return wgrad_reduce(p.ws, p.dw, n, splits, p.accumulate, s);
   return GCT2_OK;
 }

@@ -193,6 +193,12 @@ class UNetEngine:
         self.wgrad_workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
         self.ctx.set_workspace(self.workspace)
         self.ctx.set_wgrad_workspace(self.wgrad_workspace)
+        # the image layer's weight gradient (HBM-bound, no LDS) is enqueued on the dgrad chain's stream, which has nothing left to
+        # do by then, so that it runs BESIDE DownShuffle_1's MFMA-bound weight gradient instead of behind it at the very end of the
+        # step; its slabs go to the chain's own scratch (free once the last input gradient is done): a second context
+        self.tail_on_chain = True
+        self.ctx_tail = _lib.Context()
+        self.ctx_tail.set_workspace(self.workspace)
         self.ls_state = None
         if loss_scaling:
             self.enable_loss_scaling()
@@ -545,6 +551,12 @@ class UNetEngine:
 
             if adam_inline:
                 dgrad_d()
+            if i == 0 and adam_inline and side is not main and self.tail_on_chain and self.workspace is not None:
+                call("gct2_conv4s2_wgrad", self.ctx_tail.handle, dt, xw, ldxw, dz, lddz, A.gptr("D0.w"), None, b.B, H, W, t.cx(0),
+                     t.fd(0), 0, fused("D0"), s)
+                with torch.cuda.stream(main):
+                    self._ready("D0")
+                continue
             side_waits_main()
             call("gct2_conv4s2_wgrad", cx, dt, xw, ldxw, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), 0,
                  fused(f"D{i}"), sw)

@@ -1,0 +1,61 @@
+"""wall time of the phases of one train step, no profiler attached (diagnostic): forward (noise .. fused head), reverse pass
+with the fused optimizer, whole step; compare with the per-kernel sums of profiles/rNN_kernel_stats*.csv to see what the
+launch boundaries cost.  usage: python scripts/bench_phases.py [iters]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gan_class_transfer2_amd as g
+from gan_class_transfer2_amd.engine import Topology, UNetEngine, BF16
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = torch.device("cuda", 0)
+eng = UNetEngine(Topology(128, 512, 6), BF16, dev)
+x = torch.rand(64, 128, 128, 3, device=dev) * 2 - 1
+b = eng.buffers(64, 128, 128)
+
+
+def fwd():
+    eng.begin_step()
+    eng.sample_and_noise_into_r0(b, x, keep_eps=False)
+    eng.forward(b, head=False, stop_before_u0=True)
+    return eng.u0_head_train(b, x)
+
+
+def bwd():
+    eng.backward(b, head_done=True, adam_inline=True)
+    eng.finish_step()
+
+
+def timed(fn, n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+for _ in range(5):
+    eng.train_step(x)
+print("step      %8.1f us" % timed(lambda: eng.train_step(x), iters))
+print("forward   %8.1f us  (back to back: host-bound if above the step's share)" % timed(fwd, iters))
+fwd()
+print("reverse   %8.1f us" % timed(bwd, iters))
+# the forward again with a device-side idle gap in front of every repetition, so the host is ahead of the GPU as in the step
+def fwd_ahead():
+    torch.cuda._sleep(4_000_000)
+    fwd()
+t_sleep = timed(lambda: torch.cuda._sleep(4_000_000), iters)
+print("forward   %8.1f us  (host ahead: enqueued behind a device-side sleep)" % (timed(fwd_ahead, iters) - t_sleep))
+# in-process A/B of engine switches (boxes differ by +-3 %, so only same-process comparisons count): GCT2_AB=attr[,attr...]
+for attr in [a for a in os.environ.get("GCT2_AB", "").split(",") if a]:
+    for rnd in range(3):
+        res = []
+        for val in (False, True):
+            setattr(eng, attr, val)
+            for _ in range(3):
+                eng.train_step(x)
+            res.append(timed(lambda: eng.train_step(x), iters))
+        print("A/B %-16s off %8.1f us   on %8.1f us" % (attr, res[0], res[1]))
