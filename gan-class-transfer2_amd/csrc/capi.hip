@@ -275,24 +275,39 @@ static int check_s1(const char* fn, int dtype, const void* a, const void* b, con
 }
 int gct2_conv2d_s1_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
                        int Cin, int Cout, int KS, int relu, void* stream) {
-  (void)ctx;
+  const gct2_ctx& c = C(ctx);
   if (int e = check_s1("conv2d_s1_fwd", dtype, x, w, y, B, H, W, Cin, Cout, KS)) return e;
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "conv2d_s1_fwd: ld smaller than channel count");
+  {   // matrix-core form (third tap-GEMM form: ks x ks taps on one grid) where the 16-bit layouts allow it, else one thread per output
+    TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H, W, Cin, Cout, relu, 0};
+    p.ks = KS;
+    if (!c.force_direct && KS <= 5 && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(c, dtype, FORM_S1, EPI_BIAS_ACT, p, S(stream));
+  }
   return conv_s1_direct(dtype, false, x, ldx, w, bias, nullptr, 0, y, ldy, B, H, W, Cin, Cout, KS, relu, 0, S(stream));
 }
 int gct2_conv2d_s1_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
                          int H, int W, int Cin, int Cout, int KS, int accumulate, void* stream) {
-  (void)ctx;
+  const gct2_ctx& c = C(ctx);
   if (int e = check_s1("conv2d_s1_dgrad", dtype, dz, w, dx, B, H, W, Cin, Cout, KS)) return e;
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "conv2d_s1_dgrad: ld smaller than channel count");
+  {
+    TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H, W, Cout, Cin, 0, accumulate};
+    p.ks = KS;
+    if (!c.force_direct && KS <= 5 && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(c, dtype, FORM_S1T, EPI_MASK, p, S(stream));
+  }
   return conv_s1_direct(dtype, true, dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H, W, Cout, Cin, KS, 0, accumulate, S(stream));
 }
 int gct2_conv2d_s1_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
                          int Cin, int Cout, int KS, int accumulate, void* stream) {
-  (void)ctx;
+  const gct2_ctx& c = C(ctx);
   if (int e = check_s1("conv2d_s1_wgrad", dtype, x, dz, dw, B, H, W, Cin, Cout, KS)) return e;
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "conv2d_s1_wgrad: ld smaller than channel count");
-  if (int e = conv_s1_wgrad_direct(dtype, x, ldx, dz, lddz, dw, B, H, W, Cin, Cout, KS, accumulate, S(stream))) return e;
+  WgradParams p{x, ldx, dz, lddz, dw, B, H, W, Cin, Cout, 1};
+  p.accumulate = accumulate ? 1 : 0;
+  p.ks = KS;
+  if (!c.force_direct && wgrad_mfma_supported(dtype, p)) {
+    if (int e = wgrad_mfma(c, dtype, p, S(stream), nullptr)) return e;
+  } else if (int e = conv_s1_wgrad_direct(dtype, x, ldx, dz, lddz, dw, B, H, W, Cin, Cout, KS, accumulate, S(stream))) return e;
   if (db) return wgrad_db(dtype, dz, lddz, db, (size_t)B * H * W, Cout, accumulate, stream);
   return GCT2_OK;
 }

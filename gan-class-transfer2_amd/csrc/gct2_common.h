@@ -108,7 +108,10 @@ template <typename T> __device__ __forceinline__ float unpack_hi(uint32_t u) {
 //             weights [tap][k][n]   (Conv2D forward, Conv2DTranspose input-gradient)
 // FORM_CONVT: out on the BIG grid, one launch-z per output parity phase, source on the SMALL grid,
 //             4 taps per phase, weights [tap][n][k]   (Conv2DTranspose forward, Conv2D input-gradient)
-enum { FORM_CONV = 0, FORM_CONVT = 1 };
+// FORM_S1   : 'same' stride-1 convolution with ks x ks taps (Block's 3x3, the 1x1 projection of residual=True; train.py:104-143):
+//             out and source on ONE grid, tap (dh, dw) reads (h + dh - pad, w + dw - pad), weights [tap][k][n] like FORM_CONV
+// FORM_S1T  : its input gradient: the same walk with the taps flipped, weights [tap][n][k] like FORM_CONVT
+enum { FORM_CONV = 0, FORM_CONVT = 1, FORM_S1 = 2, FORM_S1T = 3 };
 enum { EPI_BIAS_ACT = 0, EPI_MASK = 1, EPI_HEAD = 2 };
 
 // Keras' mixed_float16 policy (train.py:43-45) makes the Dense output and the gradient entering it fp16 tensors; the loss is
@@ -150,6 +153,7 @@ struct TapGemmParams {
   int db_acc;                            // bit 0: db is added to (else overwritten); bit 1: the same for db2
   float* dbws;                           // partial bias-gradient rows [m_tiles*phases | finalize rows][N] in the workspace, or null (atomics)
   HeadFuse head;                         // EPI_HEAD only
+  int ks = 0;                            // FORM_S1 / FORM_S1T: kernel size (odd, <= 5)
 };
 
 // XCD-aware work-group -> tile map.  The dispatcher deals consecutive work-group ids round-robin over the 8
@@ -179,6 +183,7 @@ struct WgradParams {
   int rsplit;                     // number of r-range splits
   float* ws;                      // partial-tile slabs [rsplit][16*Cb][Cs] in the registered workspace, or null (atomics)
   int accumulate;                 // 1: dw += result (caller keeps a running / pre-zeroed gradient); 0: dw = result
+  int ks = 0;                     // 0: the 4x4 / stride-2 layers; odd ks: 'same' stride-1 convolution (both tensors on one grid, ks*ks taps)
 };
 // wgrad_mfma(): when `defer` is non-null and the launch left its result as workspace slabs, the slab reduction is NOT launched and
 // the slabs are described here (the caller folds them into the optimizer read); nslab = 0 means dw holds the gradient

@@ -66,14 +66,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   constexpr int NWV = (BM / WM) * (BN / 64);       // waves, each a WM x 64 sub-tile
   constexpr int MF = WM / 16;                      // 16-pixel fragments per wave
   static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
-  static_assert(FORM == FORM_CONVT || BN % 128 == 0, "T images are 128 columns wide");
+  constexpr bool S1 = (FORM == FORM_S1 || FORM == FORM_S1T);   // stride-1 'same' convolution: p.ks x p.ks taps on the output's own grid
+  constexpr bool WT = (FORM == FORM_CONV || FORM == FORM_S1);   // weights [tap][k][n] (T image); otherwise [tap][n][k] (N image)
+  static_assert(!WT || BN % 128 == 0, "T images are 128 columns wide");
   constexpr int WAVES_N = BN / 64;
   constexpr int NA = BM / 8 / NWV;                 // 1-KiB pieces per wave, activation tile (8 rows each)
-  constexpr int NW = ((FORM == FORM_CONV) ? 16 * (BN / 128) : BN / 8) / NWV;
+  constexpr int NW = (WT ? 16 * (BN / 128) : BN / 8) / NWV;
   constexpr int NDMA = NA + NW;                    // DMA instructions per wave per step
   constexpr int A_BYTES = BM * 128;
-  constexpr int W_BYTES = (FORM == FORM_CONV) ? 64 * 256 * (BN / 128) : BN * 128;   // FORM_CONV: BN/128 T images side by side
-  constexpr int NTAPS = (FORM == FORM_CONV) ? 16 : 4;
+  constexpr int W_BYTES = WT ? 64 * 256 * (BN / 128) : BN * 128;   // T images: BN/128 of them side by side
+  constexpr int NTAPS = (FORM == FORM_CONV) ? 16 : 4;              // (the stride-1 forms: p.ks * p.ks, run-time)
 
   // DISTINCT LDS objects: lets hipcc prove that the DMA into one buffer does not alias the ds_reads of another,
   // so it does not drain vmcnt before every read (cdna_hip_programming.md, "Three .s-level traps" (a))
@@ -125,14 +127,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     if (m < M) {
       const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
       // origin = the tap with the smallest row/column: (2sh-1, 2sw-1) for conv, (sh+ph-1, sw+pw-1) for convT
-      const int h0 = (FORM == FORM_CONV) ? 2 * sh - 1 : sh + ph - 1;
-      const int w0 = (FORM == FORM_CONV) ? 2 * sw - 1 : sw + pw - 1;
+      const int h0 = (FORM == FORM_CONV) ? 2 * sh - 1 : (S1 ? sh - (p.ks - 1) / 2 : sh + ph - 1);
+      const int w0 = (FORM == FORM_CONV) ? 2 * sw - 1 : (S1 ? sw - (p.ks - 1) / 2 : sw + pw - 1);
       a_off[i] = (unsigned)(((b * Hsrc + h0) * Wsrc + w0) * ldx2 + a_lchunk * 16);   // may wrap below 0: only used when valid
-      constexpr int TW = (FORM == FORM_CONV) ? 4 : 2;
+      if constexpr (S1) {
+        for (int t2 = 0; t2 < p.ks * p.ks; t2++) {
+          const int dh = t2 / p.ks, dw = t2 - dh * p.ks;
+          if ((unsigned)(h0 + dh) < (unsigned)Hsrc && (unsigned)(w0 + dw) < (unsigned)Wsrc) a_mask[i] |= 1u << t2;
+        }
+      } else {
+        constexpr int TW = (FORM == FORM_CONV) ? 4 : 2;
 #pragma unroll
-      for (int t2 = 0; t2 < NTAPS; t2++) {
-        const int dh = t2 / TW, dw = t2 % TW;
-        if ((unsigned)(h0 + dh) < (unsigned)Hsrc && (unsigned)(w0 + dw) < (unsigned)Wsrc) a_mask[i] |= 1u << t2;
+        for (int t2 = 0; t2 < NTAPS; t2++) {
+          const int dh = t2 / TW, dw = t2 % TW;
+          if ((unsigned)(h0 + dh) < (unsigned)Hsrc && (unsigned)(w0 + dw) < (unsigned)Wsrc) a_mask[i] |= 1u << t2;
+        }
       }
     }
   }
@@ -142,7 +151,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   int w_k[NW];                                     // FORM_CONV: k row inside the 64-step; FORM_CONVT: unused
 #pragma unroll
   for (int i = 0; i < NW; i++) {
-    if (FORM == FORM_CONV) {                       // T image: piece = 4 k-rows x 16 chunks
+    if (WT) {                                      // T image: piece = 4 k-rows x 16 chunks
       const int q = wave + NWV * i;                // pieces 0..15 fill image 0 (columns n0..n0+127), 16..31 image 1
       const int k = 4 * (q & 15) + (lane >> 4);
       const int lc = ((((lane & 15) >> 1) ^ timg_swz(k)) << 1) | (lane & 1);
@@ -159,19 +168,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   }
 
   const int nk = (K + BK - 1) / BK;
-  const int niter = NTAPS * nk;
+  const int niter = (S1 ? p.ks * p.ks : NTAPS) * nk;
 
   auto issue = [&](int it, char* abase) {
     const int tap = it / nk, c0 = (it - tap * nk) * BK;
     int tap16, dh, dw;
     if (FORM == FORM_CONV) { tap16 = tap; dh = tap >> 2; dw = tap & 3; }
-    else {
+    else if (S1) {                                 // the input gradient walks the same window with the kernel flipped
+      dh = tap / p.ks; dw = tap - dh * p.ks;
+      tap16 = (FORM == FORM_S1) ? tap : (p.ks - 1 - dh) * p.ks + (p.ks - 1 - dw);
+    } else {
       // source row sh+ph-a  = origin + (1-a); kernel row kh = 1-ph+2a
       const int a = tap >> 1, c = tap & 1;
       dh = 1 - a; dw = 1 - c;
       tap16 = (1 - ph + 2 * a) * 4 + (1 - pw + 2 * c);
     }
-    const int abit = (FORM == FORM_CONV) ? tap : dh * 2 + dw;
+    const int abit = (FORM == FORM_CONVT) ? dh * 2 + dw : tap;
     const unsigned tapoff = (unsigned)((dh * Wsrc + dw) * ldx2 + c0 * 2);
     const bool a_cok = (c0 + a_lchunk * 8) < K;
 #pragma unroll
@@ -180,7 +192,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       dma16<NBUF == 3>(rs_x, abase + (wave + NWV * i) * 1024, ok ? a_off[i] + tapoff : OOB);
     }
     char* wbase = abase + A_BYTES;
-    const unsigned wtap = (FORM == FORM_CONV) ? (unsigned)(((tap16 * K + c0) * N) * 2) : (unsigned)((tap16 * N * K + c0) * 2);
+    const unsigned wtap = WT ? (unsigned)(((tap16 * K + c0) * N) * 2) : (unsigned)((tap16 * N * K + c0) * 2);
 #pragma unroll
     for (int i = 0; i < NW; i++) {
       const bool ok = w_nok[i] && (c0 + w_k[i]) < K;
@@ -204,7 +216,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       u32x4_t wf[4], af[MF];
 #pragma unroll
       for (int i = 0; i < 4; i++)
-        wf[i] = (FORM == FORM_CONV) ? timg_frag(w_img + (wn >> 1) * (64 * 256), (wn & 1) * 64 + i * 16, kk, lane)
+        wf[i] = WT ? timg_frag(w_img + (wn >> 1) * (64 * 256), (wn & 1) * 64 + i * 16, kk, lane)
                                     : nimg_frag(w_img, wn * 64 + i * 16, kk, lane);
 #pragma unroll
       for (int j = 0; j < MF; j++) af[j] = nimg_frag(a_img, wm * WM + j * 16, kk, lane);
@@ -306,7 +318,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       const int m = m0 + wm * WM + j * 16 + (elane & 15);
       if (m >= M) continue;
       size_t opix;
-      if (FORM == FORM_CONV) opix = (size_t)m;
+      if (FORM != FORM_CONVT) opix = (size_t)m;
       else {
         const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
         opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
@@ -358,7 +370,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     const int m = m0 + wm * WM + j * 16 + (elane & 15);
     if (m >= M) continue;
     size_t opix;
-    if (FORM == FORM_CONV) opix = (size_t)m;
+    if (FORM != FORM_CONVT) opix = (size_t)m;
     else {
       const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
       opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
@@ -549,7 +561,8 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   const int M = p.B * p.Hs * p.Ws;
   constexpr int PH = FORM == FORM_CONVT ? 4 : 1;
   const int tiles = ((M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * PH;
-  const int niter = (FORM == FORM_CONV ? 16 : 4) * ((p.K + BK - 1) / BK);
+  const int ntaps = FORM == FORM_CONV ? 16 : (FORM == FORM_CONVT ? 4 : p.ks * p.ks);
+  const int niter = ntaps * ((p.K + BK - 1) / BK);
   const size_t npix = (size_t)M * PH;
   // small-M layers (bottleneck of the U-Net) cannot fill 256 CUs with output tiles: split the reduction
   p.ksplit = 1;
@@ -580,7 +593,7 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   // tile -> XCD order: by default an XCD owns a band of m-tiles (the source pixels are re-read by every n-tile / phase / tap); when
   // the weight tensor is the bigger operand and there are at least 8 weight slices, an XCD owns weight slices instead (p.wstat)
-  const size_t w_bytes = (size_t)16 * p.K * p.N * 2, src_bytes = (size_t)M * (FORM == FORM_CONV ? 4 : 1) * p.ldx * 2;
+  const size_t w_bytes = (size_t)(FORM == FORM_CONV || FORM == FORM_CONVT ? 16 : ntaps) * p.K * p.N * 2, src_bytes = (size_t)M * (FORM == FORM_CONV ? 4 : 1) * p.ldx * 2;
   const int slices = p.n_tiles * PH * p.ksplit;
   p.wstat = (c.xcd_order == 2 || (c.xcd_order == 0 && w_bytes >= 3 * src_bytes)) && slices >= 8 ? 1 : 0;   // measured per layer: profiles/r02_layers.txt
   dim3 grid(p.wstat ? 8 * ((slices + 7) / 8) * p.m_tiles : 8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
@@ -601,6 +614,10 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
 template <typename T>
 int dispatch(const gct2_ctx& c, int form, int epi, const TapGemmParams& p, hipStream_t s) {
   const int g_tapgemm_variant = c.tap_variant;
+  // the stride-1 forms (off-by-default model variants): one tile shape; the epilogue is the forward's / the input gradient's
+  // (tapgemm_mfma checks the pairing)
+  if (form == FORM_S1) return launch<T, FORM_S1, 128, 128, EPI_BIAS_ACT, 2>(c, p, s);
+  if (form == FORM_S1T) return launch<T, FORM_S1T, 128, 128, EPI_MASK, 2>(c, p, s);
   // big layers: 256 x 128 tile, 8 waves, 3 LDS buffers; layers with few output pixels keep the 128 x 128 tile
   // (more work-groups + split-K); N <= 64 (UpShuffle_0) uses the 256 x 64 tile
   const int M = p.B * p.Hs * p.Ws;
@@ -672,6 +689,12 @@ int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, h
 }
 
 int tapgemm_mfma(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s) {
+  if (form == FORM_S1 || form == FORM_S1T) {
+    if (epi != (form == FORM_S1 ? EPI_BIAS_ACT : EPI_MASK) || p.ks < 1 || p.ks > 5 || !(p.ks & 1))
+      return gct2_fail(GCT2_EINVAL, "tapgemm_mfma: stride-1 form with kernel size %d / epilogue %d", p.ks, epi);
+    if (dtype == GCT2_BF16) return dispatch<__bf16>(c, form, epi, p, s);
+    return dispatch<_Float16>(c, form, epi, p, s);
+  }
   if (form == FORM_CONVT && c.tap_variant == 0 && halo_convT_wanted(c, epi, p)) return halo_convT(c, dtype, epi, p, s);
   if (dtype == GCT2_BF16) return dispatch<__bf16>(c, form, epi, p, s);
   return dispatch<_Float16>(c, form, epi, p, s);

@@ -29,9 +29,12 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_pie
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
 }
 
-template <typename T, int NBUF>
+// S1: the weight gradient of a 'same' stride-1 convolution with p.ks x p.ks taps (Block's 3x3, the 1x1 projection of residual=True:
+// train.py:104-143): both tensors on ONE grid, tap (kh, kw) pairs pixel r with (h + kh - pad, w + kw - pad); everything else is shared.
+template <typename T, int NBUF, bool S1 = false>
 __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradParams p) {
   constexpr int IMG = 64 * 256;
+  const int KS = S1 ? p.ks : 4, STRIDE = S1 ? 1 : 2, PAD = S1 ? (p.ks - 1) / 2 : 1;   // compile-time constants for the 4x4 layers
   __shared__ __attribute__((aligned(16))) char lds0[2 * IMG];     // [big image | small image]
   __shared__ __attribute__((aligned(16))) char lds1[NBUF == 2 ? 2 * IMG : 16];
 
@@ -39,9 +42,9 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wm = wave >> 1;
   const int Hs = p.Hs, Ws = p.Ws, Cb = p.Cb, Cs = p.Cs;
-  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  const int Hb = STRIDE * Hs, Wb = STRIDE * Ws;
   const int R = p.B * Hs * Ws;
-  const int GC = 16 * Cb;
+  const int GC = KS * KS * Cb;
   const int tiles_n = (Cs + 127) / 128;
   // XCD-aware 1-D grid: all output tiles of one r-split re-read the same rows of both operands, so a whole split
   // runs on ONE XCD (ids with equal id % 8 share an L2); with fewer than 8 splits the plain order is kept
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
   const int gc = gc0 + lc * 8;
   const bool gc_ok = gc < GC;
   const int tap = gc_ok ? gc / Cb : 0, cb = gc_ok ? gc - tap * Cb : 0;
-  const int kh = tap >> 2, kw = tap & 3;
+  const int kh = S1 ? tap / KS : tap >> 2, kw = S1 ? tap - kh * KS : tap & 3;
   const bool cs_ok = (cs0 + lc * 8) < Cs;
   const int ldb2 = p.ldbig * 2, lds2 = p.ldsmall * 2;
 
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = step * 64 + row0 + 16 * i;
-      const int h = 2 * rh[i] + kh - 1, w = 2 * rw[i] + kw - 1;
+      const int h = STRIDE * rh[i] + kh - PAD, w = STRIDE * rw[i] + kw - PAD;
       const bool okb = gc_ok && r < R && (unsigned)h < (unsigned)Hb && (unsigned)w < (unsigned)Wb;
       const unsigned offb = (unsigned)(((rb[i] * Hb + h) * Wb + w) * ldb2 + cb * 2);
       dma16(rs_b, base + (wave + 4 * i) * 1024, okb ? offb : OOB);
@@ -546,7 +549,8 @@ bool wgrad_mfma_supported(int dtype, const WgradParams& p) {
   if (dtype != GCT2_BF16 && dtype != GCT2_F16) return false;
   if (p.Cb % 8 || p.Cs % 8 || p.ldbig % 8 || p.ldsmall % 8) return false;
   if ((uintptr_t)p.big % 16 || (uintptr_t)p.small % 16 || (uintptr_t)p.dw % 16) return false;    // 16-byte loads and stores
-  const size_t big_bytes = (size_t)p.B * p.Hs * p.Ws * 4 * p.ldbig * 2, small_bytes = (size_t)p.B * p.Hs * p.Ws * p.ldsmall * 2;
+  if (p.ks && (p.ks < 1 || p.ks > 7 || !(p.ks & 1))) return false;
+  const size_t big_bytes = (size_t)p.B * p.Hs * p.Ws * (p.ks ? 1 : 4) * p.ldbig * 2, small_bytes = (size_t)p.B * p.Hs * p.Ws * p.ldsmall * 2;
   if (big_bytes >= 0x7ff00000u || small_bytes >= 0x7ff00000u) return false;     // 31-bit buffer offsets
   return true;
 }
@@ -555,14 +559,15 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   if (defer) *defer = WgradSlabs{nullptr, 0, 0};
   const int g_wgrad_variant = c.wgrad_variant, g_wgrad_target = c.wgrad_target, g_wgrad_slab_max = c.wgrad_slab_max, g_wgrad_pipe = c.wgrad_pipe;
   const int R = p.B * p.Hs * p.Ws;
+  const int taps = p.ks ? p.ks * p.ks : 16;          // p.ks != 0: stride-1 'same' convolution (128 x 128 tile kernels only)
   // 256 x 256 tile (one work-group per CU) whenever the 128 x 128 tiling would have to split the reduction anyway
   // (fewer than 512 tiles): measured -10..-22 % on U0/U1/U2/D1/D2 (profiles/r01_wgrad_variants.txt)
-  const int tiles128 = ((16 * p.Cb + 127) / 128) * ((p.Cs + 127) / 128);
-  const int tiles256 = ((16 * p.Cb + 255) / 256) * ((p.Cs + 255) / 256);
+  const int tiles128 = ((taps * p.Cb + 127) / 128) * ((p.Cs + 127) / 128);
+  const int tiles256 = ((taps * p.Cb + 255) / 256) * ((p.Cs + 255) / 256);
   const int blocks256 = tiles256 * std::max(1, std::min((g_wgrad_target + tiles256 - 1) / tiles256, ((R + 63) / 64) / 4));
   // ... and only if the big tiling still yields ~one work-group per CU (the 2x2 / 4x4 bottleneck levels have too few pixels)
-  const bool big_tile = g_wgrad_variant == 2 || (g_wgrad_variant == 0 && tiles128 < 512 && blocks256 >= 192);
-  const int tiles = big_tile ? ((16 * p.Cb + 255) / 256) * ((p.Cs + 255) / 256) : ((16 * p.Cb + 127) / 128) * ((p.Cs + 127) / 128);
+  const bool big_tile = !p.ks && (g_wgrad_variant == 2 || (g_wgrad_variant == 0 && tiles128 < 512 && blocks256 >= 192));
+  const int tiles = big_tile ? tiles256 : tiles128;
   const int steps_total = (R + 63) / 64;
   // aim at ~768 workgroups (3 per CU; 512 for the big tile) but keep >= 4 steps of 64 rows per split; one owner per tile
   // once the tiles alone give every CU a work-group
@@ -572,7 +577,7 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   rsplit = (steps_total + per - 1) / per;            // every split non-empty (each one owns a slab)
   p.rsplit = rsplit;
   p.ws = nullptr;
-  const size_t n = (size_t)16 * p.Cb * p.Cs;
+  const size_t n = (size_t)taps * p.Cb * p.Cs;
   size_t ws_bytes = 0;
   float* ws = c.wgrad_scratch(&ws_bytes);
   // measured (scripts/bench_wgrad.py): slabs beat atomics up to ~24 splits; beyond that (UpShuffle_0: 16 tiles x 48
@@ -585,7 +590,10 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
     (void)hipMemsetAsync(p.dw, 0, n * sizeof(float), s);
   }
   const bool one_buf = g_wgrad_variant == 1;
-  if (big_tile && g_wgrad_pipe) {
+  if (p.ks) {
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad_kernel<__bf16, 2, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<_Float16, 2, true>), grid, dim3(256), 0, s, p);
+  } else if (big_tile && g_wgrad_pipe) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256p_kernel<__bf16>, grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL(wgrad256p_kernel<_Float16>, grid, dim3(512), 0, s, p);
   } else if (big_tile) {

@@ -138,8 +138,10 @@ int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const 
  * its (Cin, Cout) kernel the same memory as (1, 1, Cin, Cout)).  Stride-1 'same' convolution, KS odd (symmetric padding):
  *   y[b,h,w,o] = act(bias[o] + sum_{kh,kw,i} x[b,h+kh-p,w+kw-p,i] w[kh,kw,i,o]),  p = (KS-1)/2;  w: (KS,KS,Cin,Cout) of `dtype`.
  * dgrad: dx[b,h,w,i] (+)= mask * sum dz[b,h-kh+p,w-kw+p,o] w[kh,kw,i,o] (mask / accumulate as for conv4s2_dgrad);
- * wgrad: dw (+)= sum x dz (fp32), db (+)= column sums of dz.  Direct kernels (one thread per output), every dtype: these layers are
- * unreachable at the reference's defaults and are built for results, not for the roofline. */
+ * wgrad: dw (+)= sum x dz (fp32), db (+)= column sums of dz.  16-bit dtypes with whole 8-channel chunks (Cin, Cout and the lds
+ * multiples of 8, 16-byte aligned views, KS <= 5) run on the matrix cores as a third tap-GEMM form (KS x KS taps on one grid;
+ * split-K / slabs through the ctx scratch like the 4x4 layers); fp32 and the remaining shapes (the 3-channel input of a Block in
+ * front of level 0) on direct kernels, one thread per output. */
 int gct2_conv2d_s1_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy,
                        int B, int H, int W, int Cin, int Cout, int KS, int relu, void* stream);
 int gct2_conv2d_s1_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact,

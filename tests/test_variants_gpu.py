@@ -40,12 +40,25 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# 16-bit shapes with whole 8-channel chunks take the matrix-core forms (FORM_S1 / FORM_S1T of tapgemm_mfma.hip, the stride-1 mode of
+# wgrad_kernel): ragged K and N, several m-/n-tiles, borders on every side, 1x1 / 3x3 / 5x5; the others (3 input channels, N % 8 != 0,
+# fp32) the direct kernels.  with_ctx: a context with scratch, so that the reduction is split over work-groups (slabs + finalize).
+@pytest.mark.parametrize("with_ctx", [False, True])
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
-@pytest.mark.parametrize("shape", [(2, 8, 8, 16, 24, 3), (1, 5, 7, 3, 8, 3), (2, 6, 4, 40, 12, 1), (1, 16, 16, 64, 64, 3)])
-def test_conv2d_s1_kernels(gpu, dt, shape):
+@pytest.mark.parametrize("shape", [(2, 8, 8, 16, 24, 3), (1, 5, 7, 3, 8, 3), (2, 6, 4, 40, 12, 1), (1, 16, 16, 64, 64, 3),
+                                   (3, 12, 20, 72, 136, 3), (2, 6, 4, 40, 16, 1), (1, 9, 11, 24, 40, 5), (2, 4, 4, 264, 128, 3)])
+def test_conv2d_s1_kernels(gpu, dt, shape, with_ctx):
     import gan_class_transfer2_amd as g
     L = g._lib
     B, H, W, Cin, Cout, KS = shape
+    ctx = None
+    if with_ctx:
+        if dt == F32 or shape[3] % 8 or shape[4] % 8:
+            pytest.skip("direct kernels take no scratch")
+        ctx_obj = L.Context()
+        scratch = torch.empty(8 << 20, dtype=torch.float32, device=gpu)
+        ctx_obj.set_workspace(scratch)
+        ctx = ctx_obj.handle
     rng = np.random.default_rng(21)
     x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
     w = rnd(rng.standard_normal((KS, KS, Cin, Cout)) * 0.2, dt)
@@ -56,7 +69,7 @@ def test_conv2d_s1_kernels(gpu, dt, shape):
     yb = torch.full((B, H, W, ldy), 7.0, dtype=TDT[dt], device=gpu)
     wd, bd = dev(w, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
     es = xb.element_size()
-    L.call("gct2_conv2d_s1_fwd", None, dt, xb.data_ptr() + 8 * es, ldx, wd.data_ptr(), bd.data_ptr(), yb.data_ptr(), ldy, B, H, W, Cin, Cout, KS, 1, stream())
+    L.call("gct2_conv2d_s1_fwd", ctx, dt, xb.data_ptr() + 8 * es, ldx, wd.data_ptr(), bd.data_ptr(), yb.data_ptr(), ldy, B, H, W, Cin, Cout, KS, 1, stream())
     torch.cuda.synchronize()
     assert rel_l2(yb[..., :Cout].double().cpu().numpy(), np.maximum(V.conv_s1_fwd(x, w, b), 0)) <= TOL_OUT[dt]
     assert float((yb[..., Cout:].float() - 7).abs().max()) == 0
@@ -65,9 +78,9 @@ def test_conv2d_s1_kernels(gpu, dt, shape):
     prev = rnd(rng.standard_normal((B, H, W, Cin)), dt)
     dx_ref, dw_ref, db_ref = V.conv_s1_bwd(x, w, dz)
     dzd, xd, dxd = dev(dz, dt, gpu), dev(x, dt, gpu), dev(prev, dt, gpu)
-    L.call("gct2_conv2d_s1_dgrad", None, dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dxd.data_ptr(), Cin, B, H, W, Cin, Cout, KS, 1, stream())
+    L.call("gct2_conv2d_s1_dgrad", ctx, dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dxd.data_ptr(), Cin, B, H, W, Cin, Cout, KS, 1, stream())
     dw = torch.full((KS, KS, Cin, Cout), 5.0, device=gpu); db = torch.full((Cout,), 5.0, device=gpu)
-    L.call("gct2_conv2d_s1_wgrad", None, dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(), B, H, W, Cin, Cout, KS, 0, stream())
+    L.call("gct2_conv2d_s1_wgrad", ctx, dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), db.data_ptr(), B, H, W, Cin, Cout, KS, 0, stream())
     torch.cuda.synchronize()
     assert rel_l2(dxd.double().cpu().numpy(), dx_ref * (x > 0) + prev) <= TOL_OUT[dt]
     assert rel_l2(dw.cpu().numpy(), dw_ref) <= TOL_F32OUT[dt] and rel_l2(db.cpu().numpy(), db_ref) <= TOL_F32OUT[dt]
