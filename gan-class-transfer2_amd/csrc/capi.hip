@@ -160,6 +160,7 @@ int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   ctx->wgrad_slab_max = (wv & 0x20) ? 64 : 24;
   ctx->halo_mode = (v >> 24) & 3;
   ctx->xcd_order = (v >> 26) & 3;
+  ctx->wgrad_split = (v >> 28) & 7;
   return GCT2_OK;
 }
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on) {

@@ -566,12 +566,18 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   const int tiles256 = ((taps * p.Cb + 255) / 256) * ((p.Cs + 255) / 256);
   const int blocks256 = tiles256 * std::max(1, std::min((g_wgrad_target + tiles256 - 1) / tiles256, ((R + 63) / 64) / 4));
   // ... and only if the big tiling still yields ~one work-group per CU (the 2x2 / 4x4 bottleneck levels have too few pixels)
-  const bool big_tile = !p.ks && (g_wgrad_variant == 2 || (g_wgrad_variant == 0 && tiles128 < 512 && blocks256 >= 192));
+  // ... and only below 256 small tiles: from there on the 128 x 128 tiling fills the chip with at most TWO pixel splits, and a
+  // big-tile launch always leaves 256 work-groups x 256 KiB = 64 MiB of slabs (written here, read back by the optimizer), whatever
+  // the size of the tensor.  Measured r02 (scripts/bench_wgrad.py, incl. the slab sum): DownShuffle_4 35 -> 18 us (one owner per
+  // tile, no slabs), DownShuffle_3 57 -> 48, UpShuffle_2 153-160 -> 145 (two splits: 32 MiB of slabs instead of 64); in the step -5..-25 us (in-process A/B)
+  const bool big_tile = !p.ks && (g_wgrad_variant == 2 || (g_wgrad_variant == 0 && tiles128 < 256 && blocks256 >= 192));
   const int tiles = big_tile ? tiles256 : tiles128;
   const int steps_total = (R + 63) / 64;
   // aim at ~768 workgroups (3 per CU; 512 for the big tile) but keep >= 4 steps of 64 rows per split; one owner per tile
   // once the tiles alone give every CU a work-group
   int rsplit = big_tile ? (g_wgrad_target + tiles - 1) / tiles : (tiles >= 512 ? 1 : (768 + tiles - 1) / tiles);
+  if (!big_tile && tiles >= 256 && tiles < 512) rsplit = steps_total >= 32 ? 2 : 1;    // two work-groups per CU once the reduction is long enough
+  if (!big_tile && c.wgrad_split) rsplit = c.wgrad_split;
   rsplit = max(1, min(rsplit, steps_total / 4));
   const int per = (steps_total + rsplit - 1) / rsplit;
   rsplit = (steps_total + per - 1) / per;            // every split non-empty (each one owns a slab)

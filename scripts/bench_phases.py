@@ -59,3 +59,14 @@ for attr in [a for a in os.environ.get("GCT2_AB", "").split(",") if a]:
                 eng.train_step(x)
             res.append(timed(lambda: eng.train_step(x), iters))
         print("A/B %-16s off %8.1f us   on %8.1f us" % (attr, res[0], res[1]))
+
+if os.environ.get("GCT2_AB_ENV"):
+    name = os.environ["GCT2_AB_ENV"]
+    for rnd in range(4):
+        res = []
+        for val in ("1", "0"):
+            os.environ[name] = val
+            for _ in range(3):
+                eng.train_step(x)
+            res.append(timed(lambda: eng.train_step(x), iters))
+        print("A/B env %-20s =1 %8.1f us   =0 %8.1f us" % (name, res[0], res[1]))

@@ -12,7 +12,8 @@ CTX = L.Context(); CTX.set_workspace(ws)   # code 7 = keep atomics although a wo
 LAYERS = {  # name: (kind, H, W, Cin, Cout) with H, W = spatial size of the layer INPUT
     "U0.wgrad": ("convT", 64, 64, 256, 64), "U1.wgrad": ("convT", 32, 32, 512, 128), "U2.wgrad": ("convT", 16, 16, 1024, 256),
     "U3.wgrad": ("convT", 8, 8, 1024, 512), "D1.wgrad": ("conv", 64, 64, 128, 256), "D2.wgrad": ("conv", 32, 32, 256, 512),
-    "D3.wgrad": ("conv", 16, 16, 512, 512),
+    "D3.wgrad": ("conv", 16, 16, 512, 512), "D4.wgrad": ("conv", 8, 8, 512, 512), "D5.wgrad": ("conv", 4, 4, 512, 512),
+    "U5.wgrad": ("convT", 2, 2, 512, 512), "U4.wgrad": ("convT", 4, 4, 1024, 512),
 }
 def run(name, code, iters=20):
     kind, H, W, Cin, Cout = LAYERS[name]
@@ -22,12 +23,12 @@ def run(name, code, iters=20):
     if kind == "conv":
         x = torch.randn(B, H, W, Cin, device=dev).to(bf); dz = torch.randn(B, H // 2, W // 2, Cout, device=dev).to(bf)
         dw = torch.zeros(4, 4, Cin, Cout, device=dev)
-        f = lambda: L.call("gct2_conv4s2_wgrad", CTX.handle, 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, s)
+        f = lambda: L.call("gct2_conv4s2_wgrad", CTX.handle, 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, None, s)
         flops = 2.0 * B * (H // 2) * (W // 2) * Cout * 16 * Cin
     else:
         x = torch.randn(B, H, W, Cin, device=dev).to(bf); dz = torch.randn(B, 2 * H, 2 * W, Cout, device=dev).to(bf)
         dw = torch.zeros(4, 4, Cout, Cin, device=dev)
-        f = lambda: L.call("gct2_convT4s2_wgrad", CTX.handle, 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 1, None, s)
+        f = lambda: L.call("gct2_convT4s2_wgrad", CTX.handle, 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, None, s)
         flops = 2.0 * B * H * W * Cout * 16 * Cin
     for _ in range(3): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
