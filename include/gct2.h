@@ -58,7 +58,7 @@ int gct2_ctx_set_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
 int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
 /* tuning (same results for every value; tests cover each tile, scripts/bench_layer.py does A/B timing).
  * bits 0-7: dgrad/forward tile, 0 = automatic, 1/2 = 128x128 with 1/2 LDS buffers, 3 = 256x128 8 waves 3 buffers,
- * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles), 7 = 256x256 pipelined;
+ * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles);
  * bits 16-19: weight-gradient tile, 0 = automatic, 1/3 = 128x128 with 1/2 buffers, 2 = 256x256, 7 = atomics;
  * bit 22: 256x256 weight-gradient tile with two 64-row buffers instead of the four-stage pipeline;
  * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D dgrad), 0 = automatic, 1 = never, 2 = wherever the shape allows;
