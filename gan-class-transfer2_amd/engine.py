@@ -185,11 +185,14 @@ class UNetEngine:
         self.overlap = True
         self.fuse_adam = True          # per-layer Adam fused behind the weight-gradient calls (single replica, no loss scaling)
         self._side = torch.cuda.Stream(device=self.device)
-        # the dgrad chain (the only true dependency chain of the reverse pass, with its short split-K finalize / row-sum launches)
-        # runs on a HIGH-priority stream: its work-groups are dispatched ahead of the side stream's queued weight-gradient
-        # work-groups as CU slots free up, instead of waiting behind a whole full-chip grid
-        self.chain_priority = True
-        self._chain = torch.cuda.Stream(device=self.device, priority=-1)
+        # chain_priority: run the dgrad chain (the only true dependency chain of the reverse pass, with its short split-K finalize /
+        # row-sum launches) on a HIGH-priority stream of its own, so that its work-groups are dispatched ahead of the side stream's
+        # queued weight-gradient work-groups.  Worth -2 % when it was introduced (r02.c); since the image layer's weight gradient
+        # left the tail and the bottleneck weight gradients shrank it measures +0.8 % in an in-process A/B (scripts/bench_phases.py,
+        # GCT2_AB=chain_priority: 2.743 vs 2.765 ms), and every additional stream is a hazard once more than GPU_MAX_HW_QUEUES = 4
+        # are in use (distributed._one_stream_less): off by default, the stream is created on first use
+        self.chain_priority = False
+        self._chain_stream = None
         self.wgrad_workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
         self.ctx.set_workspace(self.workspace)
         self.ctx.set_wgrad_workspace(self.wgrad_workspace)
@@ -469,7 +472,9 @@ class UNetEngine:
         the last reader of its weights - is done.  The current stream joins the side stream before returning."""
         t, n, dt, A, cx = self.topo, self.topo.octaves, self.dtype, self.arena, self.ctx.handle
         caller = torch.cuda.current_stream(self.device)
-        main = self._chain if (self.overlap and self.chain_priority) else caller
+        if self.overlap and self.chain_priority and self._chain_stream is None:
+            self._chain_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        main = self._chain_stream if (self.overlap and self.chain_priority) else caller
         if main is not caller:
             main.wait_stream(caller)
         side = self._side if self.overlap else main
