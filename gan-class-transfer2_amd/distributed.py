@@ -85,8 +85,8 @@ class BucketedAllReducer:
 
 def _one_stream_less(engine, exchange: bool) -> None:
     """The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues, and streams that share a queue
-    block each other (a stream waiting for an event stalls its queue-mate).  The single-GPU step uses three (caller, the
-    high-priority input-gradient chain, the weight-gradient side stream); an exchange adds the communication stream and the
+    block each other (a stream waiting for an event stalls its queue-mate).  With engine.chain_priority the single-GPU step uses three
+    (caller, the high-priority input-gradient chain, the weight-gradient side stream); an exchange adds the communication stream and the
     collective library's own, which pushed the chain onto a shared queue: measured on one rank with the exchange forced
     (scripts/bench_dp_overhead.py) 3.99 ms (all-reduce) / 4.24 ms (sharded) per step against 2.76 ms without exchange.  With the
     chain back on the caller's stream: 2.80 / 3.00 ms (the latter with the whole optimizer on one rank; it is 1/N per rank)."""
