@@ -43,7 +43,7 @@ __device__ __forceinline__ u32x4_t gather_chunk(const T* __restrict__ x, int ldx
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void rgb_fwd_kernel(TapGemmParams p) {
+__global__ __launch_bounds__(256, 4) void rgb_fwd_kernel(TapGemmParams p) {   // <= 128 registers: four work-groups per CU (this layer is store-bound: occupancy = bytes in flight)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* a_img = smem;                 // N image: 128 pixels x 64 k'
   char* w_img = smem + 128 * 128;     // T image: 64 k' x 128 n
@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(TapGemmParams p) {
   if (wide) {
     // v_permlane16_swap pairs the n-fragments 2k / 2k+1: afterwards a lane owns 8 consecutive channels of its pixel (see the
     // epilogue of tapgemm_kernel): half the store instructions of this store-bound layer
+    const bool staged = n0 + 128 <= N;                          // whole 128-channel tile (block-uniform)
+    if (staged) __syncthreads();                                // every wave is done with the operand images: smem becomes the output stage
     const int eg = lane >> 4;
     const int nlane = wn * 64 + 16 * (eg & 1) + 4 * (eg & ~1);
 #pragma unroll
@@ -111,8 +113,9 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(TapGemmParams p) {
           v1[ip][r] = xb;
         }
       }
-      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
-      if (m >= M) continue;
+      const int ml = wm * 64 + j * 16 + (lane & 15);
+      const int m = m0 + ml;
+      if (m >= M && !staged) continue;
 #pragma unroll
       for (int ip = 0; ip < 2; ip++) {
         const int n = n0 + nlane + 32 * ip;
@@ -127,7 +130,20 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(TapGemmParams p) {
           for (int r = 0; r < 4; r++) { a[r] = fmaxf(a[r], 0.f); c[r] = fmaxf(c[r], 0.f); }
         }
         const u32x4_t o = {pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(c[0], c[1]), pack2<T>(c[2], c[3])};
-        *reinterpret_cast<u32x4_t*>(y + (size_t)m * p.ldy + n) = o;
+        if (staged) lds_write128(smem, ml * 256 + ((((nlane + 32 * ip) >> 3) ^ (ml & 15)) << 4), o);
+        else *reinterpret_cast<u32x4_t*>(y + (size_t)m * p.ldy + n) = o;
+      }
+    }
+    if (staged) {
+      // the tile leaves through LDS so that 16 consecutive lanes store the 256 contiguous bytes of ONE pixel (a lane's own
+      // fragments are 64-byte runs of 16 different pixels per instruction: half cache lines, measured 1.9 TB/s on this store-bound layer)
+      __syncthreads();
+      const int c16 = tid & 15;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int pr = (tid >> 4) + 16 * k;
+        if (m0 + pr < M)
+          *reinterpret_cast<u32x4_t*>(y + (size_t)(m0 + pr) * p.ldy + n0 + c16 * 8) = lds_read128(smem, pr * 256 + ((c16 ^ (pr & 15)) << 4));
       }
     }
     return;
