@@ -144,8 +144,8 @@ def cpu_baseline(topo_kw, size, batch, steps, warmup, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
@@ -211,18 +211,22 @@ def main():
     for _ in range(args.warmup):
         dp.train_step(x)
     barrier()
-    # HIP events bracket every MFMA launch on every EV-th timed step only: each event pair costs a barrier packet on the
-    # stream (~8 % of the step when recorded on all steps), and the headline `value` should not pay for its own probes
-    EV = 4
-    ev_steps = 0
+    # the timed region carries no probes: HIP events around every MFMA launch cost a barrier packet each (~8 % of a step), so the
+    # per-kernel legs below run on extra steps AFTER it
     t0 = time.perf_counter()
     for i in range(args.steps):
-        timer.enabled = (not args.no_kernel_events) and (i % EV == EV - 1 or args.steps < EV)
-        ev_steps += int(timer.enabled)
         loss = dp.train_step(x)
     barrier()
     dt = time.perf_counter() - t0
-    timer.enabled = False
+    # in-situ leg: the step as timed (two streams), with events: what a launch takes while it shares the chip with the other stream
+    ev_steps = 0
+    if not args.no_kernel_events:
+        timer.enabled = True
+        for _ in range(4):
+            dp.train_step(x)
+            ev_steps += 1
+        barrier()
+        timer.enabled = False
     # roofline leg: the same step with ONE stream, so that every MFMA launch has the chip to itself and its HIP-event duration
     # is the kernel's own (with two streams a launch shares the CUs with whatever the other stream is running)
     iso_steps = 0
