@@ -212,7 +212,9 @@ def test_data_parallel_exchange_streams_single_rank(gpu):
         for wrapped in (False, True):
             eng = make_engine(cfg, 1, gpu)
             eng.set_params(params)
+            eng.chain_priority = True            # the optional third stream of the reverse pass ...
             stepper = DataParallelStep(eng, bucket_elems=100_000, force_exchange=True) if wrapped else eng
+            assert eng.chain_priority == (not wrapped)   # ... which an exchange switches off (4 hardware queues: distributed._one_stream_less)
             for step in range(3):
                 x, t_int, eps = O.synthetic_batch(cfg, seed=step)
                 stepper.train_step(torch.tensor(x, dtype=torch.float32, device=gpu), torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32))
