@@ -89,6 +89,34 @@ __device__ __forceinline__ u32x4_t timg_frag(const char* img, int colbase, int k
   return r;
 }
 
+// sum over the 16 lanes of a row (lane & 15), result in every lane: four DPP adds (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror) - the same operand pairs, hence the same bits, as the butterfly t += __shfl_xor(t, 1 / 2 / 4 / 8), which hipcc lowers to
+// four ds_bpermute round trips through the LDS crossbar
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float t) {
+  t += dpp_f32<0xB1>(t);
+  t += dpp_f32<0x4E>(t);
+  t += dpp_f32<0x141>(t);
+  t += dpp_f32<0x140>(t);
+  return t;
+}
+// sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: v_permlane16_swap / v_permlane32_swap
+// of a value with itself leave (row, partner row) in the two operands - the same pairs as t += __shfl_xor(t, 16); t += __shfl_xor(t, 32)
+// (the second operand goes through an opaque copy: with the SAME value tied to both read-write operands hipcc (ROCm 7.2) emitted a
+// swap whose first operand kept its old upper half - caught by tests/hw_probe/probe_rowsum.hip)
+__device__ __forceinline__ float rows4_sum(float t) {
+  float a = t, b = t;
+  asm volatile("" : "+v"(b));
+  asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  t = a + b;
+  a = t; b = t;
+  asm volatile("" : "+v"(b));
+  asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 __device__ __forceinline__ u32x4_t gload128(const void* p) {
   return *reinterpret_cast<const u32x4_t*>(p);
 }

@@ -277,8 +277,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       float dsc[3];
 #pragma unroll
       for (int o = 0; o < 3; o++) {
-        float t = s3[o];
-        t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);      // the pixel's four lane groups
+        const float t = rows4_sum(s3[o]);                            // the pixel's four lane groups
         const float pr = keras_f16_point<T>(t + bd[o]);
         const float d = o < Cout ? pr - tg[o] : 0.f;
         if (eg == 0 && o < Cout) {
@@ -311,10 +310,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
     float* red = reinterpret_cast<float*>(halo0);          // [8][HEAD_ROW]
     for (int i = tid; i < 8 * HEAD_ROW; i += 512) red[i] = 0.f;
     __syncthreads();
-    auto bfly = [](float t) {
-      t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-      return t;
-    };
+    auto bfly = [](float t) { return row16_sum(t); };
     float* rw = red + wave * HEAD_ROW;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
@@ -405,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         float t = bsum[i][r];
-        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+        t = row16_sum(t);
         const int c = 32 * (i >> 1) + 8 * eg + 4 * (i & 1) + r;   // the channel this accumulator belongs to (w_row)
         if (eq == 0) {
           if (p.dbws) red[wave * 64 + c] = t;

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void dense_head_mfma_kernel(const T* __rest
   for (int i = tid; i < 4 * HEAD_ROW; i += 256) (&red[0][0])[i] = 0.f;
   __syncthreads();
   auto bfly = [](float t) {
-    t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+    t = row16_sum(t);
     return t;
   };
 #pragma unroll

@@ -427,7 +427,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         float t = bsum[i][r];
-        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+        t = row16_sum(t);
         const int eg2 = elane >> 4;
         const int c = wide ? wn * 64 + 32 * (i >> 1) + 16 * (eg2 & 1) + 4 * (eg2 & ~1) + 4 * (i & 1) + r   // bsum[2k + h][r] after the swap
                            : wn * 64 + i * 16 + 4 * eg2 + r;
