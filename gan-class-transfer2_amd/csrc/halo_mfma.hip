@@ -42,8 +42,24 @@ constexpr int HPIECES = 41;                   // 1-KiB pieces (8 pixel rows each
 constexpr int HALO_BYTES = HPIECES * 1024;
 constexpr int WB_BYTES = 4 * 64 * 128;        // 4 phases x 64 n-rows x 128 B
 
+#ifdef GCT2_STAMP
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(k) st[k] = stamp()
+#else
+#define STAMP(k)
+#endif
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
+#ifdef GCT2_STAMP
+  unsigned long long st[6];
+  STAMP(0);
+#endif
   __shared__ __attribute__((aligned(16))) char halo0[HALO_BYTES];
   __shared__ __attribute__((aligned(16))) char halo1[HALO_BYTES];
   __shared__ __attribute__((aligned(16))) char wb0[WB_BYTES];
@@ -186,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   asm volatile("" : "+v"(elane));                              // keeps the output addresses out of the K loop
   const int eq = elane & 15, eg = elane >> 4;
   if constexpr (EPI == EPI_HEAD) {
+    STAMP(1);
     // ---- UpShuffle_0 forward + Dense(3) head + fp32 MSE + both gradients (train.py:188, 198-202, 262-272) ------------------
     // A wave holds ALL N = 64 channels of its 128 pixels (the 4 lane groups g of a pixel column q carry 16 channels each), so the
     // head runs on the accumulators: y = relu(acc + bias) rounded to the storage type (the value the unfused path would have
@@ -220,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       hw[i] = (c < hd.Cin && o < Cout) ? hd.w[c * Cout + o] : 0.f;
     }
     __syncthreads();
+    STAMP(2);
     const float gscale = (hd.loss_scale ? *hd.loss_scale : 1.f) * 2.0f / hd.count;
     float bd[3];
 #pragma unroll
@@ -281,7 +299,9 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
         const float pr = keras_f16_point<T>(t + bd[o]);
         const float d = o < Cout ? pr - tg[o] : 0.f;
         if (eg == 0 && o < Cout) {
+#ifndef GCT2_STAMP
           if (hd.pred) hd.pred[opix * Cout + o] = pr;
+#endif
           lacc = fmaf(d, d, lacc);
         }
         dsc[o] = keras_f16_point<T>(d * gscale);
@@ -306,7 +326,9 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
         *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + 32 * ip + 8 * eg) = o;
       }
     }
+    STAMP(3);
     __syncthreads();                                       // every wave is done with its parked rows
+    STAMP(4);
     float* red = reinterpret_cast<float*>(halo0);          // [8][HEAD_ROW]
     for (int i = tid; i < 8 * HEAD_ROW; i += 512) red[i] = 0.f;
     __syncthreads();
@@ -342,6 +364,13 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       for (int k = 1; k < 8; k++) t += red[k * HEAD_ROW + tid];
       hd.part[(size_t)m_tile * HEAD_ROW + tid] = t;
     }
+#ifdef GCT2_STAMP
+    STAMP(5);
+    if (hd.pred && (tid & 63) == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(hd.pred) + ((size_t)m_tile * 8 + wave) * 8;
+      for (int k = 0; k < 6; k++) o[k] = st[k];
+    }
+#endif
     return;
   }
   f32x4_t bsum[4];

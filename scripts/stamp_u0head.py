@@ -1,3 +1,6 @@
+"""phases of the fused UpShuffle_0 + head launch from in-kernel s_memrealtime stamps (diagnostic build only):
+    make -C gan-class-transfer2_amd/csrc clean all EXTRA=-DGCT2_STAMP && python scripts/stamp_u0head.py && make -C gan-class-transfer2_amd/csrc clean all
+The stamped build writes its stamps where the prediction would go (keep_pred) and no prediction: never ship it."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, numpy as np
