@@ -376,10 +376,29 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   f32x4_t bsum[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) bsum[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // the ReLU-mask words of patch row j + 1 are loaded while row j is processed (as in tapgemm_kernel: one exposed load latency
+  // per tile instead of one per row)
+  auto out_pixel = [&](int j) {
+    const int sh = sh0 + mhalf * 8 + j, sw = sw0 + eq;
+    return ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
+  };
+  u32x4_t mk[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
+  auto load_masks = [&](int j, u32x4_t* dst) {
+    if (EPI == EPI_MASK && actp) {
+      const size_t opix = out_pixel(j);
+#pragma unroll
+      for (int ip = 0; ip < 2; ip++) {
+        const int n = n0 + 32 * ip + 8 * eg;
+        if (n < N) dst[ip] = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
+      }
+    }
+  };
+  load_masks(0, mk);
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    const int sh = sh0 + mhalf * 8 + j, sw = sw0 + eq;
-    const size_t opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
+    u32x4_t mkn[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
+    if (j + 1 < 8) load_masks(j + 1, mkn);
+    const size_t opix = out_pixel(j);
 #pragma unroll
     for (int ip = 0; ip < 2; ip++) {                           // fragments 2 ip, 2 ip + 1: channels n .. n + 7 of this lane
       const int n = n0 + 32 * ip + 8 * eg;
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
         }
       } else {
         if (actp) {
-          const u32x4_t a4 = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
+          const u32x4_t a4 = mk[ip];
 #pragma unroll
           for (int h = 0; h < 2; h++) {
             if (!(unpack_lo<T>(a4[h]) > 0.f)) v0[2 * h] = 0.f;
@@ -419,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       const u32x4_t o = {pack2<T>(v0[0], v0[1]), pack2<T>(v0[2], v0[3]), pack2<T>(v1[0], v1[1]), pack2<T>(v1[2], v1[3])};
       *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + n) = o;
     }
+    mk[0] = mkn[0]; mk[1] = mkn[1];
     __builtin_amdgcn_sched_barrier(0);
   }
   if (EPI == EPI_MASK && (p.db || p.db2)) {

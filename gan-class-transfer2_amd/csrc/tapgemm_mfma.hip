@@ -61,6 +61,20 @@ __device__ __forceinline__ bool db_adds(const TapGemmParams& p, int n) { return 
 //           across the barrier that publishes step t+1 (counted vmcnt + raw s_barrier).
 // WM = 64 : every wave owns a 64 (m) x 64 (n) sub-tile;  WM = 128: 128 (m) x 64 (n), used by the 256 x 256 tile
 //           (8 waves; 96 LDS bytes per MFMA instead of 128, half the L2->LDS bytes per flop of the 128 x 128 tile).
+#ifdef GCT2_STAMP
+// diagnostic build (make EXTRA=-DGCT2_STAMP, scripts/stamp_layer.py): s_memrealtime at the phase boundaries of one wave per work-group;
+// an input-gradient call with db == NULL and db_split == -12345 hands the stamp buffer over in db2
+__device__ __forceinline__ unsigned long long tg_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define TG_STAMP(k) st[k] = tg_stamp()
+#else
+#define TG_STAMP(k)
+#endif
 template <typename T, int FORM, int BM, int BN, int EPI, int NBUF, int WM = 64>
 __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64) ? 4 : (WM == 64 ? 2 : 1)) void tapgemm_kernel(TapGemmParams p) {
   constexpr int NWV = (BM / WM) * (BN / 64);       // waves, each a WM x 64 sub-tile
@@ -83,6 +97,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   __shared__ __attribute__((aligned(16))) char lds1[NBUF >= 2 ? A_BYTES + W_BYTES : 16];
   __shared__ __attribute__((aligned(16))) char lds2[NBUF == 3 ? A_BYTES + W_BYTES : 16];
 
+#ifdef GCT2_STAMP
+  unsigned long long st[5];
+  unsigned long long* stamp_out = (EPI == EPI_MASK && !p.db && p.db_split == -12345) ? reinterpret_cast<unsigned long long*>(p.db2) : nullptr;
+  if (stamp_out) p.db2 = nullptr;
+  TG_STAMP(0);
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WAVES_N, wm = wave / WAVES_N;
@@ -230,6 +250,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   // unrolled steps of a trip are merged into one scheduling region and the register allocator spills (wgrad256p_kernel: 440
   // spilled registers, 10x slower; here: the 256 x 256 and three-buffer variants); behind the guard each step stays its own region.
   const bool live = p.ksplit > 0;
+  TG_STAMP(1);
   if constexpr (NBUF == 1) {
     // one LDS buffer (32 KiB): no overlap inside a work-group; 4 work-groups per CU cover each other instead
     for (int it = it_lo; it < it_hi; it++) {
@@ -283,6 +304,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     }
   }
 
+  TG_STAMP(2);
   // ---- epilogue: lane holds out[m = .. + (lane&15)][n = .. + 4*(lane>>4) + r], r = 0..3 ----
   T* __restrict__ yout = reinterpret_cast<T*>(p.y);
   const T* __restrict__ actp = reinterpret_cast<const T*>(p.act);
@@ -301,8 +323,35 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     // (measured on the halo kernel, which gets the same layout from its weight image: -10..-15 %).
     const int eg = elane >> 4;
     const int nlane = wn * 64 + 16 * (eg & 1) + 4 * (eg & ~1);
+    // the ReLU-mask words of pixel column j + 1 are loaded while column j is processed: one exposed load latency per tile instead
+    // of one per column (in-kernel stamps, scripts/stamp_layer.py: the epilogue of UpShuffle_0's input gradient took 8.2 us of a
+    // 41-us work-group life, most of it four serialized 16-byte-load round trips)
+    auto out_pixel = [&](int j, size_t& opix) -> bool {
+      const int m = m0 + wm * WM + j * 16 + (elane & 15);
+      if (m >= M) return false;
+      if (FORM != FORM_CONVT) opix = (size_t)m;
+      else {
+        const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
+        opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
+      }
+      return true;
+    };
+    u32x4_t mk[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
+    auto load_masks = [&](int j, u32x4_t* dst) {
+      size_t opix;
+      if (EPI == EPI_MASK && actp && out_pixel(j, opix)) {
+#pragma unroll
+        for (int ip = 0; ip < 2; ip++) {
+          const int n = n0 + nlane + 32 * ip;
+          if (n < N) dst[ip] = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
+        }
+      }
+    };
+    load_masks(0, mk);
 #pragma unroll
     for (int j = 0; j < MF; j++) {
+      u32x4_t mkn[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
+      if (j + 1 < MF) load_masks(j + 1, mkn);
       f32x4_t v0[2], v1[2];
 #pragma unroll
       for (int ip = 0; ip < 2; ip++) {
@@ -315,18 +364,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
           v1[ip][r] = xb;
         }
       }
-      const int m = m0 + wm * WM + j * 16 + (elane & 15);
-      if (m >= M) continue;
       size_t opix;
-      if (FORM != FORM_CONVT) opix = (size_t)m;
-      else {
-        const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
-        opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
-      }
+      const bool row_ok = out_pixel(j, opix);
 #pragma unroll
       for (int ip = 0; ip < 2; ip++) {
         const int n = n0 + nlane + 32 * ip;
-        if (n >= N) continue;                                   // N is a multiple of 8
+        if (!row_ok || n >= N) continue;                        // N is a multiple of 8
         f32x4_t a = v0[ip], c = v1[ip];
         if (EPI == EPI_BIAS_ACT) {
           if (p.bias) {
@@ -339,7 +382,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
           }
         } else {
           if (actp) {
-            const u32x4_t a4 = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
+            const u32x4_t a4 = mk[ip];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
               if (!(unpack_lo<T>(a4[h]) > 0.f)) a[2 * h] = 0.f;
@@ -362,6 +405,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
         const u32x4_t o = {pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(c[0], c[1]), pack2<T>(c[2], c[3])};
         *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + n) = o;
       }
+      mk[0] = mkn[0]; mk[1] = mkn[1];
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -415,6 +459,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     __builtin_amdgcn_sched_barrier(0);   // one 16-pixel column of the tile at a time: bounds the epilogue's live registers
   }
   }
+  TG_STAMP(3);
+#ifdef GCT2_STAMP
+  if (stamp_out && lane == 0) {
+    TG_STAMP(4);
+    unsigned long long* o = stamp_out + ((size_t)blockIdx.x * NWV + wave) * 8;
+    for (int k = 0; k < 5; k++) o[k] = st[k];
+  }
+#endif
   if (EPI == EPI_MASK && (p.db || p.db2) && p.ksplit == 1) {
     // column sums over the wave's WM pixels: butterfly over the 16 lanes that share (lane>>4); then the waves of one
     // tile column meet in LDS (free after the K loop's last barrier) and the work-group stores ONE partial row,
@@ -572,7 +624,11 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   float* ws = c.ws;
   p.m_tiles = (M + BM - 1) / BM;
   p.n_tiles = (p.N + BN - 1) / BN;
+#ifdef GCT2_STAMP
+  const bool want_db = EPI == EPI_MASK && (p.db || p.db2) && p.db_split != -12345;
+#else
   const bool want_db = EPI == EPI_MASK && (p.db || p.db2);
+#endif
   // fused bias gradient: partial rows at the tail of the workspace (one per (m-tile, phase), or per finalize work-group)
   const size_t fin_rows = (npix + 7) / 8;
   const size_t dbws_bytes = want_db ? std::max((size_t)p.m_tiles * PH, fin_rows) * p.N * sizeof(float) : 0;
