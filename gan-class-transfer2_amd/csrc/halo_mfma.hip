@@ -267,6 +267,14 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       if (im_ok) im_n = *reinterpret_cast<const u32x2_t*>(x2 + px * hd.ldx2);
     };
     prefetch(0);
+    // this lane's 16 rows of the Dense kernel stay in registers for the whole row loop (they were re-read from LDS twice per row:
+    // 32 of the ~40 LDS instructions of a row; the kernel has the registers since the lane reductions went to DPP)
+    float hwr[16][3];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(hw + 4 * (32 * (c >> 3) + 8 * eg + (c & 7)));
+      hwr[c][0] = w4[0]; hwr[c][1] = w4[1]; hwr[c][2] = w4[2];
+    }
 #pragma unroll 1
     for (int j = 0; j < 8; j++) {
       const size_t opix = row_pix(j);
@@ -283,8 +291,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       float s3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 16; c++) {
-        const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(hw + 4 * (32 * (c >> 3) + 8 * eg + (c & 7)));
-        s3[0] = fmaf(yq[c], w4[0], s3[0]); s3[1] = fmaf(yq[c], w4[1], s3[1]); s3[2] = fmaf(yq[c], w4[2], s3[2]);
+        s3[0] = fmaf(yq[c], hwr[c][0], s3[0]); s3[1] = fmaf(yq[c], hwr[c][1], s3[1]); s3[2] = fmaf(yq[c], hwr[c][2], s3[2]);
       }
       float mult = eg == 0 ? 1.f : 0.f;                    // multiplier of dsc in wx
       if (im_ok) {                                         // image channel N + imc from the packed copy
@@ -313,8 +320,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
           const int c = 8 * ip + k;
-          const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(hw + 4 * (32 * ip + 8 * eg + k));
-          float gch = dsc[0] * w4[0] + dsc[1] * w4[1] + dsc[2] * w4[2];
+          float gch = dsc[0] * hwr[c][0] + dsc[1] * hwr[c][1] + dsc[2] * hwr[c][2];
           if (!(yq[c] > 0.f)) gch = 0.f;
           gv[k] = gch;
           bacc[c] += gch;
