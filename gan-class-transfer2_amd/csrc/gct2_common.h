@@ -183,7 +183,24 @@ struct TapGemmParams {
   float* dbws;                           // partial bias-gradient rows [m_tiles*phases | finalize rows][N] in the workspace, or null (atomics)
   HeadFuse head;                         // EPI_HEAD only
   int ks = 0;                            // FORM_S1 / FORM_S1T: kernel size (odd, <= 5)
+  int ws_shift = -1, hs_shift = -1;      // log2 of Ws / Hs when they are powers of two (filled by the launcher), else -1: the per-lane
+                                         // pixel decode then uses shifts instead of four integer divisions per row
 };
+inline int pow2_shift(int v) { return (v > 0 && !(v & (v - 1))) ? __builtin_ctz((unsigned)v) : -1; }
+// m -> (sw, sh, b) on a [B][Hs][Ws] grid
+__device__ __forceinline__ void decode_pixel(int m, int Hs, int Ws, int hs_shift, int ws_shift, int& sw, int& sh, int& b) {
+  if (ws_shift >= 0 && hs_shift >= 0) {            // wave-uniform
+    sw = m & (Ws - 1);
+    const int t = m >> ws_shift;
+    sh = t & (Hs - 1);
+    b = t >> hs_shift;
+  } else {
+    sw = m % Ws;
+    const int t = m / Ws;
+    sh = t % Hs;
+    b = t / Hs;
+  }
+}
 
 // XCD-aware work-group -> tile map.  The dispatcher deals consecutive work-group ids round-robin over the 8
 // XCDs (private L2 each; observed, speed only - MI355X_MICROARCH.md "Workgroup dispatch"), so ids with equal

@@ -145,7 +145,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     const int m = m0 + 8 * (wave + NWV * i) + (lane >> 3);
     a_off[i] = 0; a_mask[i] = 0;
     if (m < M) {
-      const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
+      int sw, sh, b;
+      decode_pixel(m, Hs, Ws, p.hs_shift, p.ws_shift, sw, sh, b);
       // origin = the tap with the smallest row/column: (2sh-1, 2sw-1) for conv, (sh+ph-1, sw+pw-1) for convT
       const int h0 = (FORM == FORM_CONV) ? 2 * sh - 1 : (S1 ? sh - (p.ks - 1) / 2 : sh + ph - 1);
       const int w0 = (FORM == FORM_CONV) ? 2 * sw - 1 : (S1 ? sw - (p.ks - 1) / 2 : sw + pw - 1);
@@ -156,12 +157,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
           if ((unsigned)(h0 + dh) < (unsigned)Hsrc && (unsigned)(w0 + dw) < (unsigned)Wsrc) a_mask[i] |= 1u << t2;
         }
       } else {
+        // validity of tap (dh, dw) = (row dh inside) & (column dw inside): one TW-bit column mask, OR-ed in per valid row
         constexpr int TW = (FORM == FORM_CONV) ? 4 : 2;
+        unsigned cm = 0;
 #pragma unroll
-        for (int t2 = 0; t2 < NTAPS; t2++) {
-          const int dh = t2 / TW, dw = t2 % TW;
-          if ((unsigned)(h0 + dh) < (unsigned)Hsrc && (unsigned)(w0 + dw) < (unsigned)Wsrc) a_mask[i] |= 1u << t2;
-        }
+        for (int dw = 0; dw < TW; dw++) cm |= ((unsigned)(w0 + dw) < (unsigned)Wsrc ? 1u : 0u) << dw;
+#pragma unroll
+        for (int dh = 0; dh < TW; dh++)
+          if ((unsigned)(h0 + dh) < (unsigned)Hsrc) a_mask[i] |= cm << (dh * TW);
       }
     }
   }
@@ -331,7 +334,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       if (m >= M) return false;
       if (FORM != FORM_CONVT) opix = (size_t)m;
       else {
-        const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
+        int sw, sh, b;
+        decode_pixel(m, Hs, Ws, p.hs_shift, p.ws_shift, sw, sh, b);
         opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
       }
       return true;
@@ -416,7 +420,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     size_t opix;
     if (FORM != FORM_CONVT) opix = (size_t)m;
     else {
-      const int sw = m % Ws, t = m / Ws, sh = t % Hs, b = t / Hs;
+      int sw, sh, b;
+      decode_pixel(m, Hs, Ws, p.hs_shift, p.ws_shift, sw, sh, b);
       opix = ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
     }
 #pragma unroll
@@ -624,6 +629,8 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   float* ws = c.ws;
   p.m_tiles = (M + BM - 1) / BM;
   p.n_tiles = (p.N + BN - 1) / BN;
+  p.ws_shift = pow2_shift(p.Ws);
+  p.hs_shift = pow2_shift(p.Hs);
 #ifdef GCT2_STAMP
   const bool want_db = EPI == EPI_MASK && (p.db || p.db2) && p.db_split != -12345;
 #else
