@@ -25,7 +25,7 @@ struct gct2_ctx {
   int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 24;
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
   int xcd_order = 0;                               // tile -> XCD order: 0 = automatic, 1 = m-tile bands, 2 = weight slices
-  int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile (0 = automatic)
+  int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile: 0 = automatic, v: 2^(v-1)
   int force_direct = 0;
   float* wgrad_scratch(size_t* bytes) const {
     if (wws) { *bytes = wws_bytes; return wws; }

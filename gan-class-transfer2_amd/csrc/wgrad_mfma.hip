@@ -570,6 +570,9 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   // big-tile launch always leaves 256 work-groups x 256 KiB = 64 MiB of slabs (written here, read back by the optimizer), whatever
   // the size of the tensor.  Measured r02 (scripts/bench_wgrad.py, incl. the slab sum): DownShuffle_4 35 -> 18 us (one owner per
   // tile, no slabs), DownShuffle_3 57 -> 48, UpShuffle_2 153-160 -> 145 (two splits: 32 MiB of slabs instead of 64); in the step -5..-25 us (in-process A/B)
+  // (going further down - the small tile with ~512 work-groups for DownShuffle_1/2 and UpShuffle_1, 32 MiB of slabs each - is faster
+  // launch by launch (92 -> 80, 84 -> 80, 145 -> 143 us incl. the slab sum) and SLOWER in the step: +38 us in an in-process A/B, the
+  // small work-groups interleave with the input-gradient chain's instead of alternating with them)
   const bool big_tile = !p.ks && (g_wgrad_variant == 2 || (g_wgrad_variant == 0 && tiles128 < 256 && blocks256 >= 192));
   const int tiles = big_tile ? tiles256 : tiles128;
   const int steps_total = (R + 63) / 64;
@@ -577,7 +580,7 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   // once the tiles alone give every CU a work-group
   int rsplit = big_tile ? (g_wgrad_target + tiles - 1) / tiles : (tiles >= 512 ? 1 : (768 + tiles - 1) / tiles);
   if (!big_tile && tiles >= 256 && tiles < 512) rsplit = steps_total >= 32 ? 2 : 1;    // two work-groups per CU once the reduction is long enough
-  if (!big_tile && c.wgrad_split) rsplit = c.wgrad_split;
+  if (!big_tile && c.wgrad_split) rsplit = 1 << (c.wgrad_split - 1);
   rsplit = max(1, min(rsplit, steps_total / 4));
   const int per = (steps_total + rsplit - 1) / rsplit;
   rsplit = (steps_total + per - 1) / per;            // every split non-empty (each one owns a slab)

@@ -64,7 +64,7 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D dgrad), 0 = automatic, 1 = never, 2 = wherever the shape allows;
  * bits 26-27: tile -> XCD order of the forward / input-gradient GEMMs, 0 = automatic, 1 = bands of output pixels per XCD,
  * 2 = weight slices per XCD (layers whose weight tensor is the bigger operand);
- * bits 28-30: forced pixel split of the 128x128 weight-gradient tile (0 = automatic). */
+ * bits 28-30: forced pixel split of the 128x128 weight-gradient tile, 0 = automatic, v = 1..7: 2^(v-1) splits. */
 int gct2_ctx_set_tuning(gct2_ctx* ctx, int v);
 /* test hook: non-zero routes every convolution of this ctx through the direct (non-MFMA) kernels */
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on);
