@@ -70,3 +70,15 @@ if os.environ.get("GCT2_AB_ENV"):
                 eng.train_step(x)
             res.append(timed(lambda: eng.train_step(x), iters))
         print("A/B env %-20s =1 %8.1f us   =0 %8.1f us" % (name, res[0], res[1]))
+# in-process comparison of ctx tuning words (include/gct2.h gct2_ctx_set_tuning) on the whole step: GCT2_AB_TUNE=0,2,5,...
+if os.environ.get("GCT2_AB_TUNE"):
+    words = [int(v, 0) for v in os.environ["GCT2_AB_TUNE"].split(",")]
+    for rnd in range(3):
+        row = []
+        for wd in words:
+            eng.ctx.set_tuning(wd)
+            for _ in range(3):
+                eng.train_step(x)
+            row.append("%#x: %7.1f" % (wd, timed(lambda: eng.train_step(x), iters)))
+        print("tuning  " + "   ".join(row))
+    eng.ctx.set_tuning(0)
