@@ -82,3 +82,24 @@ if os.environ.get("GCT2_AB_TUNE"):
             row.append("%#x: %7.1f" % (wd, timed(lambda: eng.train_step(x), iters)))
         print("tuning  " + "   ".join(row))
     eng.ctx.set_tuning(0)
+# tuning word for the reverse pass only (the forward keeps the automatic choices): GCT2_AB_BWD_TUNE=1,2,...
+if os.environ.get("GCT2_AB_BWD_TUNE"):
+    words = [0] + [int(v, 0) for v in os.environ["GCT2_AB_BWD_TUNE"].split(",")]
+    orig = eng.backward
+    state = {"w": 0}
+    def wrapped(*a, **k):
+        eng.ctx.set_tuning(state["w"])
+        try:
+            return orig(*a, **k)
+        finally:
+            eng.ctx.set_tuning(0)
+    eng.backward = wrapped
+    for rnd in range(3):
+        row = []
+        for wd in words:
+            state["w"] = wd
+            for _ in range(3):
+                eng.train_step(x)
+            row.append("%#x: %7.1f" % (wd, timed(lambda: eng.train_step(x), iters)))
+        print("reverse-pass tuning  " + "   ".join(row))
+    eng.backward = orig
