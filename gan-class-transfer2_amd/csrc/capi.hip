@@ -262,6 +262,10 @@ int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const 
   if (adam && accumulate) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: the fused optimizer step needs accumulate = 0");
   WgradParams p{dz, lddz, x, ldx, dw, B, H, W, Cout, Cin, 1};
   p.accumulate = accumulate ? 1 : 0;
+#ifdef GCT2_STAMP          // diagnostic build: db carries the stamp buffer instead of receiving the bias gradient
+  p.stamps = reinterpret_cast<unsigned long long*>(db);
+  db = nullptr;
+#endif
   WgradSlabs sl{nullptr, 0, 0};
   if (int e = run_wgrad(C(ctx), dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)

@@ -230,6 +230,9 @@ struct WgradParams {
   float* ws;                      // partial-tile slabs [rsplit][16*Cb][Cs] in the registered workspace, or null (atomics)
   int accumulate;                 // 1: dw += result (caller keeps a running / pre-zeroed gradient); 0: dw = result
   int ks = 0;                     // 0: the 4x4 / stride-2 layers; odd ks: 'same' stride-1 convolution (both tensors on one grid, ks*ks taps)
+#ifdef GCT2_STAMP
+  unsigned long long* stamps = nullptr;   // diagnostic build: phase stamps of one wave per work-group (scripts/stamp_wgrad.py)
+#endif
 };
 // wgrad_mfma(): when `defer` is non-null and the launch left its result as workspace slabs, the slab reduction is NOT launched and
 // the slabs are described here (the caller folds them into the optimizer read); nslab = 0 means dw holds the gradient

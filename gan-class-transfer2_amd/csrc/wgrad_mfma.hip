@@ -338,8 +338,24 @@ __device__ __forceinline__ void dma16_hidden(__amdgpu_buffer_rsrc_t rsrc, char* 
                : "memory", "m0");
 }
 
+#ifdef GCT2_STAMP
+__device__ __forceinline__ unsigned long long wg_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define WG_STAMP(k) st[k] = wg_stamp()
+#else
+#define WG_STAMP(k)
+#endif
 template <typename T>
 __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
+#ifdef GCT2_STAMP
+  unsigned long long st[4];
+  WG_STAMP(0);
+#endif
   constexpr int IMG = 32 * 256;                                   // one T image of a stage: 32 r-rows x 128 columns
   constexpr int NDMA = 4;                                         // DMA instructions per wave per stage (one piece of each image)
   __shared__ __attribute__((aligned(16))) char lds0[4 * IMG];
@@ -448,6 +464,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
     else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
     __builtin_amdgcn_s_barrier();
   };
+  WG_STAMP(1);
   issue(st_lo, lds0);
   if (st_lo + 1 < st_hi) issue(st_lo + 1, lds1);
   if (st_lo + 2 < st_hi) issue(st_lo + 2, lds2);
@@ -464,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
     if (st + 3 >= st_hi) break;
     stage(st + 3, lds3, lds2);
   }
+  WG_STAMP(2);
   float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
   // an opaque copy of the lane id: keeps hipcc from hoisting the 32 tiles' output addresses above the reduction loop (they would
@@ -487,6 +505,13 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
       }
     }
   }
+#ifdef GCT2_STAMP
+  WG_STAMP(3);
+  if (p.stamps && lane == 0) {
+    unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+    for (int q = 0; q < 4; q++) o[q] = st[q];
+  }
+#endif
 }
 
 // dw[e] += sum_s slab[s][e], 4 elements per thread, slabs added in index order
