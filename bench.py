@@ -185,6 +185,8 @@ def main():
     from gan_class_transfer2_amd import _lib, engine as engine_mod
     from gan_class_transfer2_amd.distributed import DataParallelStep, ShardedDataParallelStep
 
+    if _lib.build_flags() != 0:       # (_lib.load() refuses a stamped library already unless the diagnostic override is set)
+        raise SystemExit(f"bench.py refuses a diagnostic build of libgct2.so (gct2_build_flags() = {_lib.build_flags()}): rebuild it")
     dtype = {"bf16": g.BF16, "f16": g.F16, "f32": g.F32}[args.dtype]
     topo = g.Topology(128, 512, 6)                      # reference defaults, train.py:18-21
     eng = g.UNetEngine(topo, dtype, dev, rng_seed=rank, loss_scaling=(args.dtype == "f16"))
@@ -244,8 +246,12 @@ def main():
         # evidence of what RCCL ran (rank 0): ranks it saw, the buckets of one extra step and the HIP-event time of every collective
         buckets = dp.buckets if sharded else dp.reducer.buckets
         esz = 4
+        # streams this process drives: the caller's, the weight-gradient side stream, the communication stream (+ the chain's
+        # own when chain_priority is on) - RCCL adds its internal one; more than GPU_MAX_HW_QUEUES = 4 share hardware queues
+        streams = 2 + (1 if eng.chain_priority else 0) + 1
         comm = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "mode": args.dp_mode, "buckets": len(buckets),
-                "bytes_per_bucket": [int((hi - lo) * esz) for lo, hi in buckets]}
+                "bytes_per_bucket": [int((hi - lo) * esz) for lo, hi in buckets], "process_streams": streams,
+                "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))}
         if sharded:
             dp.time_collectives, dp.events = True, []
             dp.train_step(x)
@@ -270,6 +276,7 @@ def main():
                                    f"pixel_size 128, max_size 512, {args.dtype} operands / fp32 accumulate, Keras Adam + WarmUp",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "loss": loss_val,
+            "library": {"abi": int(_lib.load().gct2_abi_version()), "build_flags": int(_lib.build_flags())},
             "comm": comm,
             "flops_per_image": f_img,
             "step_roofline_frac": round(imgs / world * f_img / MFMA_PEAK, 5),

@@ -10,6 +10,10 @@ import os
 
 F32, BF16, F16 = 0, 1, 2
 DTYPE_NAMES = {F32: "f32", BF16: "bf16", F16: "f16"}
+ABI_VERSION = 12
+# gct2_diffusion_update modes (include/gct2.h; the sampler's objective switches, train.py:29-32)
+SAMPLE_X, SAMPLE_EPS, SAMPLE_SCALED_EPS, SAMPLE_ODE = 0, 1, 2, 3
+BUILD_STAMP = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgct2.so")
@@ -37,6 +41,7 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 # name -> argtypes, exactly the prototypes of include/gct2.h
 SIGNATURES = {
     "gct2_abi_version": [],
+    "gct2_build_flags": [],
     "gct2_device_check": [],
     "gct2_ctx_create": [C.POINTER(C.c_void_p)],
     "gct2_ctx_destroy": [_vp],
@@ -44,8 +49,9 @@ SIGNATURES = {
     "gct2_ctx_set_wgrad_workspace": [_vp, _vp, _sz],
     "gct2_ctx_set_tuning": [_vp, _i],
     "gct2_ctx_force_direct": [_vp, _i],
+    "gct2_ctx_set_stamp_buffer": [_vp, _vp, _sz],
     "gct2_diffusion_mix": [_i, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _sz, _i, _vp],
-    "gct2_diffusion_update": [_vp, _vp, _f, _vp, _vp, _sz, _vp],
+    "gct2_diffusion_update": [_i, _vp, _vp, _f, _f, _vp, _vp, _sz, _vp],
     "gct2_noise_edits": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "gct2_image_prepare": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "gct2_conv4s2_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -97,8 +103,20 @@ def load() -> C.CDLL:
         fn.restype = _i
     lib.gct2_last_error.argtypes = []
     lib.gct2_last_error.restype = C.c_char_p
+    if lib.gct2_abi_version() != ABI_VERSION:
+        raise Gct2Error(f"{LIB_PATH} has ABI version {lib.gct2_abi_version()}, this binding is written for {ABI_VERSION}: rebuild it "
+                        "(`make -C gan-class-transfer2_amd/csrc`)")
+    flags = lib.gct2_build_flags()
+    if flags != 0 and os.environ.get("GCT2_ALLOW_DIAGNOSTIC_BUILD") != "1":
+        raise Gct2Error(f"{LIB_PATH} is a DIAGNOSTIC build (gct2_build_flags() = {flags}: in-kernel stamps): results and timings of "
+                        "such a library are never product numbers.  Rebuild with `make -C gan-class-transfer2_amd/csrc clean all`, or "
+                        "set GCT2_ALLOW_DIAGNOSTIC_BUILD=1 for the scripts/stamp_*.py diagnostics")
     _lib = lib
     return lib
+
+
+def build_flags() -> int:
+    return int(load().gct2_build_flags())
 
 
 def check(rc: int, what: str = "") -> None:
@@ -120,22 +138,36 @@ class Context:
         h = C.c_void_p()
         call("gct2_ctx_create", C.byref(h))
         self.handle = h.value
-        self._keep = [None, None]
+        self._keep = [None, None, None]
+        # bumped by every setter: whoever caches something that bakes in this context's pointers or tile choices (the sampler's
+        # HIP graphs of the forward pass) keys its cache on it
+        self.version = 0
+
+    def set_stamp_buffer(self, tensor) -> None:
+        """diagnostic builds only (gct2_build_flags() & BUILD_STAMP): where the next stamped launch writes its phase stamps."""
+        self._keep[2] = tensor
+        self.version += 1
+        call("gct2_ctx_set_stamp_buffer", self.handle, tensor.data_ptr() if tensor is not None else None,
+             tensor.numel() * tensor.element_size() if tensor is not None else 0)
 
     def set_workspace(self, tensor) -> None:
         self._keep[0] = tensor
+        self.version += 1
         call("gct2_ctx_set_workspace", self.handle, tensor.data_ptr() if tensor is not None else None,
              tensor.numel() * tensor.element_size() if tensor is not None else 0)
 
     def set_wgrad_workspace(self, tensor) -> None:
         self._keep[1] = tensor
+        self.version += 1
         call("gct2_ctx_set_wgrad_workspace", self.handle, tensor.data_ptr() if tensor is not None else None,
              tensor.numel() * tensor.element_size() if tensor is not None else 0)
 
     def set_tuning(self, v: int) -> None:
+        self.version += 1
         call("gct2_ctx_set_tuning", self.handle, int(v))
 
     def force_direct(self, on: bool) -> None:
+        self.version += 1
         call("gct2_ctx_force_direct", self.handle, int(bool(on)))
 
     def __del__(self):

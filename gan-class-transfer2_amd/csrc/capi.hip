@@ -35,7 +35,7 @@ int conv_s1_direct(int dtype, bool dgrad, const void* x, int ldx, const void* w,
 int conv_s1_wgrad_direct(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, int B, int H, int W, int Cin, int Cout, int KS,
                          int accumulate, hipStream_t s);
 int pw_diffusion_mix(int, const float*, const float*, float, float*, void*, int, void*, int, size_t, int, hipStream_t);
-int pw_diffusion_update(const float*, const float*, float, float*, float*, size_t, hipStream_t);
+int pw_diffusion_update(int, const float*, const float*, float, float, float*, float*, size_t, hipStream_t);
 int pw_noise_edits(const float*, const float*, int, float*, int, int, int, hipStream_t);
 int pw_image_prepare(const uint8_t*, const int64_t*, const int32_t*, float*, int, int, hipStream_t);
 int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const gct2_loss_scale_state*, int, hipStream_t,
@@ -85,9 +85,7 @@ int run_tapgemm(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmPa
 // column sums of the output view after the launch, minus those before it when the launch accumulates.
 int run_dgrad(const gct2_ctx& c, int dtype, int form, TapGemmParams p, size_t out_pixels, float* db, int split, float* db2, int db_acc,
               void* stream) {
-#ifndef GCT2_STAMP          // (the diagnostic build takes db_split = -12345 as "db2 is the stamp buffer": tapgemm_mfma.hip)
   if (split < 0 || split > p.N) return gct2_fail(GCT2_EINVAL, "dgrad: db_split out of range");
-#endif
   p.db = db; p.db_split = split; p.db2 = db2; p.db_acc = db_acc;
   if (!c.force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(c, dtype, form, EPI_MASK, p, S(stream));
   zero_overwritten_db(p, S(stream));        // the column-sum kernels below add with atomics
@@ -126,7 +124,14 @@ int adam_after_wgrad(const gct2_adam_args* a, float* dw, size_t nw, const WgradS
 
 extern "C" {
 
-int gct2_abi_version(void) { return 11; }
+int gct2_abi_version(void) { return 12; }
+int gct2_build_flags(void) {
+#ifdef GCT2_STAMP
+  return GCT2_BUILD_STAMP;
+#else
+  return 0;
+#endif
+}
 const char* gct2_last_error(void) { return g_err; }
 
 int gct2_ctx_create(gct2_ctx** ctx) {
@@ -164,6 +169,18 @@ int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   ctx->xcd_order = (v >> 26) & 3;
   ctx->wgrad_split = (v >> 28) & 7;
   return GCT2_OK;
+}
+int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_stamp_buffer: null ctx");
+#ifdef GCT2_STAMP
+  if (stamps && ((uintptr_t)stamps % 8)) return gct2_fail(GCT2_EINVAL, "ctx_set_stamp_buffer: pointer must be 8-byte aligned");
+  ctx->stamps = reinterpret_cast<unsigned long long*>(stamps);
+  ctx->stamps_bytes = stamps ? bytes : 0;
+  return GCT2_OK;
+#else
+  (void)stamps; (void)bytes;
+  return gct2_fail(GCT2_EINVAL, "ctx_set_stamp_buffer: this is the product build (rebuild with make EXTRA=-DGCT2_STAMP for in-kernel stamps)");
+#endif
 }
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on) {
   if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_force_direct: null ctx");
@@ -262,10 +279,6 @@ int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const 
   if (adam && accumulate) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: the fused optimizer step needs accumulate = 0");
   WgradParams p{dz, lddz, x, ldx, dw, B, H, W, Cout, Cin, 1};
   p.accumulate = accumulate ? 1 : 0;
-#ifdef GCT2_STAMP          // diagnostic build: db carries the stamp buffer instead of receiving the bias gradient
-  p.stamps = reinterpret_cast<unsigned long long*>(db);
-  db = nullptr;
-#endif
   WgradSlabs sl{nullptr, 0, 0};
   if (int e = run_wgrad(C(ctx), dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)
@@ -399,10 +412,19 @@ int gct2_diffusion_mix(int dtype, const float* x_theta, const float* eps_theta, 
   return pw_diffusion_mix(dtype, x_theta, eps_theta, alpha, fake, out, ldout, out2, ldout2, npix, C, S(stream));
 }
 
-int gct2_diffusion_update(const float* pred, const float* fake, float alpha, float* x_theta, float* eps_theta, size_t n, void* stream) {
-  if (!pred || !fake || !x_theta || !eps_theta || n == 0) return gct2_fail(GCT2_EINVAL, "diffusion_update: null pointer or n == 0");
+int gct2_diffusion_update(int mode, const float* pred, const float* fake, float alpha, float alpha_prev, float* x_theta, float* eps_theta,
+                          size_t n, void* stream) {
+  if (mode < GCT2_SAMPLE_X || mode > GCT2_SAMPLE_ODE) return gct2_fail(GCT2_EINVAL, "diffusion_update: unknown mode %d", mode);
+  if (!pred || !fake || !x_theta || (!eps_theta && mode != GCT2_SAMPLE_ODE) || n == 0)
+    return gct2_fail(GCT2_EINVAL, "diffusion_update: null pointer or n == 0");
   if (!(alpha >= 0.f && alpha < 1.f)) return gct2_fail(GCT2_EINVAL, "diffusion_update: alpha must be in [0, 1)");
-  return pw_diffusion_update(pred, fake, alpha, x_theta, eps_theta, n, S(stream));
+  if (mode != GCT2_SAMPLE_X && !(alpha > 0.f)) return gct2_fail(GCT2_EINVAL, "diffusion_update: this mode divides by sqrt(alpha): alpha must be > 0");
+  if (mode == GCT2_SAMPLE_ODE) {
+    if (!(alpha_prev >= 0.f && alpha_prev <= 1.f)) return gct2_fail(GCT2_EINVAL, "diffusion_update: alpha_prev must be in [0, 1]");
+    if (sqrtf(alpha_prev) * sqrtf(1.f - alpha) - sqrtf(alpha) * sqrtf(1.f - alpha_prev) == 0.f)
+      return gct2_fail(GCT2_EINVAL, "diffusion_update: alpha == alpha_prev makes the ODE step singular (train.py:386-391)");
+  }
+  return pw_diffusion_update(mode, pred, fake, alpha, alpha_prev, x_theta, eps_theta, n, S(stream));
 }
 
 int gct2_noise_edits(const float* eps, const float* dictionary, int K, float* out, int H, int W, int C, void* stream) {

@@ -27,6 +27,7 @@ struct gct2_ctx {
   int xcd_order = 0;                               // tile -> XCD order: 0 = automatic, 1 = m-tile bands, 2 = weight slices
   int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile: 0 = automatic, v: 2^(v-1)
   int force_direct = 0;
+  unsigned long long* stamps = nullptr; size_t stamps_bytes = 0;   // diagnostic builds only (gct2_ctx_set_stamp_buffer)
   float* wgrad_scratch(size_t* bytes) const {
     if (wws) { *bytes = wws_bytes; return wws; }
     *bytes = ws_bytes; return ws;
@@ -185,6 +186,9 @@ struct TapGemmParams {
   int ks = 0;                            // FORM_S1 / FORM_S1T: kernel size (odd, <= 5)
   int ws_shift = -1, hs_shift = -1;      // log2 of Ws / Hs when they are powers of two (filled by the launcher), else -1: the per-lane
                                          // pixel decode then uses shifts instead of four integer divisions per row
+#ifdef GCT2_STAMP
+  unsigned long long* stamps = nullptr;  // diagnostic build: phase stamps of one wave per work-group (gct2_ctx_set_stamp_buffer)
+#endif
 };
 inline int pow2_shift(int v) { return (v > 0 && !(v & (v - 1))) ? __builtin_ctz((unsigned)v) : -1; }
 // m -> (sw, sh, b) on a [B][Hs][Ws] grid
@@ -231,7 +235,7 @@ struct WgradParams {
   int accumulate;                 // 1: dw += result (caller keeps a running / pre-zeroed gradient); 0: dw = result
   int ks = 0;                     // 0: the 4x4 / stride-2 layers; odd ks: 'same' stride-1 convolution (both tensors on one grid, ks*ks taps)
 #ifdef GCT2_STAMP
-  unsigned long long* stamps = nullptr;   // diagnostic build: phase stamps of one wave per work-group (scripts/stamp_wgrad.py)
+  unsigned long long* stamps = nullptr;   // diagnostic build: phase stamps of one wave per work-group (gct2_ctx_set_stamp_buffer)
 #endif
 };
 // wgrad_mfma(): when `defer` is non-null and the launch left its result as workspace slabs, the slab reduction is NOT launched and

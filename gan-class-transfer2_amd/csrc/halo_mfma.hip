@@ -306,9 +306,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
         const float pr = keras_f16_point<T>(t + bd[o]);
         const float d = o < Cout ? pr - tg[o] : 0.f;
         if (eg == 0 && o < Cout) {
-#ifndef GCT2_STAMP
           if (hd.pred) hd.pred[opix * Cout + o] = pr;
-#endif
           lacc = fmaf(d, d, lacc);
         }
         dsc[o] = keras_f16_point<T>(d * gscale);
@@ -372,8 +370,8 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
     }
 #ifdef GCT2_STAMP
     STAMP(5);
-    if (hd.pred && (tid & 63) == 0) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(hd.pred) + ((size_t)m_tile * 8 + wave) * 8;
+    if (p.stamps && (tid & 63) == 0) {
+      unsigned long long* o = p.stamps + ((size_t)m_tile * 8 + wave) * 8;
       for (int k = 0; k < 6; k++) o[k] = st[k];
     }
 #endif
@@ -517,6 +515,9 @@ int halo_head(const gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* d
   p.ksplit = 1;
   p.dbws = nullptr;
   p.head.part = c.ws;
+#ifdef GCT2_STAMP
+  p.stamps = c.stamps;
+#endif
   dim3 grid(8 * p.xcd_chunk);
   if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_HEAD>), grid, dim3(512), 0, s, p);
   else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_HEAD>), grid, dim3(512), 0, s, p);

@@ -651,14 +651,28 @@ __global__ void diffusion_mix_kernel(const float* __restrict__ x, const float* _
     if (out2) out2[pix * ldout2 + c] = from_f32<T>(f);
   }
 }
-// predict_x branch (train.py:394-398, 463-467): x_theta = prediction; eps_theta = (fake - sqrt(a) x_theta) / sqrt(1-a)
-__global__ void diffusion_update_kernel(const float* __restrict__ pred, const float* __restrict__ fake, float sa, float sb,
+// one sampler update from the prediction, by objective (train.py:338-355, 382-413, 452-479; modes of include/gct2.h):
+//   X: x = pred, e = (fake - sa x) / sb;  EPS: e = pred, x = (fake - pred sb) / sa;  SCALED_EPS: e = pred / sb, x = (fake - pred) / sa;
+//   ODE: x = (pred sb - fake sb1) / (sa1 sb - sa sb1), e untouched.  sa = sqrt(a_t), sb = sqrt(1 - a_t), sa1 / sb1 the same at t - 1.
+template <int MODE>
+__global__ void diffusion_update_kernel(const float* __restrict__ pred, const float* __restrict__ fake, float sa, float sb, float sa1, float sb1,
                                         float* __restrict__ x, float* __restrict__ e, size_t n) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float den = sa1 * sb - sa * sb1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float p = pred[i];
-    x[i] = p;
-    e[i] = (fake[i] - sa * p) / sb;
+    const float p = pred[i], f = fake[i];
+    if (MODE == GCT2_SAMPLE_X) {
+      x[i] = p;
+      e[i] = (f - sa * p) / sb;
+    } else if (MODE == GCT2_SAMPLE_EPS) {
+      e[i] = p;
+      x[i] = (f - p * sb) / sa;
+    } else if (MODE == GCT2_SAMPLE_SCALED_EPS) {
+      e[i] = p / sb;
+      x[i] = (f - p) / sa;
+    } else {
+      x[i] = (p * sb - f * sb1) / den;
+    }
   }
 }
 // the four noise variants of train.py:416-431 from one eps image [H,W,C]: out[0] = eps, out[1] = nearest-upsample x4 of the
@@ -1051,8 +1065,14 @@ int pw_diffusion_mix(int dtype, const float* x, const float* e, float a, float* 
   if (dtype == GCT2_BF16) return diffusion_mix_t<__bf16>(x, e, a, fake, out, ldout, out2, ldout2, npix, C, s);
   return diffusion_mix_t<_Float16>(x, e, a, fake, out, ldout, out2, ldout2, npix, C, s);
 }
-int pw_diffusion_update(const float* pred, const float* fake, float a, float* x, float* e, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(diffusion_update_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, pred, fake, sqrtf(a), sqrtf(1.f - a), x, e, n);
+int pw_diffusion_update(int mode, const float* pred, const float* fake, float a, float a1, float* x, float* e, size_t n, hipStream_t s) {
+  const dim3 grid(blocks_for(n, 256)), block(256);
+  const float sa = sqrtf(a), sb = sqrtf(1.f - a), sa1 = sqrtf(a1), sb1 = sqrtf(1.f - a1);
+  if (mode == GCT2_SAMPLE_X) hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_X>, grid, block, 0, s, pred, fake, sa, sb, sa1, sb1, x, e, n);
+  else if (mode == GCT2_SAMPLE_EPS) hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_EPS>, grid, block, 0, s, pred, fake, sa, sb, sa1, sb1, x, e, n);
+  else if (mode == GCT2_SAMPLE_SCALED_EPS)
+    hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_SCALED_EPS>, grid, block, 0, s, pred, fake, sa, sb, sa1, sb1, x, e, n);
+  else hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_ODE>, grid, block, 0, s, pred, fake, sa, sb, sa1, sb1, x, e, n);
   return gct2_check_launch("diffusion_update");
 }
 int pw_noise_edits(const float* eps, const float* dict, int K, float* out, int H, int W, int C, hipStream_t s) {

@@ -611,6 +611,9 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   rsplit = (steps_total + per - 1) / per;            // every split non-empty (each one owns a slab)
   p.rsplit = rsplit;
   p.ws = nullptr;
+#ifdef GCT2_STAMP
+  p.stamps = c.stamps;
+#endif
   const size_t n = (size_t)taps * p.Cb * p.Cs;
   size_t ws_bytes = 0;
   float* ws = c.wgrad_scratch(&ws_bytes);

@@ -172,7 +172,7 @@ class ShardedDataParallelStep:
     arenas on every rank: checkpoints, tests).  With loss scaling every rank checks its shards and the found_inf flags are
     combined with one 4-byte MAX all-reduce."""
 
-    def __init__(self, engine, bucket_elems: int = 4 << 20, group=None, force_exchange: bool = False):
+    def __init__(self, engine, bucket_elems: int = 4 << 20, group=None, force_exchange: bool = False, tail_layers: int = 2):
         self.engine, self.group = engine, group
         A = engine.arena
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -182,8 +182,19 @@ class ShardedDataParallelStep:
         if A.total % unit:
             raise ValueError(f"arena of {A.total} elements is not a multiple of world x 64 = {unit}")
         bsz = max(unit, (bucket_elems + unit - 1) // unit * unit)
-        self.buckets: List[Tuple[int, int]] = [(lo, min(lo + bsz, A.total)) for lo in range(0, A.total, bsz)]
         order = engine.topo.layer_order()
+        # The LAST bucket closes only when the last layer of the reverse pass (DownShuffle_0) is ready, so its reduce-scatter, Adam
+        # and all-gather are always exposed: keep it small.  It starts at the first of the `tail_layers` last layers
+        # (DownShuffle_1 and _0 of the reference topology: 0.53 M of the 41.7 M parameters), rounded down to a
+        # shard unit; every bucket before it is a fixed-size piece that closes with an earlier layer.
+        tail = A.total
+        if 0 < tail_layers < len(order):
+            tail = A.layer_ranges[order[-tail_layers]][0] // unit * unit
+        if tail <= 0 or tail >= A.total:
+            tail = A.total
+        self.buckets: List[Tuple[int, int]] = [(lo, min(lo + bsz, tail)) for lo in range(0, tail, bsz)]
+        if tail < A.total:
+            self.buckets.append((tail, A.total))
         self.layer_index = {name: i for i, name in enumerate(order)}
         ends = [A.layer_ranges[name][1] for name in order]
         # last_layer[k]: index of the layer that holds the last element of bucket k (the bucket is complete when it is ready)
@@ -194,6 +205,23 @@ class ShardedDataParallelStep:
         _one_stream_less(engine, self.exchange)
         self.events: List[Tuple[int, object, object]] = []      # (bucket, start, end) of the collectives when timing is on
         self.time_collectives = False
+        # Parameters the kernels read in FP32 straight from the master arena (every bias, the Dense(3) kernel and bias:
+        # engine.forward / backward pass A.pptr(...), include/gct2.h declares `const float* bias`).  In the 16-bit modes the
+        # all-gather above only carries the compute-dtype shadow, so a rank never saw the updates of such parameters outside its
+        # own shards and kept computing with their initial values (r02).  They are few (a few thousand floats):
+        # after the last bucket's update every rank contributes the ones it owns to ONE small all-reduce (everybody else adds
+        # zeros, so the sum is the owner's value bit for bit) and writes the result back into its master arena.
+        self._small_idx = self._small_own = None
+        if A.shadow is not None:
+            names = [n for n in A.shapes if n.endswith(".b") or n.startswith("dense.")]
+            idx = torch.cat([torch.arange(A.offsets[n], A.offsets[n] + A.numel(n)) for n in names])
+            own = torch.zeros(A.total, dtype=torch.bool)
+            for k in range(len(self.buckets)):
+                slo, shi = self.shard(k)
+                own[slo:shi] = True
+            self._small_idx = idx.to(A.p.device)
+            self._small_own = own[idx].to(A.p.device)
+        engine._masters_sharded = False     # True after a sharded step, until gather_master(): UNetEngine.state_dict refuses
         self._begin()
 
     # ---- helpers ----------------------------------------------------------------------------------------------------------
@@ -288,13 +316,27 @@ class ShardedDataParallelStep:
         while self.next_opt < len(self.buckets):
             self._optimize_and_gather(self.next_opt)
             self.next_opt += 1
+        self._exchange_fp32_read_parameters()
         if self.on_cuda:
             torch.cuda.current_stream(eng.device).wait_stream(self.comm_stream)
+        eng._masters_sharded = True
         eng.finish_step()
         return loss
 
+    def _exchange_fp32_read_parameters(self) -> None:
+        """biases + Dense(3): owner's fp32 values to every rank (see __init__); on the communication stream behind the updates."""
+        if self._small_idx is None:
+            return
+        A = self.engine.arena
+        with self._on_comm():
+            buf = A.p.index_select(0, self._small_idx)
+            buf = torch.where(self._small_own, buf, torch.zeros_like(buf))
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            A.p.index_copy_(0, self._small_idx, buf)
+
     def gather_master(self) -> None:
-        """assemble the full fp32 parameter and Adam-slot arenas on every rank from the per-rank shards."""
+        """assemble the full fp32 parameter and Adam-slot arenas on every rank from the per-rank shards (a collective: every rank
+        calls it)."""
         if not self.exchange:
             return
         A = self.engine.arena
@@ -302,6 +344,21 @@ class ShardedDataParallelStep:
             for k, (lo, hi) in enumerate(self.buckets):
                 slo, shi = self.shard(k)
                 dist.all_gather_into_tensor(t[lo:hi], t[slo:shi].clone(), group=self.group)
+        self.engine._masters_sharded = False
+
+    def state_dict(self):
+        """UNetEngine.state_dict of the WHOLE model: the sharded masters and Adam slots are gathered first (a collective: every
+        rank calls it; each gets the same dictionary).  The engine's own state_dict refuses while the masters are sharded - a
+        checkpoint written from one rank's arenas would resume from stale parameters and zero Adam slots outside its shards."""
+        self.gather_master()
+        return self.engine.state_dict()
+
+    def save_checkpoint(self, path: str) -> None:
+        """every rank calls it (gather), rank 0 writes."""
+        sd = self.state_dict()
+        if self.rank == 0:
+            from safetensors.torch import save_file
+            save_file(sd, path)
 
     def collective_times_ms(self) -> List[Tuple[int, float]]:
         return [(k, s.elapsed_time(e)) for k, s, e in self.events]

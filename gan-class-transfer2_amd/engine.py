@@ -679,6 +679,10 @@ class UNetEngine:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """everything a run needs to continue bit-identically: fp32 parameters and Adam slots (one arena each, layout =
         ParamArena.offsets), optimizer iterations, RNG stream positions, loss-scale state.  CPU tensors, safetensors-ready."""
+        if getattr(self, "_masters_sharded", False):
+            raise _lib.Gct2Error("the fp32 parameters and Adam slots of this engine are sharded over the data-parallel ranks "
+                                 "(ShardedDataParallelStep): use its state_dict() / save_checkpoint() (they gather first), or call "
+                                 "gather_master() on every rank")
         torch.cuda.synchronize(self.device)
         A = self.arena
         sd = {"arena.p": A.p.cpu(), "arena.m": A.m.cpu(), "arena.v": A.v.cpu(),

@@ -57,6 +57,13 @@ def configure(**kw) -> None:
         setattr(mod, k, v)
 
 
+def objective_switches() -> Dict[str, bool]:
+    """the four objective globals of train.py:29-32 as they stand NOW (Trainer.call and log_sample read them at call time)."""
+    return dict(predict_x=bool(predict_x), predict_scaled_epsilon=bool(predict_scaled_epsilon),
+                prediction_weighting=bool(prediction_weighting),
+                ordinary_differential_equation=bool(ordinary_differential_equation))
+
+
 def preferred_dtype_code() -> int:
     """train.py:38: preferred_type = float16 if mixed_precision else float32 (+ the bf16 knob)."""
     if compute_dtype is not None:
@@ -379,16 +386,20 @@ class Denoiser(Layer):
         return block_depth != 0 or residual or not concat
 
     def ensure_engine(self, **engine_kw):
+        """build the engine on first use.  Whoever comes first - `denoiser(...)`, `trainable_variables`, the sampler callback at
+        on_epoch_begin, or `trainer(...)` - the engine gets the objective switches of train.py:29-32 from the module-level
+        globals (train.py reads them as module constants at call time; r02 took them from Trainer's constructor only, so an
+        engine built by anything else silently trained the default objective)."""
         if self.engine is None and self.variant():
             from .variants import VariantEngine
-            kw = dict(steps=steps, warm_up=warm_up, seed=self._seed, loss_scaling=bool(mixed_precision))
+            kw = dict(steps=steps, warm_up=warm_up, seed=self._seed, loss_scaling=bool(mixed_precision), **objective_switches())
             kw.update(engine_kw)
             self.engine = VariantEngine(pixel_size, max_size, octaves, block_depth, residual, concat, self.dtype_code, self._device, **kw)
             self._bind_variant_parameters()
         if self.engine is None:
             # no optimizer known yet (train.py:505-509 calls the model before compile): the module-level mixed_precision
             # decides about loss scaling, as it decides about the LossScaleOptimizer wrapper in train.py:82-83
-            kw = dict(steps=steps, warm_up=warm_up, seed=self._seed, loss_scaling=bool(mixed_precision))
+            kw = dict(steps=steps, warm_up=warm_up, seed=self._seed, loss_scaling=bool(mixed_precision), **objective_switches())
             kw.update(engine_kw)
             self.engine = UNetEngine(self.topology, self.dtype_code, self._device, **kw)
             A = self.engine.arena
@@ -470,15 +481,10 @@ class Trainer(Layer):
         self.denoiser = denoiser
         self.optimizer = None
         self.loss_fn = None
-        # the objective switches of train.py:29-32 are read when the engine is built (train.py reads them at call time, but
-        # they are module constants there as well)
-        self._objective = dict(predict_x=predict_x, predict_scaled_epsilon=predict_scaled_epsilon,
-                               prediction_weighting=prediction_weighting,
-                               ordinary_differential_equation=ordinary_differential_equation)
 
     def _engine(self) -> UNetEngine:
         opt = self.optimizer
-        kw = dict(self._objective)
+        kw = {}
         if opt is not None and self.denoiser.engine is None:
             inner = getattr(opt, "inner", opt)
             kw.update(beta_1=inner.beta_1, beta_2=inner.beta_2, epsilon=inner.epsilon,
@@ -491,6 +497,10 @@ class Trainer(Layer):
             else:
                 raise NotImplementedError("only WarmUp or constant learning rates are supported")
         eng = self.denoiser.ensure_engine(**kw)
+        # train.py:238-252 reads the objective globals every time Trainer.call runs: an engine built earlier (by denoiser(...),
+        # trainable_variables, the log_sample callback) follows the switches as they stand now
+        for k, v in objective_switches().items():
+            setattr(eng, k, v)
         return eng
 
     def call(self, x):

@@ -37,7 +37,11 @@ enum {
 };
 
 /* library / device identification ------------------------------------------------------------ */
-int gct2_abi_version(void);                 /* bumps when a signature below changes */
+int gct2_abi_version(void);                 /* bumps when a signature below changes (v12: diffusion_update modes, build flags) */
+/* how the library was built: 0 for the product build; bit 0 (GCT2_BUILD_STAMP) = diagnostic build with in-kernel phase stamps
+ * (make EXTRA=-DGCT2_STAMP).  Product hosts (the Python binding, bench.py, the tests) refuse a library whose flags are not 0. */
+enum { GCT2_BUILD_STAMP = 1 };
+int gct2_build_flags(void);
 const char* gct2_last_error(void);          /* host string describing the last non-OK return */
 int gct2_device_check(void);                /* GCT2_OK iff the current device is gfx950 */
 /* ---- call context: caller-owned scratch + tuning, re-entrant across streams -------------------------------------------
@@ -68,6 +72,9 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
 int gct2_ctx_set_tuning(gct2_ctx* ctx, int v);
 /* test hook: non-zero routes every convolution of this ctx through the direct (non-MFMA) kernels */
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on);
+/* diagnostic builds only (gct2_build_flags() & GCT2_BUILD_STAMP): device buffer that receives the s_memrealtime phase stamps of
+ * one wave per work-group of the next stamped launch of this ctx (layout: scripts/stamp_*.py).  GCT2_EINVAL in a product build. */
+int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes);
 
 /* ---- DownShuffle = Conv2D(f, 4, 2, 'same', relu)   train.py:158-169 ------------------------- */
 /* y[b,oh,ow,o] = act(bias[o] + sum_{kh,kw,i} x[b,2oh+kh-1,2ow+kw-1,i] * w[kh,kw,i,o])
@@ -228,15 +235,23 @@ int gct2_noise_image_rng(int dtype, const float* x, const int32_t* t_int, uint64
                          uint64_t offset, float* eps_out, void* out, int ldout, void* out2, int ldout2, int B, int HW,
                          int C, int steps, void* stream);
 
-/* ---- log_sample, the reference's sampler (train.py:323-496, predict_x branch): pointwise steps, fp32 state ---- */
+/* ---- log_sample, the reference's sampler (train.py:323-496, every objective switch of train.py:29-32): pointwise steps, fp32 state ---- */
 /* fake = sqrt(alpha) x_theta + sqrt(1-alpha) eps_theta  (train.py:372-375, 441-444), alpha = alpha_dash(t) from the caller.
  * x_theta, eps_theta, fake: fp32 [npix*C]; the network input is also stored in `dtype` into the view out [npix, C] (ldout) and,
  * if non-NULL, out2 (ldout2) - the packed image and the image slice of the concat buffer. */
 int gct2_diffusion_mix(int dtype, const float* x_theta, const float* eps_theta, float alpha, float* fake,
                        void* out, int ldout, void* out2, int ldout2, size_t npix, int C, void* stream);
-/* x_theta = pred;  eps_theta = (fake - sqrt(alpha) pred) / sqrt(1-alpha)   (train.py:394-398, 463-467); fp32 [n] each. */
-int gct2_diffusion_update(const float* pred, const float* fake, float alpha, float* x_theta, float* eps_theta,
-                          size_t n, void* stream);
+/* one sampler update from the network's prediction, by objective (train.py:338-355, 382-413, 452-479); fp32 [n] each,
+ * a = alpha = alpha_dash(t), a1 = alpha_prev = alpha_dash(t - 1) (ODE mode only, ignored otherwise):
+ *   GCT2_SAMPLE_X          (predict_x)            x_theta = pred;  eps_theta = (fake - sqrt(a) pred) / sqrt(1-a)
+ *   GCT2_SAMPLE_EPS        (epsilon)              eps_theta = pred;  x_theta = (fake - pred sqrt(1-a)) / sqrt(a)
+ *   GCT2_SAMPLE_SCALED_EPS (predict_scaled_epsilon) eps_theta = pred / sqrt(1-a);  x_theta = (fake - pred) / sqrt(a)
+ *   GCT2_SAMPLE_ODE        (ordinary_differential_equation)
+ *                          x_theta = (pred sqrt(1-a) - fake sqrt(1-a1)) / (sqrt(a1) sqrt(1-a) - sqrt(a) sqrt(1-a1));
+ *                          eps_theta is NOT touched (the reference never updates it in this branch; may be NULL). */
+enum { GCT2_SAMPLE_X = 0, GCT2_SAMPLE_EPS = 1, GCT2_SAMPLE_SCALED_EPS = 2, GCT2_SAMPLE_ODE = 3 };
+int gct2_diffusion_update(int mode, const float* pred, const float* fake, float alpha, float alpha_prev, float* x_theta,
+                          float* eps_theta, size_t n, void* stream);
 /* the four inputs of the reverse pass built from one inverted noise image eps [H,W,C] (train.py:416-431): out [4,H,W,C] =
  * eps | nearest-upsample x4 of avg_pool2d(eps, 4, 4) | tf.roll by 1 along H and W | per-pixel nearest of the K entries of
  * dictionary [H,W,K,C] (squared distance, first minimum).  H, W multiples of 4. */

@@ -2,6 +2,7 @@
     make -C gan-class-transfer2_amd/csrc clean all EXTRA=-DGCT2_STAMP && python scripts/stamp_layer.py [layer] && make -C gan-class-transfer2_amd/csrc clean all
 layer: U0 (default), U1, U2 = Conv2DTranspose input gradients of config 3 (conv-form 256 x 128 tiles)."""
 import sys, os
+os.environ["GCT2_ALLOW_DIAGNOSTIC_BUILD"] = "1"       # the binding refuses a stamped library otherwise (gct2_build_flags)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import gan_class_transfer2_amd as g
@@ -16,10 +17,12 @@ ctx = L.Context(); ctx.set_workspace(ws)
 dz = torch.randn(B, 2 * H, 2 * W, Cout, device=dev).to(bf); w = (torch.randn(4, 4, Cout, Cin, device=dev) * .05).to(bf)
 act = torch.randn(B, H, W, Cin, device=dev).to(bf); dx = torch.empty_like(act)
 stamps = torch.zeros(1 << 22, dtype=torch.int64, device=dev)
+assert L.build_flags() & L.BUILD_STAMP, "build with: make -C gan-class-transfer2_amd/csrc clean all EXTRA=-DGCT2_STAMP"
+ctx.set_stamp_buffer(stamps)
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     L.call("gct2_convT4s2_dgrad", ctx.handle, 1, dz.data_ptr(), Cout, w.data_ptr(), act.data_ptr(), Cin, dx.data_ptr(), Cin, B, H, W, Cin, Cout,
-           0, None, -12345, stamps.data_ptr(), 0, s)
+           0, None, 0, None, 0, s)
 torch.cuda.synchronize()
 st = stamps.cpu().numpy().reshape(-1, 8)
 st = st[st[:, 0] != 0][:, :5]

@@ -1,6 +1,7 @@
 """phases of the 256 x 256 weight-gradient launch from in-kernel s_memrealtime stamps (diagnostic build only):
     make -C gan-class-transfer2_amd/csrc clean all EXTRA=-DGCT2_STAMP && python scripts/stamp_wgrad.py [U0|U1] && make -C gan-class-transfer2_amd/csrc clean all"""
 import sys, os
+os.environ["GCT2_ALLOW_DIAGNOSTIC_BUILD"] = "1"       # the binding refuses a stamped library otherwise (gct2_build_flags)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import gan_class_transfer2_amd as g
@@ -14,9 +15,11 @@ ctx = L.Context(); ctx.set_workspace(ws)
 x = torch.randn(B, H, W, Cin, device=dev).to(bf); dz = torch.randn(B, 2 * H, 2 * W, Cout, device=dev).to(bf)
 dw = torch.zeros(4, 4, Cout, Cin, device=dev)
 stamps = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+assert L.build_flags() & L.BUILD_STAMP, "build with: make -C gan-class-transfer2_amd/csrc clean all EXTRA=-DGCT2_STAMP"
+ctx.set_stamp_buffer(stamps)
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
-    L.call("gct2_convT4s2_wgrad", ctx.handle, 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), stamps.data_ptr(), B, H, W, Cin, Cout, 0, None, s)
+    L.call("gct2_convT4s2_wgrad", ctx.handle, 1, x.data_ptr(), Cin, dz.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, None, s)
 torch.cuda.synchronize()
 st = stamps.cpu().numpy().reshape(-1, 4)
 st = st[st[:, 0] != 0]

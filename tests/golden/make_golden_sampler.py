@@ -2,7 +2,9 @@
 `python tests/golden/make_golden_sampler.py`).  PARITY UNPINNED w.r.t. TensorFlow (see make_golden.py): the vectors come
 from oracle/sampler_oracle.py (fp64) with the denoiser evaluated by the independent torch formulation as a cross-check.
 Contents: seeded weights / example image / example noises / dictionary -> every tensor log_sample hands to tf.summary
-(train.py:323-496) for a tiny topology (size 16, octaves 2, pixel_size 8, max_size 16) with steps = 6, test_step = 2."""
+(train.py:323-496) for a tiny topology (size 16, octaves 2, pixel_size 8, max_size 16) with steps = 6, test_step = 2:
+`out/<tensor>` for the reference's default switches, `mode/<eps|scaled_eps|ode>/<tensor>` for the other branches of
+train.py:338-355, 382-413, 452-479 (predict_x = False, + predict_scaled_epsilon, ordinary_differential_equation)."""
 import os
 import sys
 
@@ -14,6 +16,8 @@ from oracle import sampler_oracle as S  # noqa: E402
 
 TINY = dict(size=16, pixel_size=8, max_size=16, octaves=2, batch_size=1)
 STEPS, TEST_STEP, BITS = 6, 2, 3
+MODES = {"eps": dict(predict_x=False), "scaled_eps": dict(predict_x=False, predict_scaled_epsilon=True),
+         "ode": dict(ordinary_differential_equation=True)}
 
 
 def inputs():
@@ -38,6 +42,9 @@ def main():
         out["param/" + k] = v
     for k, v in res.items():
         out["out/" + k] = np.asarray(v)
+    for name, kw in MODES.items():
+        for k, v in S.log_sample(S.unet_denoiser(params, cfg), image, example, dictionary, STEPS, TEST_STEP, **kw).items():
+            out[f"mode/{name}/{k}"] = np.asarray(v)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tiny_sampler.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -17,7 +17,11 @@ pytestmark = pytest.mark.gpu
 CASES = {   # name: (dtype code, topology, steps, tolerance on the final parameters, bucket size in elements)
     "f32": (0, dict(size=16, pixel_size=8, max_size=16, octaves=2), 2, 2e-6, 1500),
     "bf16": (1, dict(size=16, pixel_size=128, max_size=256, octaves=2), 2, 2e-3, 200_000),
+    # five steps without warm-up at a learning rate that moves the biases far above any tolerance, so that a
+    # replica computing with stale fp32-read parameters (biases, Dense(3)) shows up in the replicas' own views and predictions
+    "bf16_nowarm": (1, dict(size=16, pixel_size=128, max_size=256, octaves=2), 5, 2e-3, 200_000),
 }
+ENGINE_KW = {"bf16_nowarm": dict(base_lr=1e-3, warm_up=0)}
 
 
 def _free_port():
@@ -48,7 +52,7 @@ def _worker(rank, world, port, case, out_dir, mode="allreduce"):
         cfg = O.OracleConfig(batch_size=4, **topo_kw)
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
-        eng = g.UNetEngine(g.Topology(cfg.pixel_size, cfg.max_size, cfg.octaves), dt, dev)
+        eng = g.UNetEngine(g.Topology(cfg.pixel_size, cfg.max_size, cfg.octaves), dt, dev, **ENGINE_KW.get(case, {}))
         eng.set_params(O.init_params(cfg, seed=21))
         per = cfg.batch_size // world
         if mode == "sharded":
@@ -58,6 +62,19 @@ def _worker(rank, world, port, case, out_dir, mode="allreduce"):
             assert eng.iterations == nsteps and dp.launched == len(dp.buckets)
             if eng.arena.shadow is not None:       # what the replicas compute with: bit-identical operand copies
                 np.save(os.path.join(out_dir, f"shadow{rank}.npy"), eng.arena.shadow.float().cpu().numpy())
+                # ... and, BEFORE gather_master(), the parameters the kernels read in fp32 from the master arena + a prediction
+                A = eng.arena
+                names = [n for n in A.shapes if n.endswith(".b") or n.startswith("dense.")]
+                np.save(os.path.join(out_dir, f"small{rank}.npy"), torch.cat([A.param(n).reshape(-1) for n in names]).cpu().numpy())
+                probe = torch.tensor(_batches(cfg, 1)[0][0], dtype=torch.float32, device=dev)
+                np.save(os.path.join(out_dir, f"pred{rank}.npy"), eng.predict(probe).cpu().numpy())
+                try:
+                    eng.state_dict()
+                    raise AssertionError("state_dict() must refuse while the masters are sharded")
+                except g.Gct2Error:
+                    pass
+                sd = dp.state_dict()               # gathers first
+                assert float(sd["arena.m"].abs().max()) > 0
             dp.gather_master()                     # the fp32 masters are sharded: assemble them for the comparison
         else:
             dp = DataParallelStep(eng, bucket_elems=bucket)
@@ -70,18 +87,36 @@ def _worker(rank, world, port, case, out_dir, mode="allreduce"):
 
 
 @pytest.mark.parametrize("mode", ["allreduce", "sharded"])
-@pytest.mark.parametrize("case", ["f32", "bf16"])
+@pytest.mark.parametrize("case", ["f32", "bf16", "bf16_nowarm"])
 def test_two_ranks_on_one_gpu_equal_global_batch(gpu, tmp_path, case, mode):
+    if case == "bf16_nowarm" and mode != "sharded":
+        pytest.skip("the fp32-read parameter exchange belongs to the sharded scheme")
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, case, str(tmp_path), mode), nprocs=world, join=True)
-    if mode == "sharded" and case == "bf16":
-        assert np.array_equal(np.load(tmp_path / "shadow0.npy"), np.load(tmp_path / "shadow1.npy"))
     import gan_class_transfer2_amd as g
     dt, topo_kw, nsteps, tol, _ = CASES[case]
     cfg = O.OracleConfig(batch_size=4, **topo_kw)
-    eng = g.UNetEngine(g.Topology(cfg.pixel_size, cfg.max_size, cfg.octaves), dt, gpu)
+    eng = g.UNetEngine(g.Topology(cfg.pixel_size, cfg.max_size, cfg.octaves), dt, gpu, **ENGINE_KW.get(case, {}))
     eng.set_params(O.init_params(cfg, seed=21))
     _run(eng, cfg, nsteps, slice(0, cfg.batch_size), gpu)
+    if mode == "sharded" and dt != 0:
+        assert np.array_equal(np.load(tmp_path / "shadow0.npy"), np.load(tmp_path / "shadow1.npy"))
+        # the replicas' own fp32-read parameters and predictions, taken WITHOUT gather_master(): bit-identical across ranks and
+        # equal to the single-process run (r02: non-owner ranks kept the initial biases / Dense(3))
+        s0, s1 = np.load(tmp_path / "small0.npy"), np.load(tmp_path / "small1.npy")
+        assert np.array_equal(s0, s1)
+        A = eng.arena
+        names = [n for n in A.shapes if n.endswith(".b") or n.startswith("dense.")]
+        s_ref = torch.cat([A.param(n).reshape(-1) for n in names]).cpu().numpy()
+        assert np.linalg.norm(s0 - s_ref) <= tol * np.linalg.norm(s_ref)
+        if case == "bf16_nowarm":
+            zero_bias = np.linalg.norm(s_ref[: s_ref.size // 2])
+            assert zero_bias > 1e-3                                              # the biases moved: stale ones could not pass
+        p0, p1 = np.load(tmp_path / "pred0.npy"), np.load(tmp_path / "pred1.npy")
+        assert np.array_equal(p0, p1)
+        probe = torch.tensor(_batches(cfg, 1)[0][0], dtype=torch.float32, device=gpu)
+        p_ref = eng.predict(probe).cpu().numpy()
+        assert np.linalg.norm(p0 - p_ref) <= 2e-2 * np.linalg.norm(p_ref)
     ref = eng.get_params()
     r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
     for k, v in ref.items():

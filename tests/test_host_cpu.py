@@ -28,7 +28,34 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gct2.h but not exported"
     # and the ctypes table binds exactly the declared entry points (minus last_error, bound separately)
     assert sorted(set(g._lib.SIGNATURES) | {"gct2_last_error"}) == names
-    assert g._lib.load().gct2_abi_version() == 11
+    assert g._lib.load().gct2_abi_version() == g._lib.ABI_VERSION == 12
+    # the shipped library is the PRODUCT build: no in-kernel stamps, and the diagnostic hook refuses
+    assert g._lib.build_flags() == 0
+    c = g._lib.Context()
+    with pytest.raises(g.Gct2Error, match="product build"):
+        g._lib.call("gct2_ctx_set_stamp_buffer", c.handle, 4096, 1 << 20)
+
+
+def test_binding_refuses_a_diagnostic_library(monkeypatch, tmp_path):
+    """a library built with -DGCT2_STAMP reports it through gct2_build_flags(); _lib.load() (hence the engine, bench.py and every
+    test) refuses it unless GCT2_ALLOW_DIAGNOSTIC_BUILD=1 (scripts/stamp_*.py set it).  Checked with a stand-in library that only
+    exports the two identification calls - the binding must refuse before touching anything else."""
+    import subprocess
+    import gan_class_transfer2_amd as g
+    src = tmp_path / "fake.c"
+    src.write_text("int gct2_abi_version(void){return %d;}\nint gct2_build_flags(void){return 1;}\n"
+                   "const char* gct2_last_error(void){return \"\";}\n" % g._lib.ABI_VERSION)
+    so = tmp_path / "libgct2.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    monkeypatch.setattr(g._lib, "_lib", None)
+    monkeypatch.setattr(g._lib, "LIB_PATH", str(so))
+    monkeypatch.setattr(g._lib, "SIGNATURES", {"gct2_abi_version": [], "gct2_build_flags": []})
+    monkeypatch.delenv("GCT2_ALLOW_DIAGNOSTIC_BUILD", raising=False)
+    with pytest.raises(g.Gct2Error, match="DIAGNOSTIC"):
+        g._lib.load()
+    monkeypatch.setenv("GCT2_ALLOW_DIAGNOSTIC_BUILD", "1")
+    assert g._lib.load().gct2_build_flags() == 1
+    monkeypatch.setattr(g._lib, "_lib", None)
 
 
 def test_argument_validation_needs_no_gpu():

@@ -218,3 +218,61 @@ def test_model_surface_with_variants(gpu):
         assert len(hist["loss"]) == 2 and all(np.isfinite(hist["loss"])) and den.engine.iterations == 6
     finally:
         g.configure(size=256, pixel_size=128, max_size=512, octaves=6, block_depth=0, residual=False, predict_x=True, compute_dtype=None)
+
+
+def test_engine_built_before_trainer_follows_the_objective_switches(gpu):
+    """r02: the objective switches (train.py:29-32) reached the engine only through Trainer's constructor kwargs, and ensure_engine
+    ignored kwargs once an engine existed - `denoiser(...)`, `trainable_variables` or the log_sample callback at on_epoch_begin built
+    a default-objective engine first and training silently optimised the wrong target.  Now whoever builds the engine reads the
+    module switches, and Trainer re-reads them at every call (train.py reads its globals at call time)."""
+    import gan_class_transfer2_amd as g
+    from oracle import denoiser_oracle as O2
+    g.configure(size=16, pixel_size=8, max_size=16, octaves=2, predict_x=False, compute_dtype="float32")
+    try:
+        den = g.Denoiser(seed=5)
+        gen = torch.Generator().manual_seed(0)
+        ex = (torch.randint(0, 256, (2, 16, 16, 3), generator=gen).float() / 128 - 1).to(gpu)
+        t = torch.ones(2, 1, 1, 1, dtype=torch.int32, device=gpu)
+        den((ex, t))                                    # builds the engine BEFORE any Trainer exists
+        assert den.engine.predict_x is False
+        tr = g.Trainer(den)
+        tr.compile(g.Adam(g.WarmUp(2e-5, 10)), g.identity)
+        eng = tr._engine()
+        assert eng is den.engine and eng.predict_x is False
+        # one step with injected noise against the oracle's epsilon objective
+        cfg = O2.OracleConfig(size=16, pixel_size=8, max_size=16, octaves=2, batch_size=2, steps=g.model.steps)
+        params = {k: v for k, v in eng.get_params().items()}
+        x = ex.cpu().numpy().astype(np.float64)
+        rng = np.random.default_rng(9)
+        t_int = np.array([3, 150], dtype=np.int32)
+        eps = rng.standard_normal(x.shape).astype(np.float32).astype(np.float64)
+        loss_ref = O2.trainer_step({k: v.astype(np.float64) for k, v in params.items()}, x, t_int, eps, cfg,
+                                   objective=dict(predict_x=False))[0]
+        loss = eng.train_step(ex, torch.tensor(t_int), torch.tensor(eps, dtype=torch.float32), apply=False)
+        assert abs(float(loss[0]) - loss_ref) <= 2e-5 * abs(loss_ref)
+        # the switches are read at call time: flipping the global re-targets the existing engine at the next Trainer call
+        g.configure(predict_x=True)
+        assert tr._engine().predict_x is True
+    finally:
+        g.configure(size=256, pixel_size=128, max_size=512, octaves=6, predict_x=True, compute_dtype=None)
+
+
+def test_fit_with_log_sample_callback_on_a_variant_network(gpu):
+    """train.py:516-523 with the reference's callback on a block_depth = 1 network: r02's sampler died with AttributeError at the
+    first on_epoch_begin (VariantEngine has no planned buffers)."""
+    import gan_class_transfer2_amd as g
+    g.configure(size=16, pixel_size=8, max_size=16, octaves=2, block_depth=1, steps=4, compute_dtype="float32")
+    try:
+        den = g.Denoiser(seed=5)
+        tr = g.Trainer(den)
+        tr.compile(g.Adam(g.WarmUp(2e-5, 10)), g.identity)
+        gen = torch.Generator().manual_seed(0)
+        ex = (torch.randint(0, 256, (1, 16, 16, 3), generator=gen).float() / 128 - 1).to(gpu)
+        seen = []
+        cb = g.LambdaCallback(on_epoch_begin=g.make_log_sample(den, ex, torch.randn(1, 2, 16, 16, 3, generator=gen).to(gpu),
+                                                              torch.randn(16, 16, 8, 3, generator=gen).to(gpu),
+                                                              lambda epoch, images: seen.append((epoch, sorted(images)))))
+        hist = tr.fit(iter([(ex, ex)] * 4), steps_per_epoch=2, epochs=2, callbacks=[cb], verbose=0)
+        assert len(seen) == 2 and "fake" in seen[0][1] and all(np.isfinite(hist["loss"]))
+    finally:
+        g.configure(size=256, pixel_size=128, max_size=512, octaves=6, block_depth=0, steps=200, compute_dtype=None)
