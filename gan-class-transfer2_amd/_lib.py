@@ -36,7 +36,7 @@ class AdamArgs(C.Structure):
                 ("grad_mul", C.c_float)]
 
 
-_vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+_vp, _i, _f, _d, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_uint64, C.c_size_t
 
 # name -> argtypes, exactly the prototypes of include/gct2.h
 SIGNATURES = {
@@ -51,7 +51,7 @@ SIGNATURES = {
     "gct2_ctx_force_direct": [_vp, _i],
     "gct2_ctx_set_stamp_buffer": [_vp, _vp, _sz],
     "gct2_diffusion_mix": [_i, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _sz, _i, _vp],
-    "gct2_diffusion_update": [_i, _vp, _vp, _f, _f, _vp, _vp, _sz, _vp],
+    "gct2_diffusion_update": [_i, _vp, _vp, _d, _d, _vp, _vp, _sz, _vp],
     "gct2_noise_edits": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "gct2_image_prepare": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "gct2_conv4s2_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -35,7 +35,7 @@ int conv_s1_direct(int dtype, bool dgrad, const void* x, int ldx, const void* w,
 int conv_s1_wgrad_direct(int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, int B, int H, int W, int Cin, int Cout, int KS,
                          int accumulate, hipStream_t s);
 int pw_diffusion_mix(int, const float*, const float*, float, float*, void*, int, void*, int, size_t, int, hipStream_t);
-int pw_diffusion_update(int, const float*, const float*, float, float, float*, float*, size_t, hipStream_t);
+int pw_diffusion_update(int, const float*, const float*, double, double, float*, float*, size_t, hipStream_t);
 int pw_noise_edits(const float*, const float*, int, float*, int, int, int, hipStream_t);
 int pw_image_prepare(const uint8_t*, const int64_t*, const int32_t*, float*, int, int, hipStream_t);
 int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const gct2_loss_scale_state*, int, hipStream_t,
@@ -165,9 +165,11 @@ int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   ctx->wgrad_pipe = (wv & 0x40) ? 0 : 1;
   ctx->wgrad_target = (wv & 0x10) ? 512 : 256;
   ctx->wgrad_slab_max = (wv & 0x20) ? 64 : 24;
+  ctx->wgrad_ring = (wv & 0x80) ? 5 : 4;
   ctx->halo_mode = (v >> 24) & 3;
   ctx->xcd_order = (v >> 26) & 3;
   ctx->wgrad_split = (v >> 28) & 7;
+  ctx->halo_il = (int)(((unsigned)v >> 31) & 1u);
   return GCT2_OK;
 }
 int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes) {
@@ -412,16 +414,16 @@ int gct2_diffusion_mix(int dtype, const float* x_theta, const float* eps_theta, 
   return pw_diffusion_mix(dtype, x_theta, eps_theta, alpha, fake, out, ldout, out2, ldout2, npix, C, S(stream));
 }
 
-int gct2_diffusion_update(int mode, const float* pred, const float* fake, float alpha, float alpha_prev, float* x_theta, float* eps_theta,
+int gct2_diffusion_update(int mode, const float* pred, const float* fake, double alpha, double alpha_prev, float* x_theta, float* eps_theta,
                           size_t n, void* stream) {
   if (mode < GCT2_SAMPLE_X || mode > GCT2_SAMPLE_ODE) return gct2_fail(GCT2_EINVAL, "diffusion_update: unknown mode %d", mode);
   if (!pred || !fake || !x_theta || (!eps_theta && mode != GCT2_SAMPLE_ODE) || n == 0)
     return gct2_fail(GCT2_EINVAL, "diffusion_update: null pointer or n == 0");
-  if (!(alpha >= 0.f && alpha < 1.f)) return gct2_fail(GCT2_EINVAL, "diffusion_update: alpha must be in [0, 1)");
-  if (mode != GCT2_SAMPLE_X && !(alpha > 0.f)) return gct2_fail(GCT2_EINVAL, "diffusion_update: this mode divides by sqrt(alpha): alpha must be > 0");
+  if (!(alpha >= 0. && alpha < 1.)) return gct2_fail(GCT2_EINVAL, "diffusion_update: alpha must be in [0, 1)");
+  if (mode != GCT2_SAMPLE_X && !(alpha > 0.)) return gct2_fail(GCT2_EINVAL, "diffusion_update: this mode divides by sqrt(alpha): alpha must be > 0");
   if (mode == GCT2_SAMPLE_ODE) {
-    if (!(alpha_prev >= 0.f && alpha_prev <= 1.f)) return gct2_fail(GCT2_EINVAL, "diffusion_update: alpha_prev must be in [0, 1]");
-    if (sqrtf(alpha_prev) * sqrtf(1.f - alpha) - sqrtf(alpha) * sqrtf(1.f - alpha_prev) == 0.f)
+    if (!(alpha_prev >= 0. && alpha_prev <= 1.)) return gct2_fail(GCT2_EINVAL, "diffusion_update: alpha_prev must be in [0, 1]");
+    if (sqrt(alpha_prev) * sqrt(1. - alpha) - sqrt(alpha) * sqrt(1. - alpha_prev) == 0.)
       return gct2_fail(GCT2_EINVAL, "diffusion_update: alpha == alpha_prev makes the ODE step singular (train.py:386-391)");
   }
   return pw_diffusion_update(mode, pred, fake, alpha, alpha_prev, x_theta, eps_theta, n, S(stream));

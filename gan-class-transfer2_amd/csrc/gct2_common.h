@@ -23,7 +23,9 @@ struct gct2_ctx {
   float* wws = nullptr; size_t wws_bytes = 0;      // weight-gradient slabs (falls back to ws)
   int tap_variant = 0;                             // forward / input-gradient tile (0 = automatic)
   int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 24;
+  int wgrad_ring = 4;                              // stage buffers of the 256 x 256 weight-gradient pipeline (4 or 5)
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
+  int halo_il = 0;                                 // halo kernel: DMA pieces interleaved with the MFMA groups (A/B knob)
   int xcd_order = 0;                               // tile -> XCD order: 0 = automatic, 1 = m-tile bands, 2 = weight slices
   int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile: 0 = automatic, v: 2^(v-1)
   int force_direct = 0;
@@ -66,6 +68,11 @@ __device__ __forceinline__ int timg_off(int k, int chunk16) {
   return k * 256 + ((((chunk16 >> 1) ^ timg_swz(k))) << 5) + ((chunk16 & 1) << 4);
 }
 
+// "ring image" of the deep-pipelined 256 x 256 tap GEMM: [rows][32 x 16-bit] = 64-byte rows (half a 64-channel step), 16-byte chunk c
+//  of row r stored at chunk c ^ ring_swz((r>>2)&3): ds_read_b128 of 16 consecutive rows (row = base + (lane&15), chunk = lane>>4) is
+//  conflict-free for bases that are multiples of 16 (exhaustive check against the ds_read_b128 lane groups of MI355X_MICROARCH.md).
+__device__ __forceinline__ int ring_swz(int x) { return (4 - x) & 3; }       // {0, 3, 2, 1}
+
 __device__ __forceinline__ u32x4_t lds_read128(const char* lds, int off) {
   return *reinterpret_cast<const u32x4_t*>(lds + off);
 }
@@ -75,6 +82,10 @@ __device__ __forceinline__ void lds_write128(char* lds, int off, u32x4_t v) {
 // fragment (8 consecutive reduction elements for this lane's row/col) out of an N image
 __device__ __forceinline__ u32x4_t nimg_frag(const char* img, int rowbase, int kk, int lane) {
   return lds_read128(img, nimg_off(rowbase + (lane & 15), 4 * kk + (lane >> 4)));
+}
+// fragment (8 consecutive reduction elements of the 32-deep stage) out of a ring image; rowbase is a multiple of 16
+__device__ __forceinline__ u32x4_t ring_frag(const char* img, int rowbase, int lane) {
+  return lds_read128(img, (rowbase + (lane & 15)) * 64 + (((lane >> 4) ^ ring_swz((lane >> 2) & 3)) << 4));
 }
 // same fragment out of a T image (column block `colbase`, multiple of 16) via two transposed reads
 __device__ __forceinline__ u32x4_t timg_frag(const char* img, int colbase, int kk, int lane) {

@@ -655,10 +655,9 @@ __global__ void diffusion_mix_kernel(const float* __restrict__ x, const float* _
 //   X: x = pred, e = (fake - sa x) / sb;  EPS: e = pred, x = (fake - pred sb) / sa;  SCALED_EPS: e = pred / sb, x = (fake - pred) / sa;
 //   ODE: x = (pred sb - fake sb1) / (sa1 sb - sa sb1), e untouched.  sa = sqrt(a_t), sb = sqrt(1 - a_t), sa1 / sb1 the same at t - 1.
 template <int MODE>
-__global__ void diffusion_update_kernel(const float* __restrict__ pred, const float* __restrict__ fake, float sa, float sb, float sa1, float sb1,
+__global__ void diffusion_update_kernel(const float* __restrict__ pred, const float* __restrict__ fake, float sa, float sb, float sb1, float den,
                                         float* __restrict__ x, float* __restrict__ e, size_t n) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const float den = sa1 * sb - sa * sb1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float p = pred[i], f = fake[i];
     if (MODE == GCT2_SAMPLE_X) {
@@ -1065,14 +1064,16 @@ int pw_diffusion_mix(int dtype, const float* x, const float* e, float a, float* 
   if (dtype == GCT2_BF16) return diffusion_mix_t<__bf16>(x, e, a, fake, out, ldout, out2, ldout2, npix, C, s);
   return diffusion_mix_t<_Float16>(x, e, a, fake, out, ldout, out2, ldout2, npix, C, s);
 }
-int pw_diffusion_update(int mode, const float* pred, const float* fake, float a, float a1, float* x, float* e, size_t n, hipStream_t s) {
+int pw_diffusion_update(int mode, const float* pred, const float* fake, double a, double a1, float* x, float* e, size_t n, hipStream_t s) {
   const dim3 grid(blocks_for(n, 256)), block(256);
-  const float sa = sqrtf(a), sb = sqrtf(1.f - a), sa1 = sqrtf(a1), sb1 = sqrtf(1.f - a1);
-  if (mode == GCT2_SAMPLE_X) hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_X>, grid, block, 0, s, pred, fake, sa, sb, sa1, sb1, x, e, n);
-  else if (mode == GCT2_SAMPLE_EPS) hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_EPS>, grid, block, 0, s, pred, fake, sa, sb, sa1, sb1, x, e, n);
+  // every scalar in double first, like the Python floats of train.py:382-391, then one cast where it meets an fp32 tensor
+  const double dsa = sqrt(a), dsb = sqrt(1. - a), dsa1 = sqrt(a1), dsb1 = sqrt(1. - a1);
+  const float sa = (float)dsa, sb = (float)dsb, sb1 = (float)dsb1, den = (float)(dsa1 * dsb - dsa * dsb1);
+  if (mode == GCT2_SAMPLE_X) hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_X>, grid, block, 0, s, pred, fake, sa, sb, sb1, den, x, e, n);
+  else if (mode == GCT2_SAMPLE_EPS) hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_EPS>, grid, block, 0, s, pred, fake, sa, sb, sb1, den, x, e, n);
   else if (mode == GCT2_SAMPLE_SCALED_EPS)
-    hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_SCALED_EPS>, grid, block, 0, s, pred, fake, sa, sb, sa1, sb1, x, e, n);
-  else hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_ODE>, grid, block, 0, s, pred, fake, sa, sb, sa1, sb1, x, e, n);
+    hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_SCALED_EPS>, grid, block, 0, s, pred, fake, sa, sb, sb1, den, x, e, n);
+  else hipLaunchKernelGGL(diffusion_update_kernel<GCT2_SAMPLE_ODE>, grid, block, 0, s, pred, fake, sa, sb, sb1, den, x, e, n);
   return gct2_check_launch("diffusion_update");
 }
 int pw_noise_edits(const float* eps, const float* dict, int K, float* out, int H, int W, int C, hipStream_t s) {

@@ -84,18 +84,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   constexpr bool WT = (FORM == FORM_CONV || FORM == FORM_S1);   // weights [tap][k][n] (T image); otherwise [tap][n][k] (N image)
   static_assert(!WT || BN % 128 == 0, "T images are 128 columns wide");
   constexpr int WAVES_N = BN / 64;
-  constexpr int NA = BM / 8 / NWV;                 // 1-KiB pieces per wave, activation tile (8 rows each)
-  constexpr int NW = (WT ? 16 * (BN / 128) : BN / 8) / NWV;
+  // RING (NBUF = 5): the deep pipeline of wgrad256p_kernel for the forward / input-gradient GEMMs.  A stage is HALF a 64-channel
+  // step (32 channels of one tap: 16 KiB of pixels + 16 KiB of weights for the 256 x 256 tile), five stage buffers fill the CU's
+  // 160 KiB of LDS, the DMA of stage s+4 is issued while stage s is multiplied and only stage s+1 is waited for (counted vmcnt,
+  // raw s_barrier): FOUR stages = 128 KiB stay in flight across every barrier, against one step drained to zero at every barrier
+  // in the other variants.  These loops are bound by the latency of the staging requests that miss the XCD's L2.
+  constexpr bool RING = NBUF >= 5;             // NBUF = 6: the ring with the DMA pieces interleaved into the MFMA groups
+  constexpr bool RING_IL = NBUF == 6;
+  static_assert(!RING || (NWV == 8 && !S1), "the ring pipeline is built for the 8-wave 4x4 / stride-2 forms");
+  constexpr int BKS = RING ? 32 : BK;              // reduction elements per stage
+  constexpr int NA = RING ? BM / 16 / NWV : BM / 8 / NWV;   // 1-KiB pieces per wave, activation tile (8 rows of 128 B, or 16 rows of 64 B)
+  constexpr int NW = RING ? (WT ? 8 * (BN / 128) : BN / 16) / NWV : (WT ? 16 * (BN / 128) : BN / 8) / NWV;
   constexpr int NDMA = NA + NW;                    // DMA instructions per wave per step
-  constexpr int A_BYTES = BM * 128;
-  constexpr int W_BYTES = WT ? 64 * 256 * (BN / 128) : BN * 128;   // T images: BN/128 of them side by side
+  constexpr int A_BYTES = RING ? BM * 64 : BM * 128;
+  constexpr int W_BYTES = RING ? (WT ? 32 * 256 * (BN / 128) : BN * 64)
+                               : (WT ? 64 * 256 * (BN / 128) : BN * 128);   // T images: BN/128 of them side by side
   constexpr int NTAPS = (FORM == FORM_CONV) ? 16 : 4;              // (the stride-1 forms: p.ks * p.ks, run-time)
 
   // DISTINCT LDS objects: lets hipcc prove that the DMA into one buffer does not alias the ds_reads of another,
   // so it does not drain vmcnt before every read (cdna_hip_programming.md, "Three .s-level traps" (a))
   __shared__ __attribute__((aligned(16))) char lds0[A_BYTES + W_BYTES];
   __shared__ __attribute__((aligned(16))) char lds1[NBUF >= 2 ? A_BYTES + W_BYTES : 16];
-  __shared__ __attribute__((aligned(16))) char lds2[NBUF == 3 ? A_BYTES + W_BYTES : 16];
+  __shared__ __attribute__((aligned(16))) char lds2[NBUF >= 3 ? A_BYTES + W_BYTES : 16];
+  __shared__ __attribute__((aligned(16))) char lds3[RING ? A_BYTES + W_BYTES : 16];
+  __shared__ __attribute__((aligned(16))) char lds4[RING ? A_BYTES + W_BYTES : 16];
 
 #ifdef GCT2_STAMP
   unsigned long long st[5];
@@ -136,12 +148,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   // ---- per-lane DMA descriptors (fixed over the whole K loop) ------------------------------------------
   // activation tile (N image): piece q = wave + 4 i holds rows 8q .. 8q+7; lane -> row 8q + (lane>>3),
   // physical chunk lane&7 = logical chunk ^ ((row>>1)&7)
-  const int a_lchunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);   // 4*NWV*i is a multiple of 8
+  // RING: 64-byte rows (32 channels), piece q = wave + 8 i holds rows 16q .. 16q+15; lane -> row 16q + (lane>>2), physical chunk
+  // lane&3 = logical chunk ^ ring_swz((row>>2)&3) (conflict-free for ds_read_b128 of 16 consecutive rows: checked exhaustively
+  // against the lane groups of MI355X_MICROARCH.md, LDS table)
+  const int a_lchunk = RING ? ((lane & 3) ^ ring_swz((lane >> 4) & 3))
+                            : ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7));   // 4*NWV*i is a multiple of 8
   unsigned a_off[NA];                              // byte offset of (row's tap-origin pixel, logical chunk)
   unsigned a_mask[NA];                             // bit t: tap t reads inside the image for this row
 #pragma unroll
   for (int i = 0; i < NA; i++) {
-    const int m = m0 + 8 * (wave + NWV * i) + (lane >> 3);
+    const int m = RING ? m0 + 16 * (wave + NWV * i) + (lane >> 2) : m0 + 8 * (wave + NWV * i) + (lane >> 3);
     a_off[i] = 0; a_mask[i] = 0;
     if (m < M) {
       int sw, sh, b;
@@ -173,7 +189,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   int w_k[NW];                                     // FORM_CONV: k row inside the 64-step; FORM_CONVT: unused
 #pragma unroll
   for (int i = 0; i < NW; i++) {
-    if (WT) {                                      // T image: piece = 4 k-rows x 16 chunks
+    if (RING && WT) {                              // 32-row T images: piece `wave` of image i = k-rows 4 wave .. 4 wave + 3
+      const int k = 4 * wave + (lane >> 4);
+      const int lc = ((((lane & 15) >> 1) ^ timg_swz(k)) << 1) | (lane & 1);
+      const int nn = n0 + i * 128 + lc * 8;
+      w_k[i] = k;
+      w_nok[i] = nn < N;
+      w_off[i] = (unsigned)((k * N + nn) * 2);
+    } else if (RING) {                             // 64-byte-row N image of the weights: piece = 16 n-rows x 4 chunks
+      const int n = 16 * (wave + NWV * i) + (lane >> 2);
+      w_k[i] = a_lchunk * 8;
+      w_nok[i] = (n0 + n) < N;
+      w_off[i] = (unsigned)(((n0 + n) * K + a_lchunk * 8) * 2);
+    } else if (WT) {                               // T image: piece = 4 k-rows x 16 chunks
       const int q = wave + NWV * i;                // pieces 0..15 fill image 0 (columns n0..n0+127), 16..31 image 1
       const int k = 4 * (q & 15) + (lane >> 4);
       const int lc = ((((lane & 15) >> 1) ^ timg_swz(k)) << 1) | (lane & 1);
@@ -189,11 +217,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
     }
   }
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K + BKS - 1) / BKS;
   const int niter = (S1 ? p.ks * p.ks : NTAPS) * nk;
 
   auto issue = [&](int it, char* abase) {
-    const int tap = it / nk, c0 = (it - tap * nk) * BK;
+    const int tap = it / nk, c0 = (it - tap * nk) * BKS;
     int tap16, dh, dw;
     if (FORM == FORM_CONV) { tap16 = tap; dh = tap >> 2; dw = tap & 3; }
     else if (S1) {                                 // the input gradient walks the same window with the kernel flipped
@@ -211,14 +239,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
 #pragma unroll
     for (int i = 0; i < NA; i++) {
       const bool ok = a_cok && ((a_mask[i] >> abit) & 1u);
-      dma16<NBUF == 3>(rs_x, abase + (wave + NWV * i) * 1024, ok ? a_off[i] + tapoff : OOB);
+      dma16<NBUF >= 3>(rs_x, abase + (wave + NWV * i) * 1024, ok ? a_off[i] + tapoff : OOB);
     }
     char* wbase = abase + A_BYTES;
     const unsigned wtap = WT ? (unsigned)(((tap16 * K + c0) * N) * 2) : (unsigned)((tap16 * N * K + c0) * 2);
 #pragma unroll
     for (int i = 0; i < NW; i++) {
       const bool ok = w_nok[i] && (c0 + w_k[i]) < K;
-      dma16<NBUF == 3>(rs_w, wbase + (wave + NWV * i) * 1024, ok ? w_off[i] + wtap : OOB);
+      // (RING + T image: piece `wave` of image i at i * 8 KiB; every other layout: consecutive pieces)
+      dma16<NBUF >= 3>(rs_w, wbase + ((RING && WT) ? i * (32 * 256) + wave * 1024 : (wave + NWV * i) * 1024), ok ? w_off[i] + wtap : OOB);
     }
   };
 
@@ -246,6 +275,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < MF; j++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
+    }
+  };
+  // RING: one 32-deep MFMA step per stage; fragments of the 64-byte-row images / the 32-row T images
+  auto compute_ring = [&](const char* a_img) {
+    const char* w_img = a_img + A_BYTES;
+    int ql = lane;                                 // opaque copy: keeps the fragment addresses of the five unrolled stages out of
+    asm volatile("" : "+v"(ql));                   // the loop preamble (they would be hoisted and spill, as in wgrad256p_kernel)
+    u32x4_t wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      wf[i] = WT ? timg_frag(w_img + (wn >> 1) * (32 * 256), (wn & 1) * 64 + i * 16, 0, ql) : ring_frag(w_img, wn * 64 + i * 16, ql);
+#pragma unroll
+    for (int j = 0; j < MF; j++) {
+      const u32x4_t af = ring_frag(a_img, wm * WM + j * 16, ql);
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i][j] = mfma16<T>(wf[i], af, acc[i][j]);
     }
   };
   // `live` is always true (ksplit >= 1) but opaque to hipcc: a code-generation fence.  With the multiplies unconditional the
@@ -276,6 +321,91 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       if (live) compute(lds1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+    }
+  } else if constexpr (RING) {
+    // wait until at most `ahead` whole stages (the youngest ones) are still in flight
+    auto wait_ahead = [&](int ahead) {
+      if (ahead >= 3) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(3 * NDMA));
+      else if (ahead == 2) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(2 * NDMA));
+      else if (ahead == 1) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(NDMA));
+      else __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(0));
+    };
+    // stage s: issue s+4 into the buffer stage s-1 has just left (every wave is past the barrier that ended it), multiply s, wait
+    // until stage s+1 has landed (everything older than the newest `ahead` stages), raw barrier: s+1 is read only after it
+    // one DMA piece of a stage (q < NA: activation piece q, else weight piece q - NA): the interleaved form issues the four
+    // pieces of stage s+4 BETWEEN the four MFMA groups of stage s, so that a piece's issue time (60-185 cycles each beside other
+    // memory instructions, MI355X_MICROARCH.md) is covered by the eight MFMAs in front of it instead of idling the matrix pipe
+    auto issue_piece = [&](int it, char* abase, int q) {
+      const int tap = it / nk, c0 = (it - tap * nk) * BKS;
+      int tap16, dh, dw;
+      if (FORM == FORM_CONV) { tap16 = tap; dh = tap >> 2; dw = tap & 3; }
+      else {
+        const int a = tap >> 1, c = tap & 1;
+        dh = 1 - a; dw = 1 - c;
+        tap16 = (1 - ph + 2 * a) * 4 + (1 - pw + 2 * c);
+      }
+      if (q < NA) {
+        const int abit = (FORM == FORM_CONVT) ? dh * 2 + dw : tap;
+        const unsigned tapoff = (unsigned)((dh * Wsrc + dw) * ldx2 + c0 * 2);
+        const bool ok = (c0 + a_lchunk * 8) < K && ((a_mask[q] >> abit) & 1u);
+        dma16<true>(rs_x, abase + (wave + NWV * q) * 1024, ok ? a_off[q] + tapoff : OOB);
+      } else {
+        const int i = q - NA;
+        const unsigned wtap = WT ? (unsigned)(((tap16 * K + c0) * N) * 2) : (unsigned)((tap16 * N * K + c0) * 2);
+        const bool ok = w_nok[i] && (c0 + w_k[i]) < K;
+        dma16<true>(rs_w, abase + A_BYTES + (WT ? i * (32 * 256) + wave * 1024 : (wave + NWV * i) * 1024), ok ? w_off[i] + wtap : OOB);
+      }
+    };
+    auto stage_il = [&](int it, const char* cur, char* tgt) {
+      const bool more = it + 4 < it_hi;
+      const char* w_img = cur + A_BYTES;
+      int ql = lane;
+      asm volatile("" : "+v"(ql));
+      u32x4_t wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        wf[i] = WT ? timg_frag(w_img + (wn >> 1) * (32 * 256), (wn & 1) * 64 + i * 16, 0, ql) : ring_frag(w_img, wn * 64 + i * 16, ql);
+#pragma unroll
+      for (int q = 0; q < MF / 2; q++) {
+        const u32x4_t af0 = ring_frag(cur, wm * WM + (2 * q) * 16, ql), af1 = ring_frag(cur, wm * WM + (2 * q + 1) * 16, ql);
+        if (more && q < NDMA) issue_piece(it + 4, tgt, q);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { acc[i][2 * q] = mfma16<T>(wf[i], af0, acc[i][2 * q]); acc[i][2 * q + 1] = mfma16<T>(wf[i], af1, acc[i][2 * q + 1]); }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wait_ahead(min(it + 4, it_hi - 1) - (it + 1));
+      __builtin_amdgcn_s_barrier();
+    };
+    auto stage = [&](int it, const char* cur, char* tgt) {
+      if constexpr (RING_IL) {
+        if (live) stage_il(it, cur, tgt);
+        return;
+      }
+      if (it + 4 < it_hi) issue(it + 4, tgt);
+      if (live) compute_ring(cur);
+      wait_ahead(min(it + 4, it_hi - 1) - (it + 1));
+      __builtin_amdgcn_s_barrier();
+    };
+    if (it_lo < it_hi) {
+      issue(it_lo, lds0);
+      if (it_lo + 1 < it_hi) issue(it_lo + 1, lds1);
+      if (it_lo + 2 < it_hi) issue(it_lo + 2, lds2);
+      if (it_lo + 3 < it_hi) issue(it_lo + 3, lds3);
+      wait_ahead(min(it_lo + 3, it_hi - 1) - it_lo);
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int it = it_lo; it < it_hi; it += 5) {    // five stages per trip: buffer roles are compile-time
+      stage(it, lds0, lds4);
+      if (it + 1 >= it_hi) break;
+      stage(it + 1, lds1, lds0);
+      if (it + 2 >= it_hi) break;
+      stage(it + 2, lds2, lds1);
+      if (it + 3 >= it_hi) break;
+      stage(it + 3, lds3, lds2);
+      if (it + 4 >= it_hi) break;
+      stage(it + 4, lds4, lds3);
     }
   } else {
     // step t: issue the DMA of step t+2, run the MFMAs of step t, then wait until only those NDMA newest DMAs are
@@ -618,7 +748,8 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   constexpr int PH = FORM == FORM_CONVT ? 4 : 1;
   const int tiles = ((M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * PH;
   const int ntaps = FORM == FORM_CONV ? 16 : (FORM == FORM_CONVT ? 4 : p.ks * p.ks);
-  const int niter = ntaps * ((p.K + BK - 1) / BK);
+  constexpr int BKS = NBUF >= 5 ? 32 : BK;           // the ring pipeline walks half steps
+  const int niter = ntaps * ((p.K + BKS - 1) / BKS);
   const size_t npix = (size_t)M * PH;
   // small-M layers (bottleneck of the U-Net) cannot fill 256 CUs with output tiles: split the reduction
   p.ksplit = 1;
@@ -640,11 +771,11 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   const bool db_rows = want_db && ws && ws_bytes >= dbws_bytes + 16;
   const size_t slab_room = db_rows ? ws_bytes - dbws_bytes - 16 : ws_bytes;
   // (below ~1.2 work-groups per CU a second k-slice per tile beats the idle half of the chip: U_3 dgrad 102 -> 77 us)
-  if (ws && tiles < 300 && niter >= 4) {
+  if (ws && tiles < 300 && niter >= 4 * BK / BKS) {
     int want = (512 + tiles - 1) / tiles;
     const size_t slab = npix * p.N * sizeof(float);
     want = (int)std::min<size_t>((size_t)want, slab_room / slab);
-    want = std::min(want, niter / 8);   // >= 8 K-steps per work-group: shorter slices are all prologue + slab traffic (2x2 levels: 43 -> 24 us)
+    want = std::min(want, niter / (8 * BK / BKS));   // >= 8 K-steps per work-group: shorter slices are all prologue + slab traffic (2x2 levels: 43 -> 24 us)
     if (want >= 2) {
       const int per = (niter + want - 1) / want;
       p.ksplit = (niter + per - 1) / per;
@@ -701,6 +832,20 @@ int dispatch(const gct2_ctx& c, int form, int epi, const TapGemmParams& p, hipSt
                                                       : launch<T, FORM_CONV, 256, 256, EPI_MASK, 2, 128>(c, p, s);
     return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 256, EPI_BIAS_ACT, 2, 128>(c, p, s)
                                : launch<T, FORM_CONVT, 256, 256, EPI_MASK, 2, 128>(c, p, s);
+  }
+  // 256 x 256 tile with the five-stage ring (four stages in flight, counted vmcnt across raw barriers), one work-group per CU;
+  // variant 8: the same with the DMA pieces of stage s+4 issued between the MFMA groups of stage s
+  if (g_tapgemm_variant == 7 && p.N >= 256) {
+    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 256, EPI_BIAS_ACT, 5, 128>(c, p, s)
+                                                      : launch<T, FORM_CONV, 256, 256, EPI_MASK, 5, 128>(c, p, s);
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 256, EPI_BIAS_ACT, 5, 128>(c, p, s)
+                               : launch<T, FORM_CONVT, 256, 256, EPI_MASK, 5, 128>(c, p, s);
+  }
+  if (g_tapgemm_variant == 8 && p.N >= 256) {
+    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 256, EPI_BIAS_ACT, 6, 128>(c, p, s)
+                                                      : launch<T, FORM_CONV, 256, 256, EPI_MASK, 6, 128>(c, p, s);
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 256, EPI_BIAS_ACT, 6, 128>(c, p, s)
+                               : launch<T, FORM_CONVT, 256, 256, EPI_MASK, 6, 128>(c, p, s);
   }
   if (g_tapgemm_variant == 1) {
     if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 1>(c, p, s)

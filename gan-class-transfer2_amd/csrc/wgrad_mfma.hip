@@ -350,18 +350,23 @@ __device__ __forceinline__ unsigned long long wg_stamp() {
 #else
 #define WG_STAMP(k)
 #endif
-template <typename T>
+// NST = stage buffers of the ring (4: 128 KiB, three stages = 96 KiB in flight; 5: all 160 KiB of the CU's LDS, four stages = 128 KiB
+// in flight).  The loop is bound by the latency of the staging requests that miss the XCD's L2 (a stage takes
+// about (loaded miss latency) / (stages in flight)), so the deeper ring is the default.
+template <typename T, int NST>
 __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
 #ifdef GCT2_STAMP
   unsigned long long st[4];
   WG_STAMP(0);
 #endif
+  static_assert(NST == 4 || NST == 5, "four or five stage buffers");
   constexpr int IMG = 32 * 256;                                   // one T image of a stage: 32 r-rows x 128 columns
   constexpr int NDMA = 4;                                         // DMA instructions per wave per stage (one piece of each image)
   __shared__ __attribute__((aligned(16))) char lds0[4 * IMG];
   __shared__ __attribute__((aligned(16))) char lds1[4 * IMG];
   __shared__ __attribute__((aligned(16))) char lds2[4 * IMG];
   __shared__ __attribute__((aligned(16))) char lds3[4 * IMG];
+  __shared__ __attribute__((aligned(16))) char lds4[NST == 5 ? 4 * IMG : 16];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -452,34 +457,53 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
     }
   };
 
-  // stage s: issue s+3, multiply s, wait until only the DMAs of the stages beyond s+1 are outstanding, barrier.
-  // `live` is always true (rsplit >= 1) but opaque to hipcc: with the multiply unconditional the four unrolled stages are merged
+  // stage s: issue s+NST-1, multiply s, wait until only the DMAs of the stages beyond s+1 are outstanding, barrier.
+  // `live` is always true (rsplit >= 1) but opaque to hipcc: with the multiply unconditional the unrolled stages are merged
   // into one region whose live ranges no longer fit (256 VGPRs + 440 spilled, 10x slower; behind the guard: 176 VGPRs, no spill).
   const bool live = p.rsplit > 0;
-  auto stage = [&](int st, const char* cur, char* tgt) {
-    if (st + 3 < st_hi) issue(st + 3, tgt);
-    if (live) compute(cur);
-    if (st + 3 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
-    else if (st + 2 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
+  // wait until at most `ahead` whole stages (the youngest ones) are still in flight
+  auto wait_ahead = [&](int ahead) {
+    if (ahead >= 3) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(3 * NDMA));
+    else if (ahead == 2) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
+    else if (ahead == 1) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
     else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
+  };
+  auto stage = [&](int st, const char* cur, char* tgt) {
+    if (st + NST - 1 < st_hi) issue(st + NST - 1, tgt);
+    if (live) compute(cur);
+    // stages issued so far: up to min(st + NST - 1, st_hi - 1); stage st + 1 must have landed: those beyond it may stay in flight
+    wait_ahead(min(st + NST - 1, st_hi - 1) - (st + 1));
     __builtin_amdgcn_s_barrier();
   };
   WG_STAMP(1);
   issue(st_lo, lds0);
   if (st_lo + 1 < st_hi) issue(st_lo + 1, lds1);
   if (st_lo + 2 < st_hi) issue(st_lo + 2, lds2);
-  if (st_lo + 2 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
-  else if (st_lo + 1 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
-  else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
+  if (NST == 5 && st_lo + 3 < st_hi) issue(st_lo + 3, lds3);
+  wait_ahead(min(st_lo + NST - 2, st_hi - 1) - st_lo);             // stage st_lo has landed
   __builtin_amdgcn_s_barrier();
-  for (int st = st_lo; st < st_hi; st += 4) {                     // four stages per trip: buffer roles are compile-time
-    stage(st, lds0, lds3);
-    if (st + 1 >= st_hi) break;
-    stage(st + 1, lds1, lds0);
-    if (st + 2 >= st_hi) break;
-    stage(st + 2, lds2, lds1);
-    if (st + 3 >= st_hi) break;
-    stage(st + 3, lds3, lds2);
+  if constexpr (NST == 4) {
+    for (int st = st_lo; st < st_hi; st += 4) {                   // NST stages per trip: buffer roles are compile-time
+      stage(st, lds0, lds3);
+      if (st + 1 >= st_hi) break;
+      stage(st + 1, lds1, lds0);
+      if (st + 2 >= st_hi) break;
+      stage(st + 2, lds2, lds1);
+      if (st + 3 >= st_hi) break;
+      stage(st + 3, lds3, lds2);
+    }
+  } else {
+    for (int st = st_lo; st < st_hi; st += 5) {
+      stage(st, lds0, lds4);
+      if (st + 1 >= st_hi) break;
+      stage(st + 1, lds1, lds0);
+      if (st + 2 >= st_hi) break;
+      stage(st + 2, lds2, lds1);
+      if (st + 3 >= st_hi) break;
+      stage(st + 3, lds3, lds2);
+      if (st + 4 >= st_hi) break;
+      stage(st + 4, lds4, lds3);
+    }
   }
   WG_STAMP(2);
   float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
@@ -631,8 +655,13 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
     if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad_kernel<__bf16, 2, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<_Float16, 2, true>), grid, dim3(256), 0, s, p);
   } else if (big_tile && g_wgrad_pipe) {
-    if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256p_kernel<__bf16>, grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL(wgrad256p_kernel<_Float16>, grid, dim3(512), 0, s, p);
+    if (c.wgrad_ring == 5) {
+      if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad256p_kernel<__bf16, 5>), grid, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((wgrad256p_kernel<_Float16, 5>), grid, dim3(512), 0, s, p);
+    } else {
+      if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad256p_kernel<__bf16, 4>), grid, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((wgrad256p_kernel<_Float16, 4>), grid, dim3(512), 0, s, p);
+    }
   } else if (big_tile) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256_kernel<__bf16>, grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL(wgrad256_kernel<_Float16>, grid, dim3(512), 0, s, p);

@@ -248,9 +248,12 @@ int gct2_diffusion_mix(int dtype, const float* x_theta, const float* eps_theta, 
  *   GCT2_SAMPLE_SCALED_EPS (predict_scaled_epsilon) eps_theta = pred / sqrt(1-a);  x_theta = (fake - pred) / sqrt(a)
  *   GCT2_SAMPLE_ODE        (ordinary_differential_equation)
  *                          x_theta = (pred sqrt(1-a) - fake sqrt(1-a1)) / (sqrt(a1) sqrt(1-a) - sqrt(a) sqrt(1-a1));
- *                          eps_theta is NOT touched (the reference never updates it in this branch; may be NULL). */
+ *                          eps_theta is NOT touched (the reference never updates it in this branch; may be NULL).
+ */
 enum { GCT2_SAMPLE_X = 0, GCT2_SAMPLE_EPS = 1, GCT2_SAMPLE_SCALED_EPS = 2, GCT2_SAMPLE_ODE = 3 };
-int gct2_diffusion_update(int mode, const float* pred, const float* fake, float alpha, float alpha_prev, float* x_theta,
+/* alpha / alpha_prev are DOUBLES: the reference forms every coefficient (and the ODE denominator, a difference of nearly equal
+ * products at steps = 200) from Python floats and only then multiplies fp32 tensors by it; the library does the same on the host. */
+int gct2_diffusion_update(int mode, const float* pred, const float* fake, double alpha, double alpha_prev, float* x_theta,
                           float* eps_theta, size_t n, void* stream);
 /* the four inputs of the reverse pass built from one inverted noise image eps [H,W,C] (train.py:416-431): out [4,H,W,C] =
  * eps | nearest-upsample x4 of avg_pool2d(eps, 4, 4) | tf.roll by 1 along H and W | per-pixel nearest of the K entries of

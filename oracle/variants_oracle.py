@@ -119,25 +119,38 @@ def init_variant_params(cfg, block_depth, residual, concat, seed=1234):
     return params
 
 
-def variant_forward_backward(params, x0, cfg, block_depth, residual, concat, dpred_fn: Callable):
-    """forward through the nested structure recording a tape; dpred_fn(pred) -> (loss, dpred); returns (loss, pred, grads)."""
+def variant_forward_backward(params, x0, cfg, block_depth, residual, concat, dpred_fn: Callable, operand_round: Optional[str] = None,
+                             round_head: bool = False):
+    """forward through the nested structure recording a tape; dpred_fn(pred) -> (loss, dpred); returns (loss, pred, grads).
+
+    operand_round in {None, 'bf16', 'f16'} models what variants.VariantEngine keeps in HBM in a 16-bit mode (the same model as
+    denoiser_oracle.unet_forward / unet_backward): convolution / projection kernels are consumed as rounded operands (the Dense(3)
+    kernel stays fp32 in the forward pass), every stored activation is rounded once, every stored activation gradient is rounded
+    once, and a gradient that is the SUM of two stored tensors (skip + module path of Residual, gct2_add) is rounded again;
+    accumulation stays in the array dtype.  round_head (the f16 policy): the Dense(3) output and the gradient entering it are fp16."""
+    rnd = O._rounder(operand_round)
     tape: List[Callable[[], None]] = []
     grads: Dict[str, np.ndarray] = {}
+    wq = {k: (rnd(v) if k.endswith(".w") and k != "dense.w" else v) for k, v in params.items()}
 
     class V:   # a value with its gradient slot
         def __init__(self, val):
             self.val, self.grad = val, np.zeros_like(val)
 
+        def add_grad(self, c):
+            """one more stored gradient tensor flows in: stored rounded, and the running sum is what the add kernel stores"""
+            self.grad = rnd(self.grad + rnd(c))
+
     def conv(kind, name, v: V) -> V:
-        w, b = params[name + ".w"], params[name + ".b"]
+        w, b = wq[name + ".w"], params[name + ".b"]
         fwd = {"down": O.conv4s2_fwd, "up": O.convT4s2_fwd, "c3": conv_s1_fwd}[kind]
         bwd = {"down": O.conv4s2_bwd, "up": O.convT4s2_bwd, "c3": conv_s1_bwd}[kind]
-        out = V(np.maximum(fwd(v.val, w, b), 0))                              # activation='relu' (train.py:134,150,163)
+        out = V(rnd(np.maximum(fwd(v.val, w, b), 0)))                         # activation='relu' (train.py:134,150,163)
 
         def back():
-            dz = out.grad * (out.val > 0)
+            dz = rnd(out.grad * (out.val > 0))
             dx, grads[name + ".w"], grads[name + ".b"] = bwd(v.val, w, dz)
-            v.grad += dx
+            v.add_grad(dx)
         tape.append(back)
         return out
 
@@ -153,13 +166,13 @@ def variant_forward_backward(params, x0, cfg, block_depth, residual, concat, dpr
         h = block(f"blkB{i}", h)
         h = conv("up", f"U{i}", h)
         if residual:                                                           # train.py:111-112
-            wd = params[f"res{i}.dense.w"]
-            out = V(v.val + h.val @ wd)
+            wd = wq[f"res{i}.dense.w"]
+            out = V(rnd(v.val + rnd(h.val @ wd)))
 
             def back():
                 grads[f"res{i}.dense.w"] = h.val.reshape(-1, h.val.shape[-1]).T @ out.grad.reshape(-1, out.grad.shape[-1])
-                h.grad += out.grad @ wd.T
-                v.grad += out.grad
+                h.add_grad(out.grad @ wd.T)
+                v.add_grad(out.grad)
             tape.append(back)
             return out
         if concat:                                                             # train.py:113-119
@@ -167,32 +180,40 @@ def variant_forward_backward(params, x0, cfg, block_depth, residual, concat, dpr
             cm = h.val.shape[-1]
 
             def back():
-                h.grad += out.grad[..., :cm]
-                v.grad += out.grad[..., cm:]
+                h.add_grad(out.grad[..., :cm])
+                v.add_grad(out.grad[..., cm:])
             tape.append(back)
             return out
         return h                                                               # train.py:120-121
 
-    vin = V(x0)
+    vin = V(rnd(x0))
     h = block("blkTopA", vin)
     h = level(0, h)
     h = block("blkTopB", h)
     pred = h.val @ params["dense.w"] + params["dense.b"]                      # Dense(3), linear (train.py:198-202)
+    if round_head:
+        pred = O.round_f16(pred)
     loss, dpred = dpred_fn(pred)
+    if round_head:
+        dpred = O.round_f16(dpred)
     grads["dense.w"] = h.val.reshape(-1, h.val.shape[-1]).T @ dpred.reshape(-1, 3)
     grads["dense.b"] = dpred.reshape(-1, 3).sum(0)
-    h.grad += dpred @ params["dense.w"].T
+    h.add_grad(rnd(dpred) @ rnd(params["dense.w"]).T)                        # the input gradient runs through the 1 x 1 convolution entry
     for back in reversed(tape):
         back()
     return loss, pred, grads
 
 
-def variant_trainer_step(params, x, t_int, eps, cfg, block_depth=0, residual=False, concat=True, objective: Optional[dict] = None):
-    """Trainer.call (train.py:223-272) on the variant network: (loss, pred, grads)."""
-    noised = O.noise_image(x, t_int, eps, cfg.steps)
+def variant_trainer_step(params, x, t_int, eps, cfg, block_depth=0, residual=False, concat=True, objective: Optional[dict] = None,
+                         operand_round: Optional[str] = None, loss_scale: float = 1.0):
+    """Trainer.call (train.py:223-272) on the variant network: (loss, pred, grads).  operand_round: see variant_forward_backward;
+    'f16' also takes the fp16 noising arithmetic and the two fp16 points of the Dense head (denoiser_oracle.trainer_step), and
+    the returned gradients are the SCALED ones (loss_scale, train.py:82-83)."""
+    f16 = operand_round == "f16"
+    noised = O.noise_image_f16(x, t_int, eps, cfg.steps).astype(x.dtype) if f16 else O.noise_image(x, t_int, eps, cfg.steps)
     target, w = O.objective_terms(x, t_int, eps, cfg.steps, **(objective or {}))
 
     def dpred_fn(pred):
         diff = pred * w - target
-        return float(np.mean(diff ** 2)), (2.0 / diff.size) * diff * w
-    return variant_forward_backward(params, noised, cfg, block_depth, residual, concat, dpred_fn)
+        return float(np.mean(diff ** 2)), (2.0 * loss_scale / diff.size) * diff * w
+    return variant_forward_backward(params, noised, cfg, block_depth, residual, concat, dpred_fn, operand_round, round_head=f16)

@@ -19,7 +19,9 @@ CASES = {   # name: (dtype code, topology, steps, tolerance on the final paramet
     "bf16": (1, dict(size=16, pixel_size=128, max_size=256, octaves=2), 2, 2e-3, 200_000),
     # five steps without warm-up at a learning rate that moves the biases far above any tolerance, so that a
     # replica computing with stale fp32-read parameters (biases, Dense(3)) shows up in the replicas' own views and predictions
-    "bf16_nowarm": (1, dict(size=16, pixel_size=128, max_size=256, octaves=2), 5, 2e-3, 200_000),
+    # (tolerance: Adam normalises the gradient, so after five full-rate steps the half-batch / full-batch summation orders of the
+    # bf16 gradients show up at the 4e-3 level in the smallest bias vector; the replicas among themselves stay bit-identical)
+    "bf16_nowarm": (1, dict(size=16, pixel_size=128, max_size=256, octaves=2), 5, 1e-2, 200_000),
 }
 ENGINE_KW = {"bf16_nowarm": dict(base_lr=1e-3, warm_up=0)}
 

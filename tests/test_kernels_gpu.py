@@ -311,11 +311,16 @@ def test_splitk_bottleneck_layers(gpu, dt, order):
         set_ws(None)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6])
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 12, 20, 72, 136), (3, 2, 2, 256, 64), (1, 32, 32, 128, 256), (1, 8, 12, 264, 328)])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 12, 20, 72, 136), (3, 2, 2, 256, 64), (1, 32, 32, 128, 256), (1, 8, 12, 264, 328),
+                                   (2, 16, 16, 512, 256)])
 def test_tapgemm_tile_variants(gpu, variant, shape):
     """every tile variant on every use: 1/2 = 128x128 (1/2 LDS buffers), 3 = 256x128 8-wave 3-buffer (counted vmcnt),
-    5 = 256x128 single buffer, 6 = 256x256 with 128x64 wave tiles (taken where N >= 256, else falls through to the default)."""
+    5 = 256x128 single buffer, 6 = 256x256 with 128x64 wave tiles, 7 = 256x256 with the five-stage ring (four 32-channel stages in
+    flight, counted vmcnt across raw barriers; r03), 8 = 7 with the DMA pieces issued between the MFMA groups - 6, 7 and 8 are taken
+    where N >= 256, else the call falls through to the default.
+    The last shape gives the ring 16 (Conv2DTranspose forward: 4 taps x 512 / 32) to 256 stages per work-group: several trips of
+    its five-buffer loop, every tail length of the ragged shapes before it."""
     B, H, W, Cin, Cout = shape
     dt = BF16
     L = lib()
@@ -393,6 +398,60 @@ def test_dgrad_fused_bias_gradients(gpu, dt, shape, use_ws):
         assert np.abs(db2.cpu().numpy() - cst[split:]).max() <= tol * np.abs(contrib_t).reshape(-1, Cin).sum(0).max()
     finally:
         set_ws(None)
+
+
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 256, 64), (1, 16, 16, 328, 72), (8, 4, 4, 512, 256)])
+def test_ring_tile_dgrad_epilogues(gpu, shape, use_ws):
+    """the 256 x 256 ring tile (variant 7) through the input-gradient epilogues: ReLU mask, accumulation into a running buffer, the
+    fused bias gradients (partial rows in the workspace / atomics without one), split-K slabs + finalize where the workspace allows
+    it (third shape: 2 x 2 = 4 tiles per form) - against the oracle."""
+    B, H, W, Cin, Cout = shape
+    dt, L = BF16, lib()
+    ws = torch.empty(32 << 18, dtype=torch.float32, device=gpu)
+    set_ws(ws if use_ws else None)
+    set_tuning(7)
+    try:
+        rng = np.random.default_rng(23)
+        x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+        split = (Cin // 2) // 8 * 8
+        w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+        dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+        prev = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+        contrib = O.conv4s2_bwd(x, w, dz)[0] * (x > 0)
+        dxd, dzd, wd, xd = dev(prev, dt, gpu), dev(dz, dt, gpu), dev(w, dt, gpu), dev(x, dt, gpu)
+        db = torch.full((split,), 3.0, device=gpu); db2 = torch.full((Cin - split,), -1.0, device=gpu)
+        L.call("gct2_conv4s2_dgrad", ctx(), dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin,
+               dxd.data_ptr(), Cin, B, H, W, Cin, Cout, 1, db.data_ptr(), split, db2.data_ptr(), 3, stream())
+        torch.cuda.synchronize()
+        cs = contrib.reshape(-1, Cin).sum(0)
+        scale = np.abs(contrib).reshape(-1, Cin).sum(0).max()
+        assert np.abs(db.cpu().numpy() - 3.0 - cs[:split]).max() <= 2e-3 * scale
+        assert np.abs(db2.cpu().numpy() + 1.0 - cs[split:]).max() <= 2e-3 * scale
+        assert rel_l2(dxd.double().cpu().numpy(), contrib + prev) <= TOL_OUT[dt]
+        wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+        dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+        contrib_t = O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)
+        dxt, dztd, wtd = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu), dev(dzt, dt, gpu), dev(wt, dt, gpu)
+        L.call("gct2_convT4s2_dgrad", ctx(), dt, dztd.data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin,
+               dxt.data_ptr(), Cin, B, H, W, Cin, Cout, 0, db.data_ptr(), split, db2.data_ptr(), 0, stream())
+        torch.cuda.synchronize()
+        cst = contrib_t.reshape(-1, Cin).sum(0)
+        scale_t = np.abs(contrib_t).reshape(-1, Cin).sum(0).max()
+        assert np.abs(db.cpu().numpy() - cst[:split]).max() <= 2e-3 * scale_t
+        assert np.abs(db2.cpu().numpy() - cst[split:]).max() <= 2e-3 * scale_t
+        assert rel_l2(dxt.double().cpu().numpy(), contrib_t) <= TOL_OUT[dt]
+        # bit-reproducible (ordered partial rows / slabs) when a workspace is there: the race screen of the ring's hand-placed waits
+        if use_ws:
+            dxt2 = torch.zeros_like(dxt); db_a, db2_a = db.clone(), db2.clone()
+            for _ in range(3):
+                L.call("gct2_convT4s2_dgrad", ctx(), dt, dztd.data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin,
+                       dxt2.data_ptr(), Cin, B, H, W, Cin, Cout, 0, db.data_ptr(), split, db2.data_ptr(), 0, stream())
+                torch.cuda.synchronize()
+                assert torch.equal(dxt2, dxt) and torch.equal(db, db_a) and torch.equal(db2, db2_a)
+    finally:
+        set_ws(None)
+        set_tuning(0)
 
 
 def test_mfma_and_direct_paths_agree(gpu):
