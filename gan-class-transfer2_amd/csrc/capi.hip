@@ -101,8 +101,8 @@ int run_dgrad(const gct2_ctx& c, int dtype, int form, TapGemmParams p, size_t ou
   return (db || db2) ? sums(1.f) : GCT2_OK;
 }
 int run_wgrad(const gct2_ctx& c, int dtype, const WgradParams& p, void* stream, WgradSlabs* defer = nullptr) {
-  if (defer) *defer = WgradSlabs{nullptr, 0, 0};
   if (!c.force_direct && wgrad_mfma_supported(dtype, p)) return wgrad_mfma(c, dtype, p, S(stream), defer);
+  if (defer) *defer = WgradSlabs{nullptr, 0, 0};
   return wgrad_direct(dtype, p, S(stream));
 }
 // bias gradient of a weight-gradient call: db (+)= column sums of dz (atomics: an overwritten target starts from zero)
@@ -113,10 +113,21 @@ int wgrad_db(int dtype, const void* dz, int lddz, float* db, size_t pixels, int 
 // Keras Adam right behind a weight-gradient launch, on the same stream (gct2_adam_args): the layer's parameters [weights | pad |
 // bias] are one contiguous range of the caller's arenas; the weight gradient comes from the slabs the launch left (never
 // materialised) or from dw (written, not accumulated: no zeroing), the bias gradient from g (written by the dgrad launches); nothing is zeroed
-int adam_after_wgrad(const gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& sl, void* stream) {
+int check_adam_args(const gct2_adam_args* a, const float* dw, size_t nw) {
   if (!a->p || !a->m || !a->v) return gct2_fail(GCT2_EINVAL, "wgrad + adam: null arena pointers");
   if (a->n < nw || ((uintptr_t)a->p | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)dw) % 16)
     return gct2_fail(GCT2_EINVAL, "wgrad + adam: range shorter than the weight tensor or misaligned");
+  return GCT2_OK;
+}
+int adam_after_wgrad(const gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& sl, void* stream) {
+  if (sl.adam_done) {
+    // the weight-gradient launch updated the kernel in its epilogue: what is left of the layer's range is the bias (behind the
+    // kernel, gradient in the arena behind dw)
+    if (a->n == nw) return GCT2_OK;
+    const size_t es = a->shadow_dtype == GCT2_F32 ? 4 : 2;
+    return pw_adam(a->p + nw, a->m + nw, a->v + nw, dw + nw, a->shadow ? (char*)a->shadow + nw * es : nullptr, a->shadow_dtype, a->n - nw,
+                   a->alpha, a->beta1, a->beta2, a->eps, a->grad_mul, nullptr, 0, S(stream));
+  }
   return pw_adam(a->p, a->m, a->v, dw, a->shadow, a->shadow_dtype, a->n, a->alpha, a->beta1, a->beta2, a->eps, a->grad_mul, nullptr, 0,
                  S(stream), sl.base, sl.nslab, sl.stride, sl.nslab ? nw : 0);
 }
@@ -165,11 +176,12 @@ int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   ctx->wgrad_pipe = (wv & 0x40) ? 0 : 1;
   ctx->wgrad_target = (wv & 0x10) ? 512 : 256;
   ctx->wgrad_slab_max = (wv & 0x20) ? 64 : 24;
-  ctx->wgrad_ring = (wv & 0x80) ? 5 : 4;
+  ctx->wgrad_ring = (wv & 0x80) ? 4 : 5;
   ctx->halo_mode = (v >> 24) & 3;
   ctx->xcd_order = (v >> 26) & 3;
   ctx->wgrad_split = (v >> 28) & 7;
-  ctx->halo_il = (int)(((unsigned)v >> 31) & 1u);
+  ctx->halo_il = (int)(((unsigned)v >> 31) & 1u) ? 0 : 1;
+  ctx->wgrad_fuse_adam = (v & 0x100) ? 1 : 0;
   return GCT2_OK;
 }
 int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes) {
@@ -229,6 +241,8 @@ int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const v
   WgradParams p{x, ldx, dz, lddz, dw, B, H / 2, W / 2, Cin, Cout, 1};
   p.accumulate = accumulate ? 1 : 0;
   WgradSlabs sl{nullptr, 0, 0};
+  if (adam) if (int e = check_adam_args(adam, dw, (size_t)16 * Cin * Cout)) return e;
+  sl.want_adam = adam;
   if (!c.force_direct && rgb_wgrad_supported(dtype, p)) {
     if (int e = rgb_wgrad(c, dtype, p, S(stream), adam ? &sl : nullptr)) return e;
   } else if (int e = run_wgrad(c, dtype, p, stream, adam ? &sl : nullptr)) return e;
@@ -282,6 +296,8 @@ int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const 
   WgradParams p{dz, lddz, x, ldx, dw, B, H, W, Cout, Cin, 1};
   p.accumulate = accumulate ? 1 : 0;
   WgradSlabs sl{nullptr, 0, 0};
+  if (adam) if (int e = check_adam_args(adam, dw, (size_t)16 * Cin * Cout)) return e;
+  sl.want_adam = adam;
   if (int e = run_wgrad(C(ctx), dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)
     if (int e = wgrad_db(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, accumulate, stream)) return e;

@@ -23,9 +23,10 @@ struct gct2_ctx {
   float* wws = nullptr; size_t wws_bytes = 0;      // weight-gradient slabs (falls back to ws)
   int tap_variant = 0;                             // forward / input-gradient tile (0 = automatic)
   int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 24;
-  int wgrad_ring = 4;                              // stage buffers of the 256 x 256 weight-gradient pipeline (4 or 5)
+  int wgrad_ring = 5;                              // stage buffers of the 256 x 256 weight-gradient pipeline (5 = all of the LDS; 4: A/B)
+  int wgrad_fuse_adam = 0;                         // 1: one-owner weight-gradient tiles apply the fused optimizer step in their epilogue (measured +70 us per step: off)
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
-  int halo_il = 0;                                 // halo kernel: DMA pieces interleaved with the MFMA groups (A/B knob)
+  int halo_il = 1;                                 // halo kernel: DMA pieces interleaved with the MFMA groups (0: in front of them, A/B)
   int xcd_order = 0;                               // tile -> XCD order: 0 = automatic, 1 = m-tile bands, 2 = weight slices
   int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile: 0 = automatic, v: 2^(v-1)
   int force_direct = 0;
@@ -235,6 +236,22 @@ inline void zero_overwritten_db(const TapGemmParams& p, hipStream_t s) {
   if (p.db2 && !(p.db_acc & 2) && p.N > p.db_split) (void)hipMemsetAsync(p.db2, 0, (size_t)(p.N - p.db_split) * sizeof(float), s);
 }
 
+// Keras ResourceApplyAdam on one element (epsilon added to sqrt(v)); ONE definition for the optimizer kernel and
+// for the weight-gradient epilogues that apply it in place, so that both round identically (fused == separate, bit for bit)
+__device__ __forceinline__ void adam_keras_update(float& p, float& m, float& v, float g, float alpha, float b1, float ob1, float b2,
+                                                  float ob2, float eps) {
+  m = b1 * m + ob1 * g;
+  v = b2 * v + ob2 * g * g;
+  p = p - alpha * m / (sqrtf(v) + eps);
+}
+// optimizer step fused into the epilogue of a weight-gradient launch whose tiles have ONE owner (no split of the pixel range):
+// the gradient never leaves the registers - no write and no re-read of dW (8 B per parameter) and no separate Adam launch
+struct AdamFuse {
+  float* p = nullptr; float* m = nullptr; float* v = nullptr;   // fp32 arenas at the start of the kernel tensor (p == null: off)
+  void* shadow = nullptr;                                        // compute-dtype copy of p (same element type as the operands) or null
+  float alpha = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gmul = 1.f;
+};
+
 // wgrad: dw[tap][cb][cs] += sum_r big[pix_big(r,tap)][cb] * small[r][cs], r over the SMALL grid.
 struct WgradParams {
   const void* big; int ldbig;     // tensor on the BIG grid (2Hs x 2Ws), Cb channels
@@ -245,10 +262,12 @@ struct WgradParams {
   float* ws;                      // partial-tile slabs [rsplit][16*Cb][Cs] in the registered workspace, or null (atomics)
   int accumulate;                 // 1: dw += result (caller keeps a running / pre-zeroed gradient); 0: dw = result
   int ks = 0;                     // 0: the 4x4 / stride-2 layers; odd ks: 'same' stride-1 convolution (both tensors on one grid, ks*ks taps)
+  AdamFuse adam;                  // one-owner tiles only (filled by wgrad_mfma when the caller asked for the fused optimizer step)
 #ifdef GCT2_STAMP
   unsigned long long* stamps = nullptr;   // diagnostic build: phase stamps of one wave per work-group (gct2_ctx_set_stamp_buffer)
 #endif
 };
 // wgrad_mfma(): when `defer` is non-null and the launch left its result as workspace slabs, the slab reduction is NOT launched and
 // the slabs are described here (the caller folds them into the optimizer read); nslab = 0 means dw holds the gradient
-struct WgradSlabs { const float* base; int nslab; size_t stride; };
+struct WgradSlabs { const float* base; int nslab; size_t stride; bool adam_done = false;   // adam_done: the launch applied Adam to the kernel itself
+                    const gct2_adam_args* want_adam = nullptr; };                            // in: the caller's fused-optimizer request

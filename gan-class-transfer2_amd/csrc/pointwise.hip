@@ -841,10 +841,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
             vv = __builtin_nontemporal_load(reinterpret_cast<f32x4_t*>(v) + i);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const float gg = gv[k] * inv_scale;
-      mv[k] = b1 * mv[k] + ob1 * gg;
-      vv[k] = b2 * vv[k] + ob2 * gg * gg;
-      pv[k] = pv[k] - alpha * mv[k] / (sqrtf(vv[k]) + eps);
+      float pp = pv[k], mm = mv[k], v1 = vv[k];
+      adam_keras_update(pp, mm, v1, gv[k] * inv_scale, alpha, b1, ob1, b2, ob2, eps);
+      pv[k] = pp; mv[k] = mm; vv[k] = v1;
     }
     __builtin_nontemporal_store(pv, reinterpret_cast<f32x4_t*>(p) + i);
     __builtin_nontemporal_store(mv, reinterpret_cast<f32x4_t*>(m) + i);
@@ -864,8 +863,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const float gg = g[i] * inv_scale;
     if (zero_grad) g[i] = 0.f;
     if (!skip) {
-      const float mm = b1 * m[i] + ob1 * gg, vv = b2 * v[i] + ob2 * gg * gg;
-      const float pp = p[i] - alpha * mm / (sqrtf(vv) + eps);
+      float mm = m[i], vv = v[i], pp = p[i];
+      adam_keras_update(pp, mm, vv, gg, alpha, b1, ob1, b2, ob2, eps);
       m[i] = mm; v[i] = vv; p[i] = pp;
       if (HAS_SHADOW) shadow[i] = from_f32<S>(pp);
     }

@@ -175,6 +175,28 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void wgrad_kernel(WgradPara
       if (col >= Cs) continue;                         // Cs is a multiple of 8: a 4-column group is inside or outside as a whole
       float* q = out + (size_t)row * Cs + col;
       if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
+      else if (mode == 1 && p.adam.p) {
+        // the tile has ONE owner and the caller wants the optimizer step: Keras Adam right here, on the accumulators - dW is neither
+        // written nor re-read (8 B per parameter less), p / m / v / the operand copy are updated in place (streaming accesses)
+        const size_t e = (size_t)row * Cs + col;
+        f32x4_t pv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p.adam.p + e));
+        f32x4_t mv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p.adam.m + e));
+        f32x4_t vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p.adam.v + e));
+        const float ob1 = 1.f - p.adam.b1, ob2 = 1.f - p.adam.b2;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float pp = pv[r], mm = mv[r], v1 = vv[r];
+          adam_keras_update(pp, mm, v1, acc[i][j][r] * p.adam.gmul, p.adam.alpha, p.adam.b1, ob1, p.adam.b2, ob2, p.adam.eps);
+          pv[r] = pp; mv[r] = mm; vv[r] = v1;
+        }
+        __builtin_nontemporal_store(pv, reinterpret_cast<f32x4_t*>(p.adam.p + e));
+        __builtin_nontemporal_store(mv, reinterpret_cast<f32x4_t*>(p.adam.m + e));
+        __builtin_nontemporal_store(vv, reinterpret_cast<f32x4_t*>(p.adam.v + e));
+        if (p.adam.shadow) {
+          const u32x2_t o = {pack2<T>(pv[0], pv[1]), pack2<T>(pv[2], pv[3])};
+          *reinterpret_cast<u32x2_t*>(reinterpret_cast<T*>(p.adam.shadow) + e) = o;
+        }
+      }
       else if (mode == 1) { if (p.accumulate) *reinterpret_cast<f32x4_t*>(q) += acc[i][j]; else *reinterpret_cast<f32x4_t*>(q) = acc[i][j]; }
       else {
 #pragma unroll
@@ -308,6 +330,139 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(WgradParams p) {
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int row = gc0 + wm * 128 + i * 16 + (elane & 15);
+    if (row >= GC) continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int col = cs0 + wn * 64 + j * 16 + 4 * (elane >> 4);
+      if (col >= Cs) continue;
+      float* q = out + (size_t)row * Cs + col;
+      if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
+      else if (mode == 1) { if (p.accumulate) *reinterpret_cast<f32x4_t*>(q) += acc[i][j]; else *reinterpret_cast<f32x4_t*>(q) = acc[i][j]; }
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) atomicAdd(q + r, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+// ---- 256 (gc) x 128 (cs) tile, 8 waves of 64 x 64, ONE 48-KiB buffer, TWO work-groups per CU (r03) -------------------------------
+// The structure that measures best for the forward / input-gradient GEMMs (tapgemm_kernel<..., 256, 128, ..., NBUF = 1>): no
+// pipelining inside a work-group - issue, wait, multiply - and a second, independent work-group on the CU whose multiplies cover
+// the first one's wait.  87 FLOP per staged byte (128 x 128: 65; 256 x 256: 131).  One-work-group-per-CU pipelines, however deep,
+// measured 15-30 % slower than this arrangement on the tap GEMMs (profiles/r03_layer_variants.txt).
+template <typename T>
+__global__ __launch_bounds__(512, 4) void wgrad2x_kernel(WgradParams p) {
+  constexpr int IMG = 64 * 256;                                   // [big gc 0..127 | big gc 128..255 | small cs 0..127]
+  __shared__ __attribute__((aligned(16))) char lds0[3 * IMG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;                        // 4 (gc) x 2 (cs) waves of 64 x 64
+  const int Hs = p.Hs, Ws = p.Ws, Cb = p.Cb, Cs = p.Cs;
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  const int R = p.B * Hs * Ws;
+  const int GC = 16 * Cb;
+  const int tiles_n = (Cs + 127) / 128;
+  const int tiles = ((GC + 255) / 256) * tiles_n;
+  int tile, split;
+  if (p.rsplit >= 8) {            // a whole r-split on one XCD (ids with equal id % 8 share an L2)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % tiles;
+    split = (j / tiles) * 8 + xcd;
+    if (split >= p.rsplit) return;
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
+  const int gc0 = (tile / tiles_n) * 256, cs0 = (tile % tiles_n) * 128;
+  const int steps_total = (R + 63) / 64;
+  const int steps_per = (steps_total + p.rsplit - 1) / p.rsplit;
+  const int step_lo = split * steps_per;
+  const int step_hi = min(steps_total, step_lo + steps_per);
+  if (step_lo >= step_hi) return;
+
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.big), rs_s = make_rsrc(p.small);
+  // piece q = wave + 8 i (i < 2) of every image = rows 4q .. 4q+3; lane -> row 4q + (lane>>4), physical chunk lane&15
+  const int row0 = 4 * wave + (lane >> 4);                       // rows row0 and row0 + 32
+  const int lc = ((((lane & 15) >> 1) ^ timg_swz(row0)) << 1) | (lane & 1);   // same for row0 + 32
+  int kh[2], kw[2], cb[2];
+  bool gc_ok[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {                                  // the two big images
+    const int gc = gc0 + 128 * g + lc * 8;
+    gc_ok[g] = gc < GC;
+    const int tap = gc_ok[g] ? gc / Cb : 0;
+    cb[g] = gc_ok[g] ? gc - tap * Cb : 0;
+    kh[g] = tap >> 2; kw[g] = tap & 3;
+  }
+  const bool cs_ok = (cs0 + lc * 8) < Cs;
+  const int ldb2 = p.ldbig * 2, lds2 = p.ldsmall * 2;
+  const int adv_w = 64 % Ws, q1 = 64 / Ws, adv_h = q1 % Hs, adv_b = q1 / Hs;
+  int rb[2], rh[2], rw[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int r = step_lo * 64 + row0 + 32 * i;
+    rw[i] = r % Ws; const int t = r / Ws; rh[i] = t % Hs; rb[i] = t / Hs;
+  }
+  auto issue = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int r = step * 64 + row0 + 32 * i;
+      const bool r_ok = r < R;
+      char* piece = lds0 + (wave + 8 * i) * 1024;
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        const int h = 2 * rh[i] + kh[g] - 1, w = 2 * rw[i] + kw[g] - 1;
+        const bool okb = gc_ok[g] && r_ok && (unsigned)h < (unsigned)Hb && (unsigned)w < (unsigned)Wb;
+        dma16(rs_b, piece + g * IMG, okb ? (unsigned)(((rb[i] * Hb + h) * Wb + w) * ldb2 + cb[g] * 2) : OOB);
+      }
+      dma16(rs_s, piece + 2 * IMG, (cs_ok && r_ok) ? (unsigned)(r * lds2 + (cs0 + lc * 8) * 2) : OOB);
+      rw[i] += adv_w; rh[i] += adv_h; rb[i] += adv_b;
+      if (rw[i] >= Ws) { rw[i] -= Ws; rh[i]++; }
+      if (rh[i] >= Hs) { rh[i] -= Hs; rb[i]++; }
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&]() {
+    const char* bimg = lds0 + (wm >> 1) * IMG;
+    const char* simg = lds0 + 2 * IMG;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      u32x4_t bf[4], sf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        bf[i] = timg_frag(bimg, (wm & 1) * 64 + i * 16, kk, lane);
+        sf[i] = timg_frag(simg, wn * 64 + i * 16, kk, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(sf[j], bf[i], acc[i][j]);
+    }
+  };
+
+  for (int step = step_lo; step < step_hi; step++) {
+    issue(step);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    compute();
+    __syncthreads();
+  }
+
+  float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
+  const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = gc0 + wm * 64 + i * 16 + (elane & 15);
     if (row >= GC) continue;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -605,6 +760,7 @@ bool wgrad_mfma_supported(int dtype, const WgradParams& p) {
 }
 
 int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer) {
+  const gct2_adam_args* want_adam = defer ? defer->want_adam : nullptr;
   if (defer) *defer = WgradSlabs{nullptr, 0, 0};
   const int g_wgrad_variant = c.wgrad_variant, g_wgrad_target = c.wgrad_target, g_wgrad_slab_max = c.wgrad_slab_max, g_wgrad_pipe = c.wgrad_pipe;
   const int R = p.B * p.Hs * p.Ws;
@@ -622,14 +778,18 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   // (going further down - the small tile with ~512 work-groups for DownShuffle_1/2 and UpShuffle_1, 32 MiB of slabs each - is faster
   // launch by launch (92 -> 80, 84 -> 80, 145 -> 143 us incl. the slab sum) and SLOWER in the step: +38 us in an in-process A/B, the
   // small work-groups interleave with the input-gradient chain's instead of alternating with them)
-  const bool big_tile = !p.ks && (g_wgrad_variant == 2 || (g_wgrad_variant == 0 && tiles128 < 256 && blocks256 >= 192));
-  const int tiles = big_tile ? tiles256 : tiles128;
+  const bool big_tile0 = !p.ks && (g_wgrad_variant == 2 || g_wgrad_variant == 4 || (g_wgrad_variant == 0 && tiles128 < 256 && blocks256 >= 192));
+  // variant 4 (r03): the 256 x 128 tile at two work-groups per CU in place of the 256 x 256 pipeline
+  const bool tile2x = big_tile0 && g_wgrad_variant == 4;
+  const bool big_tile = big_tile0 && !tile2x;
+  const int tiles2x = ((taps * p.Cb + 255) / 256) * ((p.Cs + 127) / 128);
+  const int tiles = tile2x ? tiles2x : (big_tile ? tiles256 : tiles128);
   const int steps_total = (R + 63) / 64;
   // aim at ~768 workgroups (3 per CU; 512 for the big tile) but keep >= 4 steps of 64 rows per split; one owner per tile
   // once the tiles alone give every CU a work-group
-  int rsplit = big_tile ? (g_wgrad_target + tiles - 1) / tiles : (tiles >= 512 ? 1 : (768 + tiles - 1) / tiles);
-  if (!big_tile && tiles >= 256 && tiles < 512) rsplit = steps_total >= 32 ? 2 : 1;    // two work-groups per CU once the reduction is long enough
-  if (!big_tile && c.wgrad_split) rsplit = 1 << (c.wgrad_split - 1);
+  int rsplit = tile2x ? (512 + tiles - 1) / tiles : big_tile ? (g_wgrad_target + tiles - 1) / tiles : (tiles >= 512 ? 1 : (768 + tiles - 1) / tiles);
+  if (!big_tile && !tile2x && tiles >= 256 && tiles < 512) rsplit = steps_total >= 32 ? 2 : 1;    // two work-groups per CU once the reduction is long enough
+  if (!big_tile && !tile2x && c.wgrad_split) rsplit = 1 << (c.wgrad_split - 1);
   rsplit = max(1, min(rsplit, steps_total / 4));
   const int per = (steps_total + rsplit - 1) / rsplit;
   rsplit = (steps_total + per - 1) / per;            // every split non-empty (each one owns a slab)
@@ -643,9 +803,18 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   float* ws = c.wgrad_scratch(&ws_bytes);
   // measured (scripts/bench_wgrad.py): slabs beat atomics up to ~24 splits; beyond that (UpShuffle_0: 16 tiles x 48
   // splits) the many 1-MiB slabs cost more than the atomics they replace
-  if (rsplit > 1 && rsplit <= (big_tile ? 64 : g_wgrad_slab_max) && ws && n % 4 == 0 && (uintptr_t)p.dw % 16 == 0 && n * sizeof(float) * rsplit <= ws_bytes &&
+  if (rsplit > 1 && rsplit <= ((big_tile || tile2x) ? 128 : g_wgrad_slab_max) && ws && n % 4 == 0 && (uintptr_t)p.dw % 16 == 0 && n * sizeof(float) * rsplit <= ws_bytes &&
       g_wgrad_variant != 7)
     p.ws = ws;
+  // one owner per tile (no split), 4x4 layers on the 128 x 128 tile, operand copy in the compute dtype: the optimizer step the caller
+  // asked for (gct2_adam_args) runs in the epilogue - the gradient never leaves the registers
+  if (want_adam && c.wgrad_fuse_adam && rsplit == 1 && !big_tile && !tile2x && !p.ks && !p.accumulate && n % 4 == 0 &&
+      (!want_adam->shadow || want_adam->shadow_dtype == dtype)) {
+    p.adam.p = want_adam->p; p.adam.m = want_adam->m; p.adam.v = want_adam->v; p.adam.shadow = want_adam->shadow;
+    p.adam.alpha = want_adam->alpha; p.adam.b1 = want_adam->beta1; p.adam.b2 = want_adam->beta2; p.adam.eps = want_adam->eps;
+    p.adam.gmul = want_adam->grad_mul;
+    defer->adam_done = true;
+  }
   dim3 grid(rsplit >= 8 ? tiles * 8 * ((rsplit + 7) / 8) : tiles * rsplit);
   if (!p.ws && rsplit > 1 && !p.accumulate) {     // atomics add into the target: start it from zero
     (void)hipMemsetAsync(p.dw, 0, n * sizeof(float), s);
@@ -654,6 +823,9 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   if (p.ks) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad_kernel<__bf16, 2, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<_Float16, 2, true>), grid, dim3(256), 0, s, p);
+  } else if (tile2x) {
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad2x_kernel<__bf16>, grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(wgrad2x_kernel<_Float16>, grid, dim3(512), 0, s, p);
   } else if (big_tile && g_wgrad_pipe) {
     if (c.wgrad_ring == 5) {
       if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad256p_kernel<__bf16, 5>), grid, dim3(512), 0, s, p);

@@ -68,7 +68,15 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D dgrad), 0 = automatic, 1 = never, 2 = wherever the shape allows;
  * bits 26-27: tile -> XCD order of the forward / input-gradient GEMMs, 0 = automatic, 1 = bands of output pixels per XCD,
  * 2 = weight slices per XCD (layers whose weight tensor is the bigger operand);
- * bits 28-30: forced pixel split of the 128x128 weight-gradient tile, 0 = automatic, v = 1..7: 2^(v-1) splits. */
+ * bits 28-30: forced pixel split of the 128x128 weight-gradient tile, 0 = automatic, v = 1..7: 2^(v-1) splits;
+ * r03 additions - tile values 7 / 8 (bits 0-7): 256x256 with a five-stage LDS ring (8: DMA interleaved with the MFMA groups);
+ * bit 8: apply the fused optimizer step (gct2_adam_args) INSIDE the epilogue of weight-gradient launches whose tiles have one owner
+ * (the gradient never leaves the registers: 8 B per parameter less traffic; measured +70 us per step - the epilogue's p/m/v round
+ * trips hold the matrix-core work-groups - so off by default: the step runs the streaming Adam launch behind the gradient);
+ * bit 23: FOUR stage buffers instead of five (all 160 KiB of LDS, the default since r03: +3..7 % on the two largest layers) in the
+ * 256x256 weight-gradient pipeline;
+ * bit 31: halo-tile kernel with the DMA of the next round issued in FRONT of the current round's MFMAs (r02) instead of between
+ * its MFMA groups (default since r03: -3..-6 % on the UpShuffle_1/2 forward launches). */
 int gct2_ctx_set_tuning(gct2_ctx* ctx, int v);
 /* test hook: non-zero routes every convolution of this ctx through the direct (non-MFMA) kernels */
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on);

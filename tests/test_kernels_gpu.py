@@ -217,14 +217,18 @@ def test_wgrad_reduction_modes_agree(gpu, shape):
     assert np.array_equal(res[1], res[2])          # slab path is bitwise reproducible
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 0x42])
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 0x42, 0x82])
 @pytest.mark.parametrize("shape", [(4, 32, 32, 64, 128), (1, 12, 20, 72, 136), (2, 8, 8, 256, 512)])
-def test_wgrad_tile_variants(gpu, variant, shape):
-    """weight-gradient tile variants: 1 = 128x128 single buffer, 2 = 256x256 (8 waves of 128x64) with the four-stage spanning
-    pipeline (counted vmcnt across raw barriers), 0x42 = 256x256 with two 64-row buffers, 3 = 128x128 double buffer."""
+def test_wgrad_tile_variants(gpu, variant, shape, use_ws):
+    """weight-gradient tile variants: 1 = 128x128 single buffer, 2 = 256x256 (8 waves of 128x64) with the spanning pipeline (counted
+    vmcnt across raw barriers; five stage buffers, 0x82: four), 0x42 = 256x256 with two 64-row buffers, 3 = 128x128 double buffer,
+    4 = 256x128 single buffer at two work-groups per CU (r03); without a workspace (atomics) and with one (ordered slabs)."""
     B, H, W, Cin, Cout = shape
     dt = BF16
     L = lib()
+    ws = torch.empty(16 << 18, dtype=torch.float32, device=gpu)
+    set_ws(ws if use_ws else None)
     set_tuning(variant << 16)
     try:
         rng = np.random.default_rng(16)
@@ -241,6 +245,7 @@ def test_wgrad_tile_variants(gpu, variant, shape):
         assert rel_l2(dwt.cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
     finally:
         set_tuning(0)
+        set_ws(None)
 
 
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
@@ -740,8 +745,9 @@ def test_convT_fwd_halo_kernel(gpu, dt, shape):
     xd, wtd, bd = dev(x, dt, gpu), dev(wt, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
     ref = np.maximum(O.convT4s2_fwd(x, wt, b), 0)
     outs = []
-    for mode in (2, 1):          # halo forced / halo off: both against the oracle, and close to each other
-        set_tuning(mode << 24)
+    IL = -(1 << 31)              # bit 31 of the tuning word: the r02 order (DMA pieces in front of the round's MFMAs) instead of interleaved
+    for mode in ((2 << 24), (2 << 24) + IL, (1 << 24)):          # halo forced / forced + interleaved / off: each against the oracle
+        set_tuning(mode)
         try:
             ld = Cout + 16                # view = channels [8, 8 + Cout): 16-byte aligned rows (the halo kernel's epilogue needs that)
             yt = torch.full((B, 2 * H, 2 * W, ld), 7.0, dtype=TDT[dt], device=gpu)
@@ -753,12 +759,14 @@ def test_convT_fwd_halo_kernel(gpu, dt, shape):
         assert rel_l2(yt[..., 8:8 + Cout].double().cpu().numpy(), ref) <= TOL_OUT[dt], mode
         assert float((yt[..., :8].float() - 7).abs().max()) == 0 and float((yt[..., 8 + Cout:].float() - 7).abs().max()) == 0
         outs.append(yt)
-    assert rel_l2(outs[0].double().cpu().numpy(), outs[1].double().cpu().numpy()) <= TOL_OUT[dt]
+    assert torch.equal(outs[0], outs[1])                         # the interleaved form runs the same multiplies in the same order
+    assert rel_l2(outs[0].double().cpu().numpy(), outs[2].double().cpu().numpy()) <= TOL_OUT[dt]
 
 
+@pytest.mark.parametrize("il", [0, 1])
 @pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64, 24), (1, 32, 64, 136, 64)])
-def test_conv_dgrad_halo_kernel(gpu, shape, use_ws):
+def test_conv_dgrad_halo_kernel(gpu, shape, use_ws, il):
     """the halo-tile kernel as the Conv2D input gradient (mask, accumulation into a running buffer, fused bias gradients with the
     split at db_split, partial rows with a workspace / atomics without): forced on and compared with the oracle."""
     B, H, W, Cin, Cout = shape                     # dgrad output [B,H,W,Cin]; small grid H/2 x W/2 must tile into 16 x 16
@@ -766,7 +774,7 @@ def test_conv_dgrad_halo_kernel(gpu, shape, use_ws):
     L = lib()
     ws = torch.empty(8 << 18, dtype=torch.float32, device=gpu)
     set_ws(ws if use_ws else None)
-    set_tuning(2 << 24)
+    set_tuning((2 << 24) - (il << 31))
     try:
         rng = np.random.default_rng(41)
         x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)

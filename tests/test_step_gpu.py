@@ -365,16 +365,20 @@ def test_fused_adam_equals_separate_adam(gpu):
     ts = [torch.randint(1, 201, (16,), generator=gen, dtype=torch.int32) for _ in range(3)]
     es = [torch.randn(16, 64, 64, 3, generator=gen) for _ in range(3)]
     engines = []
-    for fuse in (False, True):
+    # third engine (r03): tuning bit 8 also moves the optimizer step of the one-owner weight-gradient launches INTO their epilogue
+    # (the gradient never leaves the registers); one shared adam_keras_update() keeps all three forms bit-identical
+    for fuse, tuning in ((False, 0), (True, 0), (True, 0x100)):
         eng = g.UNetEngine(topo, g.BF16, gpu, seed=77)
         eng.fuse_adam = fuse
+        eng.ctx.set_tuning(tuning)
         losses = [float(eng.train_step(x, t, e)[0]) for x, t, e in zip(xs, ts, es)]
         torch.cuda.synchronize()
         engines.append((eng, losses))
-    (a, la), (b, lb) = engines
-    assert la == lb and a.iterations == b.iterations == 3
+    (a, la), (b, lb), (c, lc) = engines
+    assert la == lb == lc and a.iterations == b.iterations == c.iterations == 3
     for name in ("p", "m", "v", "shadow"):
         assert torch.equal(getattr(a.arena, name), getattr(b.arena, name)), name
+        assert torch.equal(getattr(a.arena, name), getattr(c.arena, name)), name
 
 
 @pytest.mark.parametrize("size,batch", [(64, 3), (192, 2), (128, 5), (256, 1)])
