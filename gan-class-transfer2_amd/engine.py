@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -175,7 +176,10 @@ class UNetEngine:
         self.arena.refresh_shadow(self._stream())
         self._iterations = 0           # optimizer.iterations [TF] (with loss scaling the counter lives on the device)
         self.rng_seed, self.rng_offset_t, self.rng_offset_eps = rng_seed, 0, 0
-        self._bufs: Dict[Tuple[int, int, int], _Buffers] = {}
+        # activation / gradient buffer sets by (B, H, W), least recently used first; at most `max_buffer_sets` stay allocated (the
+        # train step, the sampler's batch 1 and batch 6 sets and one spare: a set at config 3 is ~0.8 GB, r02 kept every shape ever seen)
+        self._bufs: "OrderedDict[Tuple[int, int, int], _Buffers]" = OrderedDict()
+        self.max_buffer_sets = 4
         # the call context (include/gct2.h gct2_ctx): this engine's scratch tensors and tile knobs; nothing is process-wide
         self.ctx = _lib.Context()
         # split-K scratch for the bottleneck layers, partial rows of the fused bias gradients / the head; caller-owned = this tensor
@@ -250,8 +254,15 @@ class UNetEngine:
     def buffers(self, B: int, H: int, W: int) -> _Buffers:
         key = (B, H, W)
         if key in self._bufs:
+            self._bufs.move_to_end(key)
             return self._bufs[key]
         self.check_input_shape(H, W)
+        while len(self._bufs) >= max(1, self.max_buffer_sets):
+            _, old = self._bufs.popitem(last=False)             # least recently used; graphs captured on it go with it
+            graphs = getattr(self, "_forward_graphs", None)
+            if graphs:
+                for gk in [k for k in graphs if k[0] == id(old)]:
+                    del graphs[gk]
         t, n, dt = self.topo, self.topo.octaves, TORCH_DTYPE[self.dtype]
         b = _Buffers()
         b.B, b.H, b.W = B, H, W

@@ -184,3 +184,11 @@ def test_lds_swizzles_are_conflict_free_in_the_bank_model():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.main()
+
+
+def test_buffer_sets_are_bounded():
+    """UNetEngine keeps at most `max_buffer_sets` activation buffer sets, least recently used first (r02 kept one per shape ever seen)."""
+    import inspect
+    from gan_class_transfer2_amd import engine
+    src = inspect.getsource(engine.UNetEngine.buffers)
+    assert "max_buffer_sets" in src and "popitem(last=False)" in src and "move_to_end" in src
