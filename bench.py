@@ -295,10 +295,10 @@ def main():
             # achieved = algorithmic FLOPs of ALL launches of the dominant family in the serial-stream steps / their summed
             # HIP-event time (= average FLOPs per launch / average launch duration).  traffic = HBM bytes per launch of that
             # family, NOT measured in this run: the average over its launches in the committed per-layer PMC passes
-            # (profiles/r02_traffic_per_layer.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+            # (profiles/r03_traffic_per_layer.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
             # scripts/traffic_layers.py, gfx950 corrections applied), only for the default config; `traffic_source` says so.
             traffic, traffic_source = None, None
-            tname = "r02_traffic_per_layer.json"
+            tname = "r03_traffic_per_layer.json"
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and (S, B, args.dtype, world) == (128, 64, "bf16", 1):
                 with open(tpath) as f:

@@ -50,6 +50,9 @@ SIGNATURES = {
     "gct2_ctx_set_tuning": [_vp, _i],
     "gct2_ctx_force_direct": [_vp, _i],
     "gct2_ctx_set_stamp_buffer": [_vp, _vp, _sz],
+    "gct2_ctx_set_rowsum_buffer": [_vp, _vp, _sz],
+    "gct2_rowsum_begin": [_vp],
+    "gct2_rowsum_flush": [_vp, _vp, _vp, _vp, _i, _vp],
     "gct2_diffusion_mix": [_i, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _sz, _i, _vp],
     "gct2_diffusion_update": [_i, _vp, _vp, _d, _d, _vp, _vp, _sz, _vp],
     "gct2_noise_edits": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -138,7 +141,7 @@ class Context:
         h = C.c_void_p()
         call("gct2_ctx_create", C.byref(h))
         self.handle = h.value
-        self._keep = [None, None, None]
+        self._keep = [None, None, None, None]
         # bumped by every setter: whoever caches something that bakes in this context's pointers or tile choices (the sampler's
         # HIP graphs of the forward pass) keys its cache on it
         self.version = 0
@@ -148,6 +151,13 @@ class Context:
         self._keep[2] = tensor
         self.version += 1
         call("gct2_ctx_set_stamp_buffer", self.handle, tensor.data_ptr() if tensor is not None else None,
+             tensor.numel() * tensor.element_size() if tensor is not None else 0)
+
+    def set_rowsum_buffer(self, tensor) -> None:
+        """scratch for the deferred bias-gradient row sums of a whole reverse pass (gct2_rowsum_begin / gct2_rowsum_flush)."""
+        self._keep[3] = tensor
+        self.version += 1
+        call("gct2_ctx_set_rowsum_buffer", self.handle, tensor.data_ptr() if tensor is not None else None,
              tensor.numel() * tensor.element_size() if tensor is not None else 0)
 
     def set_workspace(self, tensor) -> None:

@@ -38,6 +38,8 @@ int pw_diffusion_mix(int, const float*, const float*, float, float*, void*, int,
 int pw_diffusion_update(int, const float*, const float*, double, double, float*, float*, size_t, hipStream_t);
 int pw_noise_edits(const float*, const float*, int, float*, int, int, int, hipStream_t);
 int pw_image_prepare(const uint8_t*, const int64_t*, const int32_t*, float*, int, int, hipStream_t);
+int rowsum_flush_launch(const gct2_ctx& c, const gct2_adam_args* adam, const float* g_base, const int64_t* bias_ranges, int nranges,
+                        hipStream_t s);   // tapgemm_mfma.hip
 int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const gct2_loss_scale_state*, int, hipStream_t,
             const float* slabs = nullptr, int nslab = 0, size_t slab_stride = 0, size_t n_slab = 0);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
@@ -195,6 +197,30 @@ int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes) {
   (void)stamps; (void)bytes;
   return gct2_fail(GCT2_EINVAL, "ctx_set_stamp_buffer: this is the product build (rebuild with make EXTRA=-DGCT2_STAMP for in-kernel stamps)");
 #endif
+}
+int gct2_ctx_set_rowsum_buffer(gct2_ctx* ctx, void* buf, size_t bytes) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_rowsum_buffer: null ctx");
+  if (buf && ((uintptr_t)buf % 16)) return gct2_fail(GCT2_EINVAL, "ctx_set_rowsum_buffer: pointer must be 16-byte aligned");
+  if (ctx->rowsum.open) return gct2_fail(GCT2_EINVAL, "ctx_set_rowsum_buffer: a row-sum deferral is open (flush it first)");
+  ctx->rowsum.buf = buf ? reinterpret_cast<float*>(buf) : nullptr;
+  ctx->rowsum.bytes = buf ? bytes : 0;
+  return GCT2_OK;
+}
+int gct2_rowsum_begin(gct2_ctx* ctx) {
+  if (!ctx || !ctx->rowsum.buf) return gct2_fail(GCT2_EINVAL, "rowsum_begin: needs a ctx with a row-sum buffer (gct2_ctx_set_rowsum_buffer)");
+  if (!ctx->ws) return gct2_fail(GCT2_EINVAL, "rowsum_begin: needs a ctx workspace (without one the bias gradients are summed with atomics)");
+  ctx->rowsum.open = true; ctx->rowsum.used = 0; ctx->rowsum.overflow = false;
+  ctx->rowsum.table.ntargets = 0; ctx->rowsum.table.nblocks = 0;
+  return GCT2_OK;
+}
+int gct2_rowsum_flush(gct2_ctx* ctx, const gct2_adam_args* adam, const float* g_base, const int64_t* bias_ranges, int nranges, void* stream) {
+  if (!ctx || !ctx->rowsum.open) return gct2_fail(GCT2_EINVAL, "rowsum_flush: no deferral open on this ctx (gct2_rowsum_begin)");
+  if (adam && (!adam->p || !adam->m || !adam->v || !g_base || nranges < 0 || (nranges > 0 && !bias_ranges)))
+    return gct2_fail(GCT2_EINVAL, "rowsum_flush: the fused bias optimizer needs the p / m / v arena bases, the gradient arena base and the bias ranges");
+  for (int r = 0; adam && r < nranges; r++)
+    if (bias_ranges[2 * r] < 0 || bias_ranges[2 * r + 1] <= 0 || (size_t)(bias_ranges[2 * r] + bias_ranges[2 * r + 1]) > adam->n)
+      return gct2_fail(GCT2_EINVAL, "rowsum_flush: bias range %d lies outside the arena of %zu elements", r, adam->n);
+  return rowsum_flush_launch(*ctx, adam, g_base, bias_ranges, nranges, S(stream));
 }
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on) {
   if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_force_direct: null ctx");

@@ -17,7 +17,26 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 int gct2_fail(int code, const char* fmt, ...);
 int gct2_check_launch(const char* what);
 
-// the call context of include/gct2.h: caller-owned scratch + tile-selection knobs.  Host memory, read-only during a call.
+// Deferred bias-gradient row sums (gct2_rowsum_begin / gct2_rowsum_flush, include/gct2.h): while a deferral is open, the input-gradient
+// launches of a reverse pass leave their partial rows in the caller's row-sum buffer and only RECORD where each bias gradient comes
+// from; the flush is ONE launch that sums every target's sources in recording order (and can apply Keras Adam to those biases).
+constexpr int ROWSUM_MAX_TARGETS = 16, ROWSUM_MAX_SRC = 2;
+struct RowsumSrc { const float* part; int rows; int ld; int col0; };           // part[r * ld + col0 + c], r < rows
+struct RowsumTarget { float* dst; int ncols; int nsrc; int add; int blk0; int adam; RowsumSrc src[ROWSUM_MAX_SRC]; };   // adam: the flush applies the optimizer to it
+struct RowsumTable {
+  int ntargets = 0, nblocks = 0;
+  RowsumTarget t[ROWSUM_MAX_TARGETS];
+};
+struct RowsumState {
+  float* buf = nullptr; size_t bytes = 0;          // the caller's buffer (gct2_ctx_set_rowsum_buffer)
+  bool open = false;                               // between gct2_rowsum_begin and gct2_rowsum_flush
+  size_t used = 0;                                 // bump pointer (floats)
+  bool overflow = false;                           // a launch did not fit any more: it reduced its rows itself (still correct)
+  RowsumTable table;
+};
+
+// the call context of include/gct2.h: caller-owned scratch + tile-selection knobs.  Host memory, read-only during a call (except
+// the row-sum record, which the input-gradient entry points append to while a deferral is open).
 struct gct2_ctx {
   float* ws = nullptr; size_t ws_bytes = 0;        // split-K slabs, partial rows (forward / input-gradient / head calls)
   float* wws = nullptr; size_t wws_bytes = 0;      // weight-gradient slabs (falls back to ws)
@@ -31,6 +50,7 @@ struct gct2_ctx {
   int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile: 0 = automatic, v: 2^(v-1)
   int force_direct = 0;
   unsigned long long* stamps = nullptr; size_t stamps_bytes = 0;   // diagnostic builds only (gct2_ctx_set_stamp_buffer)
+  mutable RowsumState rowsum;
   float* wgrad_scratch(size_t* bytes) const {
     if (wws) { *bytes = wws_bytes; return wws; }
     *bytes = ws_bytes; return ws;
@@ -230,6 +250,11 @@ __device__ __forceinline__ bool xcd_tile(int id, int m_tiles, int inner, int chu
   return (j / inner) < chunk && m_tile < m_tiles;
 }
 
+// row-sum deferral: rows x N floats for the partial rows of one input-gradient launch, or null (no deferral open / buffer full)
+float* rowsum_alloc(const gct2_ctx& c, size_t rows, int N);
+// ... and the record of what those rows are: channels [0, db_split) of the launch feed p.db, the rest p.db2 (tapgemm_mfma.hip)
+void rowsum_record(const gct2_ctx& c, const TapGemmParams& p, const float* part, int rows);
+
 // the atomic fall-backs of the fused bias gradients add into their targets: overwritten targets start from zero
 inline void zero_overwritten_db(const TapGemmParams& p, hipStream_t s) {
   if (p.db && !(p.db_acc & 1) && p.db_split > 0) (void)hipMemsetAsync(p.db, 0, (size_t)p.db_split * sizeof(float), s);
@@ -240,9 +265,16 @@ inline void zero_overwritten_db(const TapGemmParams& p, hipStream_t s) {
 // for the weight-gradient epilogues that apply it in place, so that both round identically (fused == separate, bit for bit)
 __device__ __forceinline__ void adam_keras_update(float& p, float& m, float& v, float g, float alpha, float b1, float ob1, float b2,
                                                   float ob2, float eps) {
-  m = b1 * m + ob1 * g;
-  v = b2 * v + ob2 * g * g;
-  p = p - alpha * m / (sqrtf(v) + eps);
+  // no FMA contraction here: which products hipcc fuses depends on the code around the call (the row-sum flush kernel fused
+  // differently from the optimizer kernel and the results differed in the last bit); plain IEEE multiplies and adds in this order
+  // are the same everywhere - and what an unfused TensorFlow kernel computes
+#pragma clang fp contract(off)
+  const float m1 = b1 * m, m2 = ob1 * g;
+  m = m1 + m2;
+  const float v1 = b2 * v, v2 = (ob2 * g) * g;
+  v = v1 + v2;
+  const float num = alpha * m, den = sqrtf(v) + eps;
+  p = p - num / den;
 }
 // optimizer step fused into the epilogue of a weight-gradient launch whose tiles have ONE owner (no split of the pixel range):
 // the gradient never leaves the registers - no write and no re-read of dW (8 B per parameter) and no separate Adam launch

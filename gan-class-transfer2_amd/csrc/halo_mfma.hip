@@ -584,11 +584,16 @@ int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   p.ksplit = 1;
   p.dbws = nullptr;
+  float* deferred = nullptr;
   if (epi == EPI_MASK && (p.db || p.db2)) {      // partial bias-gradient rows at the tail of the workspace, one per work-group row
     const size_t ws_bytes = c.ws_bytes;
     float* ws = c.ws;
     const size_t need = (size_t)p.m_tiles * p.N * sizeof(float);
     if (ws && ws_bytes >= need + 16) p.dbws = ws + (ws_bytes - need) / sizeof(float) / 4 * 4;
+    if (p.dbws) {     // an open row-sum deferral: the rows stay in the caller's row-sum buffer until gct2_rowsum_flush
+      deferred = rowsum_alloc(c, (size_t)p.m_tiles, p.N);
+      if (deferred) p.dbws = deferred;
+    }
     if (!p.dbws) zero_overwritten_db(p, s);
   }
   dim3 grid(8 * p.xcd_chunk * p.n_tiles);
@@ -607,7 +612,8 @@ int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream
     if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_MASK>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_MASK>), grid, dim3(512), 0, s, p);
   }
-  if (p.dbws) {
+  if (deferred) rowsum_record(c, p, deferred, p.m_tiles);
+  else if (p.dbws) {
     if (int e = tapgemm_dbpart_reduce(p.dbws, p.m_tiles, p, s)) return e;
   }
   return gct2_check_launch("halo_convT");

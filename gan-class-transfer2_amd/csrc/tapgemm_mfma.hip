@@ -668,6 +668,65 @@ __global__ __launch_bounds__(1024) void dbpart_reduce_kernel(const float* __rest
   }
 }
 
+// ---- deferred row sums: ONE launch for every bias gradient of a reverse pass (gct2_rowsum_flush) -----------------------------------
+// Block = 32 columns of ONE target x 128 row lanes (the geometry and the summation order of dbpart_reduce_kernel, so a deferred
+// bias gradient has the bits of an immediate one); a target's sources are added in recording order: first writer + second writer
+// of a concat slice, exactly as "overwrite, then add" does.  adam != null: Keras Adam on the bias right here (the per-layer
+// optimizer launches of the fused step then cover the kernels only).
+struct RowsumAdam { float* p; float* m; float* v; void* shadow; const float* g_base; int shadow_dtype; float alpha, b1, b2, eps, gmul; };
+__global__ __launch_bounds__(1024) void rowsum_flush_kernel(RowsumTable tab, RowsumAdam ad) {
+  int ti = 0;
+  for (int k = 1; k < tab.ntargets; k++) if ((int)blockIdx.x >= tab.t[k].blk0) ti = k;     // block-uniform
+  const RowsumTarget& T = tab.t[ti];
+  const int tid = threadIdx.x, cq = tid & 7, rl = tid >> 3;
+  const int n = ((int)blockIdx.x - T.blk0) * 32 + cq * 4;
+  __shared__ f32x4_t red[16][8];
+  f32x4_t total = {0.f, 0.f, 0.f, 0.f};
+  for (int si = 0; si < T.nsrc; si++) {
+    const RowsumSrc S = T.src[si];
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (n < T.ncols)
+      for (int r = rl; r < S.rows; r += 128) acc += *reinterpret_cast<const f32x4_t*>(S.part + (size_t)r * S.ld + S.col0 + n);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float t = acc[k];
+      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+      acc[k] = t;
+    }
+    __syncthreads();                                        // red is reused per source
+    if ((tid & 63) < 8) red[tid >> 6][cq] = acc;
+    __syncthreads();
+    if (tid < 8) {
+      f32x4_t t = red[0][tid];
+#pragma unroll
+      for (int k = 1; k < 16; k++) t += red[k][tid];
+      total = si == 0 ? t : total + t;
+    }
+  }
+  if (tid < 8 && n < T.ncols) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (n + r >= T.ncols) break;
+      float* q = T.dst + n + r;
+      // no recorded source: the launches reduced their rows themselves (no workspace rows, a full buffer, the direct kernels) and
+      // the gradient is in place already
+      const float gval = T.nsrc == 0 ? *q : (T.add ? *q + total[r] : total[r]);
+      if (T.nsrc) *q = gval;
+      if (ad.p && T.adam) {
+        const size_t e = (size_t)(q - ad.g_base);
+        float pp = ad.p[e], mm = ad.m[e], vv = ad.v[e];
+        adam_keras_update(pp, mm, vv, gval * ad.gmul, ad.alpha, ad.b1, 1.f - ad.b1, ad.b2, 1.f - ad.b2, ad.eps);
+        ad.p[e] = pp; ad.m[e] = mm; ad.v[e] = vv;
+        if (ad.shadow) {
+          if (ad.shadow_dtype == GCT2_BF16) reinterpret_cast<__bf16*>(ad.shadow)[e] = from_f32<__bf16>(pp);
+          else if (ad.shadow_dtype == GCT2_F16) reinterpret_cast<_Float16*>(ad.shadow)[e] = from_f32<_Float16>(pp);
+          else reinterpret_cast<float*>(ad.shadow)[e] = pp;
+        }
+      }
+    }
+  }
+}
+
 // sums the split-K slabs and applies the epilogue the GEMM kernel skipped.  Work-group = 8 pixels x 128 channels,
 // thread = 4 channels of one pixel (split-K layers have few pixels: keep the grid wide), and the bias-gradient
 // column sums of the 8 pixels are reduced in LDS into one partial row for dbpart_reduce_kernel.
@@ -791,12 +850,17 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   dim3 grid(p.wstat ? 8 * ((slices + 7) / 8) * p.m_tiles : 8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
   auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF, WM>;
   p.dbws = db_rows ? ws + (ws_bytes - dbws_bytes) / sizeof(float) / 4 * 4 : nullptr;
+  // an open row-sum deferral (gct2_rowsum_begin): the partial rows go to the caller's row-sum buffer and stay there until the flush
+  const int db_nrows = p.ksplit > 1 ? (int)fin_rows : p.m_tiles * PH;
+  float* deferred = (want_db && p.dbws) ? rowsum_alloc(c, (size_t)db_nrows, p.N) : nullptr;
+  if (deferred) p.dbws = deferred;
   if (want_db && !p.dbws) zero_overwritten_db(p, s);
   hipLaunchKernelGGL(kern, grid, dim3((BM / WM) * (BN / 64) * 64), 0, s, p);
   if (p.ksplit > 1) {
     hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)fin_rows, (p.N + 127) / 128), dim3(256), 0, s, p, npix);
   }
-  if (p.dbws) {
+  if (deferred) rowsum_record(c, p, deferred, db_nrows);
+  else if (p.dbws) {
     const int rows = p.ksplit > 1 ? (int)fin_rows : p.m_tiles * PH;
     hipLaunchKernelGGL(dbpart_reduce_kernel, dim3((p.N + 31) / 32), dim3(1024), 0, s, p.dbws, rows, p);
   }
@@ -869,6 +933,66 @@ int dispatch(const gct2_ctx& c, int form, int epi, const TapGemmParams& p, hipSt
 }
 
 }  // namespace
+
+float* rowsum_alloc(const gct2_ctx& c, size_t rows, int N) {
+  RowsumState& rs = c.rowsum;
+  if (!rs.open || !rs.buf) return nullptr;
+  const size_t need = (rows * (size_t)N + 3) / 4 * 4;
+  // two more targets must fit the table, the rows the buffer; otherwise this launch reduces its rows itself (same result)
+  if (rs.used + need > rs.bytes / sizeof(float) || rs.table.ntargets + 2 > ROWSUM_MAX_TARGETS) { rs.overflow = true; return nullptr; }
+  float* q = rs.buf + rs.used;
+  rs.used += need;
+  return q;
+}
+void rowsum_record(const gct2_ctx& c, const TapGemmParams& p, const float* part, int rows) {
+  RowsumTable& tab = c.rowsum.table;
+  auto add = [&](float* dst, int col0, int ncols, bool adds) {
+    if (!dst || ncols <= 0) return;
+    RowsumTarget* t = nullptr;
+    for (int k = 0; k < tab.ntargets; k++) if (tab.t[k].dst == dst) t = &tab.t[k];
+    if (t && (!adds || t->nsrc >= ROWSUM_MAX_SRC || t->ncols != ncols)) {
+      // an overwriting launch supersedes what was recorded for this target (or the record is full: cannot happen for the U-Net,
+      // every bias gradient has at most two writers) - start over
+      if (!adds) { t->nsrc = 0; t->add = 0; }
+      else return;                                           // unreachable by construction; drop rather than corrupt
+    }
+    if (!t) {
+      t = &tab.t[tab.ntargets++];
+      t->dst = dst; t->ncols = ncols; t->nsrc = 0; t->adam = 0;
+      t->add = adds ? 1 : 0;                                 // first record of the pass adds: keep what dst holds
+    }
+    t->src[t->nsrc++] = RowsumSrc{part, rows, p.N, col0};
+  };
+  add(p.db, 0, p.db_split < p.N ? p.db_split : p.N, (p.db_acc & 1) != 0);
+  add(p.db2, p.db_split, p.N - p.db_split, (p.db_acc & 2) != 0);
+}
+int rowsum_flush_launch(const gct2_ctx& c, const gct2_adam_args* adam, const float* g_base, const int64_t* bias_ranges, int nranges,
+                        hipStream_t s) {
+  RowsumState& rs = c.rowsum;
+  RowsumTable& tab = rs.table;
+  // the biases the caller wants the optimizer applied to: recorded targets get the flag, the others (their launches reduced their
+  // rows themselves: the gradient is in the arena already) join the table without sources
+  for (int r = 0; adam && r < nranges; r++) {
+    float* dst = const_cast<float*>(g_base) + bias_ranges[2 * r];
+    const int ncols = (int)bias_ranges[2 * r + 1];
+    RowsumTarget* t = nullptr;
+    for (int k = 0; k < tab.ntargets; k++) if (tab.t[k].dst == dst) t = &tab.t[k];
+    if (!t) {
+      if (tab.ntargets >= ROWSUM_MAX_TARGETS) return gct2_fail(GCT2_EINVAL, "rowsum_flush: more than %d bias targets", ROWSUM_MAX_TARGETS);
+      t = &tab.t[tab.ntargets++];
+      t->dst = dst; t->ncols = ncols; t->nsrc = 0; t->add = 1;
+    } else if (t->ncols != ncols) return gct2_fail(GCT2_EINVAL, "rowsum_flush: bias range %d has %d elements, the recorded gradient %d", r, ncols, t->ncols);
+    t->adam = 1;
+  }
+  int blocks = 0;
+  for (int k = 0; k < tab.ntargets; k++) { tab.t[k].blk0 = blocks; blocks += (tab.t[k].ncols + 31) / 32; }
+  tab.nblocks = blocks;
+  RowsumAdam ad{};
+  if (adam) ad = RowsumAdam{adam->p, adam->m, adam->v, adam->shadow, g_base, adam->shadow_dtype, adam->alpha, adam->beta1, adam->beta2, adam->eps, adam->grad_mul};
+  if (blocks > 0) hipLaunchKernelGGL(rowsum_flush_kernel, dim3(blocks), dim3(1024), 0, s, tab, ad);
+  rs.open = false; rs.used = 0; tab.ntargets = 0; tab.nblocks = 0;
+  return gct2_check_launch("rowsum_flush");
+}
 
 // true when the MFMA path can take this problem (16-byte aligned rows, whole 8-channel chunks, 31-bit byte offsets)
 bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {

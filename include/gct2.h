@@ -84,6 +84,25 @@ int gct2_ctx_force_direct(gct2_ctx* ctx, int on);
  * one wave per work-group of the next stamped launch of this ctx (layout: scripts/stamp_*.py).  GCT2_EINVAL in a product build. */
 int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes);
 
+/* ---- deferred bias-gradient row sums (r03) --------------------------------------------------------------------------------
+ * The fused bias gradients of the *_dgrad entry points (db / db2) are column sums over partial rows, one row per work-group; by
+ * default every dgrad call finishes them with a small reduction launch of its own.  Between gct2_rowsum_begin and
+ * gct2_rowsum_flush the calls of this ctx leave their partial rows in the caller's row-sum buffer instead and only record which
+ * target each belongs to; the flush is ONE launch that sums every target's sources in call order - bit-identical to the
+ * immediate form, including "first writer overwrites, second adds" (db_accumulate).  With `adam` the same launch applies Keras
+ * Adam to the biases listed in bias_ranges (HOST array of nranges (offset, count) pairs, in elements from g_base; adam->p / m /
+ * v / shadow = ARENA BASES matching g_base, the base of the gradient arena the db targets live in; adam->n = arena length): a
+ * listed bias whose gradient was not deferred (its launches reduced their rows themselves: no workspace rows, a full buffer, the
+ * direct kernels) is updated from the value already in the arena.  The bias gradients are complete only after the flush: a
+ * data-parallel run that reduces gradient buckets while the reverse pass is still running must not open a deferral.  A call that
+ * no longer fits the buffer (or the 16-target table) simply reduces its rows itself. */
+int gct2_ctx_set_rowsum_buffer(gct2_ctx* ctx, void* buf, size_t bytes);      /* 16-byte aligned device scratch, or NULL */
+int gct2_rowsum_begin(gct2_ctx* ctx);
+/* (gct2_adam_args is declared below) */
+struct gct2_adam_args;
+int gct2_rowsum_flush(gct2_ctx* ctx, const struct gct2_adam_args* adam /* or NULL */, const float* g_base,
+                      const int64_t* bias_ranges /* host */, int nranges, void* stream);
+
 /* ---- DownShuffle = Conv2D(f, 4, 2, 'same', relu)   train.py:158-169 ------------------------- */
 /* y[b,oh,ow,o] = act(bias[o] + sum_{kh,kw,i} x[b,2oh+kh-1,2ow+kw-1,i] * w[kh,kw,i,o])
  * x: [B,H,W,Cin] view, H and W even;  w: Keras kernel (4,4,Cin,Cout) of `dtype`;

@@ -57,9 +57,10 @@ def run(name, variant, iters=20):
     return us, flops / us / 1e6
 if os.environ.get("LAYERSET") == "small":
     LAYERS = SMALL
-# variant bits 24-25: halo kernel mode (1 = never, 2 = wherever the shape allows), e.g. 33554432 = halo forced
-variants = [int(v) for v in sys.argv[1:]] or [0, 2, 5]
-print("layer      " + "".join(f"{'v%d/h%d/x%d' % (v & 255, (v >> 24) & 3, v >> 26):>16s}" for v in variants))
-for name in LAYERS:
-    print(f"{name:10s} " + "".join("%8.1fus %4.0fTF" % run(name, v) for v in variants))
-CTX.set_tuning(0)
+if __name__ == "__main__":
+    # variant bits 24-25: halo kernel mode (1 = never, 2 = wherever the shape allows), e.g. 33554432 = halo forced
+    variants = [int(v) for v in sys.argv[1:]] or [0, 2, 5]
+    print("layer      " + "".join(f"{'v%d/h%d/x%d' % (v & 255, (v >> 24) & 3, v >> 26):>16s}" for v in variants))
+    for name in LAYERS:
+        print(f"{name:10s} " + "".join("%8.1fus %4.0fTF" % run(name, v) for v in variants))
+    CTX.set_tuning(0)

@@ -37,8 +37,9 @@ def run(name, code, iters=20):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     return us, flops / us / 1e6
-codes = [int(v) for v in sys.argv[1:]] or [0, 7]
-print("layer      " + "".join(f"{'v%d' % v:>16s}" for v in codes))
-for name in LAYERS:
-    print(f"{name:10s} " + "".join("%8.1fus %4.0fTF" % run(name, v) for v in codes))
-CTX.set_tuning(0)
+if __name__ == "__main__":
+    codes = [int(v) for v in sys.argv[1:]] or [0, 7]
+    print("layer      " + "".join(f"{'v%d' % v:>16s}" for v in codes))
+    for name in LAYERS:
+        print(f"{name:10s} " + "".join("%8.1fus %4.0fTF" % run(name, v) for v in codes))
+    CTX.set_tuning(0)

@@ -834,3 +834,83 @@ def test_wgrad_overwrite_mode(gpu, dt, shape, use_ws):
             assert rel_l2(dwt.cpu().numpy(), reft) <= TOL_F32OUT[dt]
     finally:
         set_ws(None)
+
+
+def test_deferred_rowsum_flush_equals_immediate_reduction(gpu):
+    """gct2_rowsum_begin / gct2_rowsum_flush (r03): two input-gradient launches that feed the same bias-gradient target (first
+    overwrites, second adds - the skip slice of a concat buffer) and a third target, deferred into ONE flush launch, against the
+    same calls with their own reduction launches: bit-identical; then the flush with the bias optimizer against Adam on the
+    immediate gradients."""
+    L = lib()
+    dt, B, H, W, Cin, Cout = BF16, 2, 32, 32, 64, 128
+    rng = np.random.default_rng(77)
+    x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+    w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+    wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+    dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+    xd, wd, wtd, dzd, dztd = dev(x, dt, gpu), dev(w, dt, gpu), dev(wt, dt, gpu), dev(dz, dt, gpu), dev(dzt, dt, gpu)
+    ws = torch.empty(8 << 18, dtype=torch.float32, device=gpu)
+    rows = torch.empty(1 << 20, dtype=torch.float32, device=gpu)
+    set_ws(ws)
+    _CTX[0].set_rowsum_buffer(rows)
+    split = 24
+    n = 256                                       # a small "arena": g | p | m | v of 256 floats, targets at offsets 0 / 64 / 128
+
+    def run(deferred, with_adam):
+        g = torch.full((n,), 5.0, device=gpu)
+        p_ = torch.linspace(-1, 1, n, device=gpu); m_ = torch.zeros(n, device=gpu); v_ = torch.zeros(n, device=gpu)
+        dx1 = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu); dx2 = torch.zeros_like(dx1)
+        if deferred:
+            L.call("gct2_rowsum_begin", ctx())
+        # launch 1 (Conv2D dgrad, halo or tap GEMM): overwrites target A = g[0:24] and target B = g[64:104]
+        L.call("gct2_conv4s2_dgrad", ctx(), dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dx1.data_ptr(), Cin, B, H, W, Cin, Cout, 0,
+               g.data_ptr(), split, g.data_ptr() + 4 * 64, 0, stream())
+        # launch 2 (Conv2DTranspose dgrad): ADDS to target B through its db2 and overwrites target C = g[128:152]
+        L.call("gct2_convT4s2_dgrad", ctx(), dt, dztd.data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dx2.data_ptr(), Cin, B, H, W, Cin, Cout, 0,
+               g.data_ptr() + 4 * 128, split, g.data_ptr() + 4 * 64, 2, stream())
+        args = None
+        if deferred:
+            if with_adam:
+                args = L.AdamArgs(p_.data_ptr(), m_.data_ptr(), v_.data_ptr(), None, 0, n, 1e-3, 0.9, 0.999, 1e-7, 1.0)
+                import ctypes
+                # target C is NOT listed: flushed to g, no optimizer step; a fourth range (200..208) was never a dgrad target:
+                # the optimizer takes the gradient the arena already holds there
+                ranges = (ctypes.c_int64 * 6)(0, split, 64, Cin - split, 200, 8)
+                L.call("gct2_rowsum_flush", ctx(), ctypes.addressof(args), g.data_ptr(), ranges, 3, stream())
+            else:
+                L.call("gct2_rowsum_flush", ctx(), None, None, None, 0, stream())
+        torch.cuda.synchronize()
+        return g, p_, m_, v_, dx1, dx2
+
+    try:
+        g_imm, *_ = run(False, False)
+        g_def, _, _, _, dx1, dx2 = run(True, False)
+        assert torch.equal(g_imm, g_def)
+        assert float(g_def[split:64].min()) == 5.0 and float(g_def[152:].min()) == 5.0           # nothing else is touched
+        ref1 = O.conv4s2_bwd(x, w, dz)[0] * (x > 0)
+        ref2 = O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)
+        cs1, cs2 = ref1.reshape(-1, Cin).sum(0), ref2.reshape(-1, Cin).sum(0)
+        scale = np.abs(ref1).reshape(-1, Cin).sum(0).max() + np.abs(ref2).reshape(-1, Cin).sum(0).max()
+        got = g_def.cpu().numpy()
+        assert np.abs(got[0:split] - cs1[:split]).max() <= 2e-3 * scale
+        assert np.abs(got[64:64 + Cin - split] - (cs1[split:] + cs2[split:])).max() <= 2e-3 * scale
+        assert np.abs(got[128:128 + split] - cs2[:split]).max() <= 2e-3 * scale
+        # the bias optimizer inside the flush == gct2_adam_keras_multi on the flushed gradients (masked to the targets)
+        g2, p2, m2, v2, *_ = run(True, True)
+        assert torch.equal(g2, g_def)
+        pr = torch.linspace(-1, 1, n, device=gpu); mr = torch.zeros(n, device=gpu); vr = torch.zeros(n, device=gpu)
+        gm = torch.zeros(n, device=gpu)
+        mask = torch.zeros(n, dtype=torch.bool, device=gpu)
+        for lo, cnt in ((0, split), (64, Cin - split), (200, 8)):
+            mask[lo:lo + cnt] = True
+        gm[mask] = g_def[mask]
+        L.call("gct2_adam_keras_multi", pr.data_ptr(), mr.data_ptr(), vr.data_ptr(), gm.data_ptr(), None, 0, n, 1e-3, 0.9, 0.999, 1e-7, 1.0, None, 0, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(p2[mask], pr[mask]) and torch.equal(m2[mask], mr[mask]) and torch.equal(v2[mask], vr[mask])
+        assert torch.equal(p2[~mask], torch.linspace(-1, 1, n, device=gpu)[~mask])               # other parameters untouched
+        with pytest.raises(L.Gct2Error):
+            L.call("gct2_rowsum_flush", ctx(), None, None, None, 0, stream())                      # no deferral open any more
+    finally:
+        _CTX[0].set_rowsum_buffer(None)
+        set_ws(None)
