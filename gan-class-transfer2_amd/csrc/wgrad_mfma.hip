@@ -714,6 +714,206 @@ __global__ __launch_bounds__(512, 2) void wgrad256p_kernel(WgradParams p) {
 #endif
 }
 
+// ---- the same pipeline with a lean stage (r03) ---------------------------------------------------------------------------------
+// wgrad256p_kernel's stage carries ~80 vector instructions besides its 32 MFMAs and 24 transposed reads (the ISA shows exec-masked
+// branches around three 64-bit multiply-adds per gathered piece, ~40 instructions that rebuild the 12 fragment addresses, a chain of
+// scalar branches for the wait count): with two lock-stepped waves per SIMD that is more than the issue slots the MFMAs leave free.
+// Here: (a) the gather addresses advance incrementally (adds and selects, no multiply, no branch: one stage = 32 rows further, with
+// carries into the next image row / image), tap validity from four precomputed per-lane flags; (b) the fragment addresses are
+// lane offsets computed ONCE, plus the stage's compile-time base; (c) ONE LDS array (the DMA is hidden inline asm, so hipcc has
+// nothing to drain); (d) a constant vmcnt in the steady state.  Same arithmetic in the same order: bit-identical results.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
+  constexpr int NST = 5;
+  constexpr int IMG = 32 * 256;                                   // one T image of a stage: 32 r-rows x 128 columns
+  constexpr int STAGE = 4 * IMG;
+  constexpr int NDMA = 4;
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wm = wave >> 2;
+  const int Hs = p.Hs, Ws = p.Ws, Cb = p.Cb, Cs = p.Cs;
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  const int R = p.B * Hs * Ws;
+  const int GC = 16 * Cb;
+  const int tiles_n = (Cs + 255) / 256;
+  const int tiles = ((GC + 255) / 256) * tiles_n;
+  int tile, split;
+  if (p.rsplit >= 8) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % tiles;
+    split = (j / tiles) * 8 + xcd;
+    if (split >= p.rsplit) return;
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
+  const int gc0 = (tile / tiles_n) * 256, cs0 = (tile % tiles_n) * 256;
+  const int steps_total = (R + 63) / 64;
+  const int steps_per = (steps_total + p.rsplit - 1) / p.rsplit;
+  const int step_lo = split * steps_per;
+  const int step_hi = min(steps_total, step_lo + steps_per);
+  if (step_lo >= step_hi) return;
+  const int st_lo = 2 * step_lo, st_hi = 2 * step_hi;
+
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.big), rs_s = make_rsrc(p.small);
+  const int row0 = 4 * wave + (lane >> 4);
+  const int lc = ((((lane & 15) >> 1) ^ timg_swz(row0)) << 1) | (lane & 1);
+  const int ldb2 = p.ldbig * 2, lds2b = p.ldsmall * 2;
+  // per image g of the big operand: byte offset of tap (kh, kw) / channel cb relative to pixel (2 sh, 2 sw), and the four cases in
+  // which the tap leaves the image: kh = 0 at the top row, kh = 3 at the bottom row, kw = 0 / 3 at the left / right column
+  // (bit masks, not bools: chains of && on per-lane conditions compile to exec-masked branches - 20 scalar branches per stage)
+  int dg[2];
+  unsigned edge[2];                                                // bit 0: kh = 0, 1: kh = 3, 2: kw = 0, 3: kw = 3; bit 4: the image is out of range
+  unsigned s_bad[2];                                               // small operand: column block out of range
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const int gc = gc0 + 128 * g + lc * 8;
+    const bool ok = gc < GC;
+    const int tap = ok ? gc / Cb : 0;
+    const int cb = ok ? gc - tap * Cb : 0;
+    const int kh = tap >> 2, kw = tap & 3;
+    dg[g] = ((kh - 1) * Wb + (kw - 1)) * ldb2 + cb * 2;
+    edge[g] = (kh == 0 ? 1u : 0u) | (kh == 3 ? 2u : 0u) | (kw == 0 ? 4u : 0u) | (kw == 3 ? 8u : 0u) | (ok ? 0u : 16u);
+    s_bad[g] = (cs0 + 128 * g + lc * 8) < Cs ? 0u : 16u;
+  }
+  // this lane's row of the current issue stage: r, its (image, row, column) on the small grid, the byte offsets of pixel (2 sh, 2 sw)
+  // of the big tensor and of row r of the small one; advanced by 32 rows per issued stage
+  const int adv_w = 32 % Ws, q1 = 32 / Ws, adv_h = q1 % Hs, adv_b = q1 / Hs;
+  const int pixA = adv_w * 2 * ldb2, pixB = Wb * ldb2, pixCD = (adv_h * 2 * Wb + adv_b * Hb * Wb) * ldb2;
+  int r = st_lo * 32 + row0;
+  int rw = r % Ws, rh, rb;
+  { const int t = r / Ws; rh = t % Hs; rb = t / Hs; }
+  unsigned pix = (unsigned)(((rb * Hb + 2 * rh) * Wb + 2 * rw) * ldb2);
+  unsigned soff = (unsigned)(r * lds2b + (cs0 + lc * 8) * 2);
+  auto issue = [&](char* base) {                                  // stages are issued in increasing order
+    // where this row sits: bit 0 top row, 1 bottom row, 2 left column, 3 right column; bit 4: beyond the last row (always "bad")
+    const unsigned pos = (rh == 0 ? 1u : 0u) | (rh == Hs - 1 ? 2u : 0u) | (rw == 0 ? 4u : 0u) | (rw == Ws - 1 ? 8u : 0u) | (r < R ? 0u : 16u);
+    char* piece = base + wave * 1024;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const unsigned badb = (edge[g] & pos & 15u) | ((edge[g] | pos) & 16u);
+      const unsigned bads = (s_bad[g] | pos) & 16u;
+      dma16_hidden(rs_b, piece + g * IMG, badb ? OOB : pix + (unsigned)dg[g]);
+      dma16_hidden(rs_s, piece + (2 + g) * IMG, bads ? OOB : soff + (unsigned)(g * 256));
+    }
+    // 32 rows further
+    r += 32; soff += (unsigned)(32 * lds2b);
+    rw += adv_w; pix += (unsigned)pixA;
+    const bool cw = rw >= Ws;
+    rw -= cw ? Ws : 0; rh += cw ? 1 : 0; pix += cw ? (unsigned)pixB : 0u;
+    rh += adv_h; rb += adv_b; pix += (unsigned)pixCD;
+    const bool ch = rh >= Hs;                                     // (into the next image: the byte offset is already right, Hb = 2 Hs)
+    rh -= ch ? Hs : 0; rb += ch ? 1 : 0;
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: lane offsets inside a stage buffer, computed once (k0 = 8 (lane>>4) + ((lane>>2)&3), two transposed reads
+  // 4 rows apart: the swizzle of row k0 + 4 equals that of row k0)
+  int sf_off[4], bf_off[8];
+  {
+    const int g4 = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    const int k0 = 8 * g4 + q;
+    const int swz = timg_swz(k0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) sf_off[j] = (2 + (wn >> 1)) * IMG + k0 * 256 + (((((wn & 1) * 64 + j * 16) >> 4) ^ swz) << 5) + pq * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) bf_off[i] = wm * IMG + k0 * 256 + ((i ^ swz) << 5) + pq * 8;
+  }
+  auto frag = [&](const char* base, int off) -> u32x4_t {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + off));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + off + 4 * 256));
+    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+    return u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+  };
+  auto compute = [&](const char* base) {
+    u32x4_t sf[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sf[j] = frag(base, sf_off[j]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const u32x4_t bf = frag(base, bf_off[i]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(sf[j], bf, acc[i][j]);
+    }
+  };
+
+  const bool live = p.rsplit > 0;                                  // opaque code-generation fence (see wgrad256p_kernel)
+  auto wait_tail = [&](int ahead) {                               // the last stages: fewer than three stages are still in flight
+    if (ahead >= 3) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(3 * NDMA));
+    else if (ahead == 2) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
+    else if (ahead == 1) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
+    else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
+  };
+  auto stage = [&](int st, const char* cur, char* tgt) {
+    const bool more = st + NST - 1 < st_hi;                        // block-uniform
+    if (more) issue(tgt);
+    if (live) compute(cur);
+    if (more) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(3 * NDMA));   // steady state: stages st+2 .. st+4 stay in flight
+    else wait_tail(st_hi - 1 - (st + 1));
+    __builtin_amdgcn_s_barrier();
+  };
+  issue(lds);
+  if (st_lo + 1 < st_hi) issue(lds + STAGE);
+  if (st_lo + 2 < st_hi) issue(lds + 2 * STAGE);
+  if (st_lo + 3 < st_hi) issue(lds + 3 * STAGE);
+  wait_tail(min(st_lo + 3, st_hi - 1) - st_lo);
+  __builtin_amdgcn_s_barrier();
+  // steady state: every stage of the trip still has a stage to issue (st + 4 + 4 < st_hi): no tail logic, one constant wait
+  auto stage_fast = [&](const char* cur, char* tgt) {
+    issue(tgt);
+    if (live) compute(cur);
+    __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(3 * NDMA));
+    __builtin_amdgcn_s_barrier();
+  };
+  int st = st_lo;
+  for (; st + 8 < st_hi; st += 5) {
+    stage_fast(lds, lds + 4 * STAGE);
+    stage_fast(lds + STAGE, lds);
+    stage_fast(lds + 2 * STAGE, lds + STAGE);
+    stage_fast(lds + 3 * STAGE, lds + 2 * STAGE);
+    stage_fast(lds + 4 * STAGE, lds + 3 * STAGE);
+  }
+  for (; st < st_hi; st += 5) {                                   // the last trips (same buffer roles: st - st_lo is a multiple of 5)
+    stage(st, lds, lds + 4 * STAGE);
+    if (st + 1 >= st_hi) break;
+    stage(st + 1, lds + STAGE, lds);
+    if (st + 2 >= st_hi) break;
+    stage(st + 2, lds + 2 * STAGE, lds + STAGE);
+    if (st + 3 >= st_hi) break;
+    stage(st + 3, lds + 3 * STAGE, lds + 2 * STAGE);
+    if (st + 4 >= st_hi) break;
+    stage(st + 4, lds + 4 * STAGE, lds + 3 * STAGE);
+  }
+  float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
+  const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int row = gc0 + wm * 128 + i * 16 + (elane & 15);
+    if (row >= GC) continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int col = cs0 + wn * 64 + j * 16 + 4 * (elane >> 4);
+      if (col >= Cs) continue;
+      float* q = out + (size_t)row * Cs + col;
+      if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
+      else if (mode == 1) { if (p.accumulate) *reinterpret_cast<f32x4_t*>(q) += acc[i][j]; else *reinterpret_cast<f32x4_t*>(q) = acc[i][j]; }
+      else {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) atomicAdd(q + rr, acc[i][j][rr]);
+      }
+    }
+  }
+}
+
 // dw[e] += sum_s slab[s][e], 4 elements per thread, slabs added in index order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n4, int nsplit,
                                                             int accumulate) {
@@ -799,7 +999,11 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   // (going further down - the small tile with ~512 work-groups for DownShuffle_1/2 and UpShuffle_1, 32 MiB of slabs each - is faster
   // launch by launch (92 -> 80, 84 -> 80, 145 -> 143 us incl. the slab sum) and SLOWER in the step: +38 us in an in-process A/B, the
   // small work-groups interleave with the input-gradient chain's instead of alternating with them)
-  const bool big_tile0 = !p.ks && (g_wgrad_variant == 2 || g_wgrad_variant == 4 || (g_wgrad_variant == 0 && tiles128 < 256 && blocks256 >= 192));
+  const bool auto_tile = g_wgrad_variant == 0 || g_wgrad_variant == 6;
+  const bool big_tile0 = !p.ks && (g_wgrad_variant == 2 || g_wgrad_variant == 4 || g_wgrad_variant == 5 || g_wgrad_variant == 8 || (auto_tile && tiles128 < c.wgrad_big_limit && blocks256 >= 192));
+  // the five-stage pipeline runs the lean stage (wgrad256q_kernel, r03: -7..-16 % on the five big-tile layers) unless the tuning
+  // word asks for the r02 stage code (variants 6 = automatic tile choice, 8 = 256 x 256 everywhere) or for four stages (bit 23)
+  const bool lean_stage = g_wgrad_variant != 6 && g_wgrad_variant != 8 && c.wgrad_ring == 5;
   // variant 4 (r03): the 256 x 128 tile at two work-groups per CU in place of the 256 x 256 pipeline
   const bool tile2x = big_tile0 && g_wgrad_variant == 4;
   const bool big_tile = big_tile0 && !tile2x;
@@ -847,6 +1051,9 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   } else if (tile2x) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad2x_kernel<__bf16>, grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL(wgrad2x_kernel<_Float16>, grid, dim3(512), 0, s, p);
+  } else if (big_tile && g_wgrad_pipe && lean_stage) {
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256q_kernel<__bf16>, grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(wgrad256q_kernel<_Float16>, grid, dim3(512), 0, s, p);
   } else if (big_tile && g_wgrad_pipe) {
     if (c.wgrad_ring == 5) {
       if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad256p_kernel<__bf16, 5>), grid, dim3(512), 0, s, p);

@@ -63,7 +63,8 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
 /* tuning (same results for every value; tests cover each tile, scripts/bench_layer.py does A/B timing).
  * bits 0-7: dgrad/forward tile, 0 = automatic, 1/2 = 128x128 with 1/2 LDS buffers, 3 = 256x128 8 waves 3 buffers,
  * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles);
- * bits 16-19: weight-gradient tile, 0 = automatic, 1/3 = 128x128 with 1/2 buffers, 2 = 256x256, 7 = atomics;
+ * bits 16-19: weight-gradient tile, 0 = automatic, 1/3 = 128x128 with 1/2 buffers, 2 (or 5) = 256x256, 4 = 256x128 at two
+ * work-groups per CU, 7 = atomics, 6 / 8 = as 0 / 2 with the r02 stage code of the 256x256 pipeline instead of the lean stage;
  * bit 22: 256x256 weight-gradient tile with two 64-row buffers instead of the four-stage pipeline;
  * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D dgrad), 0 = automatic, 1 = never, 2 = wherever the shape allows;
  * bits 26-27: tile -> XCD order of the forward / input-gradient GEMMs, 0 = automatic, 1 = bands of output pixels per XCD,

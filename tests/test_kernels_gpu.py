@@ -218,12 +218,14 @@ def test_wgrad_reduction_modes_agree(gpu, shape):
 
 
 @pytest.mark.parametrize("use_ws", [False, True])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 0x42, 0x82])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 0x42, 0x82])
 @pytest.mark.parametrize("shape", [(4, 32, 32, 64, 128), (1, 12, 20, 72, 136), (2, 8, 8, 256, 512)])
 def test_wgrad_tile_variants(gpu, variant, shape, use_ws):
     """weight-gradient tile variants: 1 = 128x128 single buffer, 2 = 256x256 (8 waves of 128x64) with the spanning pipeline (counted
-    vmcnt across raw barriers; five stage buffers, 0x82: four), 0x42 = 256x256 with two 64-row buffers, 3 = 128x128 double buffer,
-    4 = 256x128 single buffer at two work-groups per CU (r03); without a workspace (atomics) and with one (ordered slabs)."""
+    vmcnt across raw barriers; five stage buffers and the lean stage of r03 - incremental gather addresses, fragment addresses
+    computed once), 8 = the same pipeline with the r02 stage code, 0x82 = four stage buffers, 0x42 = 256x256 with two 64-row buffers,
+    3 = 128x128 double buffer, 4 = 256x128 single buffer at two work-groups per CU (r03); without a workspace (atomics) and with one
+    (ordered slabs)."""
     B, H, W, Cin, Cout = shape
     dt = BF16
     L = lib()
@@ -243,6 +245,38 @@ def test_wgrad_tile_variants(gpu, variant, shape, use_ws):
         torch.cuda.synchronize()
         assert rel_l2(dw.cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
         assert rel_l2(dwt.cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
+    finally:
+        set_tuning(0)
+        set_ws(None)
+
+
+@pytest.mark.parametrize("shape", [(3, 40, 24, 64, 128), (5, 8, 8, 128, 64), (2, 64, 64, 64, 256), (7, 4, 12, 256, 72)])
+def test_wgrad_lean_stage_equals_pipeline_bit_for_bit(gpu, shape):
+    """wgrad256q_kernel (variant 2, the default big tile) advances its gather addresses incrementally (32 rows per stage, carries into
+    the next image row and the next image) where wgrad256p_kernel (variant 8) recomputes them: same multiplies in the same order, so the fp32 results
+    must be identical - on grids narrower and wider than a stage, ragged row counts, several images per stage."""
+    B, H, W, Cin, Cout = shape
+    dt, L = BF16, lib()
+    rng = np.random.default_rng(61)
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+    dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+    xd, dzd, dztd = dev(x, dt, gpu), dev(dz, dt, gpu), dev(dzt, dt, gpu)
+    ws = torch.empty(32 << 18, dtype=torch.float32, device=gpu)
+    set_ws(ws)
+    res = {}
+    try:
+        for variant in (2, 8):
+            set_tuning(variant << 16)
+            dw = torch.zeros(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)
+            dwt = torch.zeros(4, 4, Cout, Cin, dtype=torch.float32, device=gpu)
+            L.call("gct2_conv4s2_wgrad", ctx(), dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
+            L.call("gct2_convT4s2_wgrad", ctx(), dt, xd.data_ptr(), Cin, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
+            torch.cuda.synchronize()
+            res[variant] = (dw, dwt)
+        assert torch.equal(res[2][0], res[8][0]) and torch.equal(res[2][1], res[8][1])
+        assert rel_l2(res[2][0].cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
+        assert rel_l2(res[2][1].cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
     finally:
         set_tuning(0)
         set_ws(None)
