@@ -184,7 +184,8 @@ int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   ctx->wgrad_split = (v >> 28) & 7;
   ctx->halo_il = (int)(((unsigned)v >> 31) & 1u) ? 0 : 1;
   ctx->wgrad_fuse_adam = (v & 0x100) ? 1 : 0;
-  ctx->wgrad_big_limit = (v & 0x200) ? 512 : 256;
+  ctx->wgrad_big_limit = (v & 0x200) ? 256 : 512;
+  ctx->wgrad_big_minsteps = ((v >> 10) & 3) == 1 ? 8 : ((v >> 10) & 3) == 2 ? 32 : 4;
   return GCT2_OK;
 }
 int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes) {

@@ -17,6 +17,7 @@
 // Needs Hs, Ws multiples of 16.  Epilogues: bias + ReLU (forward) or mask / accumulate / bias-gradient rows (Conv2D dgrad).
 #include "gct2_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -28,6 +29,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
 }
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
+}
+// the same with a scalar byte offset (the k-chunk / tap part of the address: wave-uniform, outside the bounds check's per-lane offset)
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, (int)soff, 0, 0);
 }
 __device__ __forceinline__ int halo_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1); }
 // Weight image: fragment i of a wave holds the output channels 32 (i>>1) + 8 g + 4 (i&1) + r in its lane group g, so that the
@@ -63,10 +68,12 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   unsigned long long st[6];
   STAMP(0);
 #endif
-  __shared__ __attribute__((aligned(16))) char halo0[HALO_BYTES];
-  __shared__ __attribute__((aligned(16))) char halo1[HALO_BYTES];
-  __shared__ __attribute__((aligned(16))) char wb0[WB_BYTES];
-  __shared__ __attribute__((aligned(16))) char wb1[WB_BYTES];
+  // ONE array, the halo images first: every fragment address of the lean rounds is a per-lane register + a 16-bit immediate
+  __shared__ __attribute__((aligned(16))) char lds_all[2 * HALO_BYTES + 2 * WB_BYTES];
+  char* const halo0 = lds_all;
+  char* const halo1 = lds_all + HALO_BYTES;
+  char* const wb0 = lds_all + 2 * HALO_BYTES;
+  char* const wb1 = lds_all + 2 * HALO_BYTES + WB_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,30 +91,27 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 
   // ---- per-lane DMA descriptors ------------------------------------------------------------------------------------
   // halo: piece pi = wave + 8 i (i < 6, pi < 41) = halo rows 8 pi .. 8 pi + 7; lane -> row 8 pi + (lane>>3), physical chunk lane&7
-  unsigned h_off[6];
-  unsigned h_ok = 0;
+  // (validity folded in: OOB lanes read zeros, and stay OOB whatever the scalar offset of the k-chunk adds)
+  unsigned h_voff[6];
   int h_lchunk[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     const int pi = wave + 8 * i;
     const int row = 8 * pi + (lane >> 3);
-    const int lchunk = (lane & 7) ^ halo_swz(row);
+    const int hy = row / HP, hx = row - hy * HP;
+    const int lchunk = (lane & 7) ^ halo_swz(hx);
     h_lchunk[i] = lchunk;
-    h_off[i] = 0;
+    h_voff[i] = OOB;
     if (pi < HPIECES && row < HP * HP) {
-      const int hy = row / HP, hx = row - hy * HP;
       const int y = sh0 - 1 + hy, x = sw0 - 1 + hx;
-      if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) {
-        h_off[i] = (unsigned)(((b * Hs + y) * Ws + x) * ldx2 + lchunk * 16);
-        h_ok |= 1u << i;
-      }
+      if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) h_voff[i] = (unsigned)(((b * Hs + y) * Ws + x) * ldx2 + lchunk * 16);
     }
   }
   // weights: piece (phase i, n-block wave): lane -> n = 8 wave + (lane>>3), physical chunk lane&7 (w_swz)
   const int w_n = 8 * wave + (lane >> 3);
   const int w_lchunk = (lane & 7) ^ w_swz(w_n);
-  const bool w_nok = (n0 + w_n) < N;
-  const unsigned w_off = (unsigned)(((n0 + w_n) * K + w_lchunk * 8) * 2);
+  const unsigned w_voff = (n0 + w_n) < N ? (unsigned)(((n0 + w_n) * K + w_lchunk * 8) * 2) : OOB;
+  const unsigned NK2 = (unsigned)(N * K * 2);
 
   const int nk = (K + 63) / 64;
   const int nround = 4 * nk;                                   // (k-chunk, tap round (a, c))
@@ -117,20 +121,18 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #pragma unroll
     for (int i = 0; i < 6; i++) {
       const int pi = wave + 8 * i;
-      if (pi < HPIECES) {                                      // wave-uniform
-        const bool ok = ((h_ok >> i) & 1u) && (c0 + h_lchunk[i] * 8) < K;
-        dma16(rs_x, hbuf + pi * 1024, ok ? h_off[i] + (unsigned)(c0 * 2) : OOB);
-      }
+      if (pi < HPIECES)                                        // wave-uniform
+        dma16s(rs_x, hbuf + pi * 1024, (c0 + h_lchunk[i] * 8) < K ? h_voff[i] : OOB, (unsigned)(c0 * 2));
     }
   };
   auto issue_w = [&](int round, char* wbuf) {
     const int kc = round >> 2, a = (round >> 1) & 1, c = round & 1;
     const int c0 = kc * 64;
-    const bool kok = w_nok && (c0 + w_lchunk * 8) < K;
+    const unsigned voff = (c0 + w_lchunk * 8) < K ? w_voff : OOB;
 #pragma unroll
     for (int i = 0; i < 4; i++) {                              // phase i = (i>>1, i&1): kernel tap (1 - ph + 2a, 1 - pw + 2c)
       const int tap16 = (1 - (i >> 1) + 2 * a) * 4 + (1 - (i & 1) + 2 * c);
-      dma16(rs_w, wbuf + i * 8192 + wave * 1024, kok ? w_off + (unsigned)((tap16 * N * K + c0) * 2) : OOB);
+      dma16s(rs_w, wbuf + i * 8192 + wave * 1024, voff, (unsigned)tap16 * NK2 + (unsigned)(c0 * 2));
     }
   };
 
@@ -140,46 +142,57 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // one piece of the above (IL): halo piece i of k-chunk kc / weight piece of phase i for `round`
-  auto issue_halo_piece = [&](int kc, char* hbuf, int i) {
-    const int pi = wave + 8 * i;
-    if (pi < HPIECES) {
-      const int c0 = kc * 64;
-      const bool ok = ((h_ok >> i) & 1u) && (c0 + h_lchunk[i] * 8) < K;
-      dma16(rs_x, hbuf + pi * 1024, ok ? h_off[i] + (unsigned)(c0 * 2) : OOB);
-    }
-  };
-  auto issue_w_piece = [&](int round, char* wbuf, int i) {
-    const int kc = round >> 2, a = (round >> 1) & 1, c = round & 1;
-    const int c0 = kc * 64;
-    const bool kok = w_nok && (c0 + w_lchunk * 8) < K;
-    const int tap16 = (1 - (i >> 1) + 2 * a) * 4 + (1 - (i & 1) + 2 * c);
-    dma16(rs_w, wbuf + i * 8192 + wave * 1024, kok ? w_off + (unsigned)((tap16 * N * K + c0) * 2) : OOB);
-  };
-  // IL form of a round: the same multiplies with the pieces of round + 1 placed behind MFMA groups
-  auto compute_il = [&](int round, const char* hbuf, const char* wbuf, char* wnext, char* hnext) {
-    const int a = (round >> 1) & 1, c = round & 1;
-    const bool more = round + 1 < nround, halo_due = more && ((round + 1) & 3) == 0;
-    int ql = q;
-    asm volatile("" : "+v"(ql));
-    const int row0 = (mhalf * 8 + ph - a + 1) * HP + (pw - c + 1) + ql;
-    const char* wimg = wbuf + phase * 8192;
+  // ---- the lean round (IL) --------------------------------------------------------------------------------------------
+  // Fragment addresses: the halo swizzle is keyed on the halo COLUMN hx = pw - c + 1 + q, which neither the tap row a nor the
+  // pixel row j changes, and the weight swizzle on bits of the channel row that the fragment index i does not touch.  So a lane
+  // needs FOUR halo addresses (tap column c x k-half kk) and TWO weight addresses for the whole K loop, and buffer, tap row, pixel
+  // row and fragment index are immediates of the ds_read (halo images first in LDS: at most 41984 + 8 * 2304 < 65536).  The r02
+  // round recomputed every address (121 vector instructions per 64 MFMAs, PMC: profiles/r03_pmc_sq_counters.txt).
+  // DMA offsets: per-lane offsets stay loop-invariant, the k-chunk and the tap go into the scalar offset of the instruction.
+  int fa[2][2], fw[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const int hx = pw - c + 1 + q;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) fa[c][kk] = (((mhalf * 8 + ph) * HP + hx) << 7) + (((4 * kk + g) ^ halo_swz(hx)) << 4);
+  }
+#pragma unroll
+  for (int kk = 0; kk < 2; kk++) {
+    const int n = w_row(0, q);
+    fw[kk] = 2 * HALO_BYTES + phase * 8192 + n * 128 + (((4 * kk + g) ^ w_swz(n)) << 4);
+  }
+  const int kfull4 = 4 * (K / 64);                             // rounds of FULL 64-channel chunks
+  // idx = round & 7 (literal at every call site: tap and buffer roles fold into immediates); hcur/hnext/wcur/wnext = byte offsets
+  // of the buffers inside their group.  FAST: every piece of the next round exists and lies in a full chunk - no tail logic.
+  auto lean_round = [&](auto fast_c, int round, int idx, int hcur, int hnext, int wcur, int wnext) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    const int a = (idx >> 1) & 1, c = idx & 1;
+    const int idn = (idx + 1) & 7, an = (idn >> 1) & 1, cn = idn & 1;
+    const bool more = FAST || round + 1 < nround;
+    const bool halo_due = (idx & 3) == 3 && more;
+    const int c0n = ((round + 1) >> 2) * 64;
+    const unsigned s_k = (unsigned)(c0n * 2);
+    const unsigned wv = FAST ? w_voff : ((c0n + w_lchunk * 8) < K ? w_voff : OOB);
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
       u32x4_t wf[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int n = w_row(i, ql);
-        wf[i] = lds_read128(wimg, n * 128 + (((4 * kk + g) ^ w_swz(n)) << 4));
-      }
+      for (int i = 0; i < 4; i++) wf[i] = lds_read128(lds_all, fw[kk] + wcur + (32 * (i >> 1) + 4 * (i & 1)) * 128);
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const int row = row0 + j * HP;
-        const u32x4_t af = lds_read128(hbuf, row * 128 + (((4 * kk + g) ^ halo_swz(row)) << 4));
+        const u32x4_t af = lds_read128(lds_all, fa[c][kk] + hcur + (1 - a + j) * HP * 128);
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i][j] = mfma16<T>(wf[i], af, acc[i][j]);
-        if (kk == 0 && (j & 1) && more) issue_w_piece(round + 1, wnext, j >> 1);
-        if (kk == 1 && j < 6 && halo_due) issue_halo_piece((round + 1) >> 2, hnext, j);
+        if (kk == 0 && (j & 1) && more) {                      // weight piece of phase i for the next round
+          const int i = j >> 1;
+          const int tap16 = (1 - (i >> 1) + 2 * an) * 4 + (1 - (i & 1) + 2 * cn);
+          dma16s(rs_w, lds_all + 2 * HALO_BYTES + wnext + i * 8192 + wave * 1024, wv, (unsigned)tap16 * NK2 + s_k);
+        }
+        if (kk == 1 && j < 6 && halo_due) {                    // halo piece j of the next k-chunk
+          const int pi = wave + 8 * j;
+          if (pi < HPIECES)
+            dma16s(rs_x, lds_all + hnext + pi * 1024, FAST ? h_voff[j] : ((c0n + h_lchunk[j] * 8) < K ? h_voff[j] : OOB), s_k);
+        }
       }
     }
   };
@@ -191,6 +204,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
     asm volatile("" : "+v"(ql));
     // source pixel of output (sh, sw), phase (ph, pw), tap (a, c) = (sh + ph - a, sw + pw - c); halo origin = (sh0-1, sw0-1)
     const int row0 = (mhalf * 8 + ph - a + 1) * HP + (pw - c + 1) + ql;
+    const int key = halo_swz(pw - c + 1 + ql);                 // keyed on the halo column (HP is even: the row parity is the column's)
     const char* wimg = wbuf + phase * 8192;
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int row = row0 + j * HP;
-        const u32x4_t af = lds_read128(hbuf, row * 128 + (((4 * kk + g) ^ halo_swz(row)) << 4));
+        const u32x4_t af = lds_read128(hbuf, row * 128 + (((4 * kk + g) ^ key) << 4));
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i][j] = mfma16<T>(wf[i], af, acc[i][j]);
       }
@@ -218,29 +232,49 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #define GCT2_HALO_ROUND(R, HCUR, WCUR, WNEXT, HNEXT)                                         \
   {                                                                                          \
     const int r_ = (R);                                                                      \
-    if constexpr (IL) {                                                                      \
-      compute_il(r_, HCUR, WCUR, WNEXT, HNEXT);                                              \
-    } else {                                                                                 \
-      if (r_ + 1 < nround) {                                                                 \
-        issue_w(r_ + 1, WNEXT);                                                              \
-        if (((r_ + 1) & 3) == 0) issue_halo((r_ + 1) >> 2, HNEXT);                           \
-      }                                                                                      \
-      compute(r_, HCUR, WCUR);                                                               \
+    if (r_ + 1 < nround) {                                                                   \
+      issue_w(r_ + 1, WNEXT);                                                                \
+      if (((r_ + 1) & 3) == 0) issue_halo((r_ + 1) >> 2, HNEXT);                             \
     }                                                                                        \
+    compute(r_, HCUR, WCUR);                                                                 \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
     __syncthreads();                                                                         \
     if (r_ + 1 >= nround) break;                                                             \
   }
-  for (int r = 0; r < nround; r += 8) {
-    GCT2_HALO_ROUND(r + 0, halo0, wb0, wb1, halo1)
-    GCT2_HALO_ROUND(r + 1, halo0, wb1, wb0, halo1)
-    GCT2_HALO_ROUND(r + 2, halo0, wb0, wb1, halo1)
-    GCT2_HALO_ROUND(r + 3, halo0, wb1, wb0, halo1)
-    GCT2_HALO_ROUND(r + 4, halo1, wb0, wb1, halo0)
-    GCT2_HALO_ROUND(r + 5, halo1, wb1, wb0, halo0)
-    GCT2_HALO_ROUND(r + 6, halo1, wb0, wb1, halo0)
-    GCT2_HALO_ROUND(r + 7, halo1, wb1, wb0, halo0)
+#define GCT2_LEAN_ROUND(FAST, R, IDX, HCUR, HNEXT, WCUR, WNEXT)                              \
+  {                                                                                          \
+    lean_round(std::integral_constant<bool, FAST>{}, (R), IDX, HCUR, HNEXT, WCUR, WNEXT);    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+    __syncthreads();                                                                         \
+    if (!FAST && (R) + 1 >= nround) break;                                                   \
   }
+#define GCT2_LEAN_TRIP(FAST)                                                                 \
+  GCT2_LEAN_ROUND(FAST, r + 0, 0, 0, HALO_BYTES, 0, WB_BYTES)                                \
+  GCT2_LEAN_ROUND(FAST, r + 1, 1, 0, HALO_BYTES, WB_BYTES, 0)                                \
+  GCT2_LEAN_ROUND(FAST, r + 2, 2, 0, HALO_BYTES, 0, WB_BYTES)                                \
+  GCT2_LEAN_ROUND(FAST, r + 3, 3, 0, HALO_BYTES, WB_BYTES, 0)                                \
+  GCT2_LEAN_ROUND(FAST, r + 4, 4, HALO_BYTES, 0, 0, WB_BYTES)                                \
+  GCT2_LEAN_ROUND(FAST, r + 5, 5, HALO_BYTES, 0, WB_BYTES, 0)                                \
+  GCT2_LEAN_ROUND(FAST, r + 6, 6, HALO_BYTES, 0, 0, WB_BYTES)                                \
+  GCT2_LEAN_ROUND(FAST, r + 7, 7, HALO_BYTES, 0, WB_BYTES, 0)
+  if constexpr (IL) {
+    int r = 0;
+    for (; r + 8 < kfull4; r += 8) { GCT2_LEAN_TRIP(true) }   // every round of the trip issues a full next round
+    for (; r < nround; r += 8) { GCT2_LEAN_TRIP(false) }      // the last trips: runtime tail logic, same buffer roles
+  } else {
+    for (int r = 0; r < nround; r += 8) {
+      GCT2_HALO_ROUND(r + 0, halo0, wb0, wb1, halo1)
+      GCT2_HALO_ROUND(r + 1, halo0, wb1, wb0, halo1)
+      GCT2_HALO_ROUND(r + 2, halo0, wb0, wb1, halo1)
+      GCT2_HALO_ROUND(r + 3, halo0, wb1, wb0, halo1)
+      GCT2_HALO_ROUND(r + 4, halo1, wb0, wb1, halo0)
+      GCT2_HALO_ROUND(r + 5, halo1, wb1, wb0, halo0)
+      GCT2_HALO_ROUND(r + 6, halo1, wb0, wb1, halo0)
+      GCT2_HALO_ROUND(r + 7, halo1, wb1, wb0, halo0)
+    }
+  }
+#undef GCT2_LEAN_TRIP
+#undef GCT2_LEAN_ROUND
 #undef GCT2_HALO_ROUND
 
   // ---- epilogue: lane holds out[pixel (row mhalf*8 + j, col q)][n = n0 + 32 (i>>1) + 8 g + 4 (i&1) + r], phase (ph, pw) ----

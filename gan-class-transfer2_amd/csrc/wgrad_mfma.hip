@@ -990,7 +990,7 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   // (fewer than 512 tiles): measured -10..-22 % on U0/U1/U2/D1/D2 (profiles/r01_wgrad_variants.txt)
   const int tiles128 = ((taps * p.Cb + 127) / 128) * ((p.Cs + 127) / 128);
   const int tiles256 = ((taps * p.Cb + 255) / 256) * ((p.Cs + 255) / 256);
-  const int blocks256 = tiles256 * std::max(1, std::min((g_wgrad_target + tiles256 - 1) / tiles256, ((R + 63) / 64) / 4));
+  const int blocks256 = tiles256 * std::max(1, std::min((g_wgrad_target + tiles256 - 1) / tiles256, ((R + 63) / 64) / c.wgrad_big_minsteps));
   // ... and only if the big tiling still yields ~one work-group per CU (the 2x2 / 4x4 bottleneck levels have too few pixels)
   // ... and only below 256 small tiles: from there on the 128 x 128 tiling fills the chip with at most TWO pixel splits, and a
   // big-tile launch always leaves 256 work-groups x 256 KiB = 64 MiB of slabs (written here, read back by the optimizer), whatever
@@ -999,6 +999,8 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   // (going further down - the small tile with ~512 work-groups for DownShuffle_1/2 and UpShuffle_1, 32 MiB of slabs each - is faster
   // launch by launch (92 -> 80, 84 -> 80, 145 -> 143 us incl. the slab sum) and SLOWER in the step: +38 us in an in-process A/B, the
   // small work-groups interleave with the input-gradient chain's instead of alternating with them)
+  // r03: with the lean stage the big tile wins UpShuffle_2 too (140 -> 130 us) and the limit moved to 512 small tiles: DownShuffle_3/4
+  // come along (47 -> 52, 18 -> 35 us alone) and the step is still 14 us shorter (profiles/r03_step_ab.txt); tuning bit 9 = the r02 limit
   const bool auto_tile = g_wgrad_variant == 0 || g_wgrad_variant == 6;
   const bool big_tile0 = !p.ks && (g_wgrad_variant == 2 || g_wgrad_variant == 4 || g_wgrad_variant == 5 || g_wgrad_variant == 8 || (auto_tile && tiles128 < c.wgrad_big_limit && blocks256 >= 192));
   // the five-stage pipeline runs the lean stage (wgrad256q_kernel, r03: -7..-16 % on the five big-tile layers) unless the tuning

@@ -74,6 +74,10 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * bit 8: apply the fused optimizer step (gct2_adam_args) INSIDE the epilogue of weight-gradient launches whose tiles have one owner
  * (the gradient never leaves the registers: 8 B per parameter less traffic; measured +70 us per step - the epilogue's p/m/v round
  * trips hold the matrix-core work-groups - so off by default: the step runs the streaming Adam launch behind the gradient);
+ * bit 9: automatic weight-gradient tile as in r02 (256x256 below 256 small tiles; default since r03 with the lean stage: below 512,
+ * which moves UpShuffle_2 and DownShuffle_3/4 to the big tile: -14 us per step in two in-process A/Bs although DownShuffle_4 alone
+ * is slower that way - one work-group per CU alternates better with the input-gradient chain on the other stream);
+ * bits 10-11: the big tile only with at least 4 (0) / 8 (1) / 32 (2) 64-row steps per pixel split (A/B knob, all within 7 us);
  * bit 23: FOUR stage buffers instead of five (all 160 KiB of LDS, the default since r03: +3..7 % on the two largest layers) in the
  * 256x256 weight-gradient pipeline;
  * bit 31: halo-tile kernel with the DMA of the next round issued in FRONT of the current round's MFMAs (r02) instead of between
