@@ -185,6 +185,7 @@ int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   ctx->halo_il = (int)(((unsigned)v >> 31) & 1u) ? 0 : 1;
   ctx->wgrad_fuse_adam = (v & 0x100) ? 1 : 0;
   ctx->wgrad_big_limit = (v & 0x200) ? 256 : 512;
+  ctx->halo_conv_auto = (v & 0x1000) ? 1 : 0;
   ctx->wgrad_big_minsteps = ((v >> 10) & 3) == 1 ? 8 : ((v >> 10) & 3) == 2 ? 32 : 4;
   return GCT2_OK;
 }

@@ -44,6 +44,7 @@ struct gct2_ctx {
   int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 24;
   int wgrad_ring = 5;                              // stage buffers of the 256 x 256 weight-gradient pipeline (5 = all of the LDS; 4: A/B)
   int wgrad_fuse_adam = 0;                         // 1: one-owner weight-gradient tiles apply the fused optimizer step in their epilogue (measured +70 us per step: off)
+  int halo_conv_auto = 0;         // 1: FORM_CONV launches with full 256-channel tiles take the conv-form halo kernel (tuning bit 12; off: measured slower)
   int wgrad_big_minsteps = 4;     // ... and only with at least this many 64-row steps per pixel split (tuning bits 10-11: 8, 32)
   int wgrad_big_limit = 512;      // automatic weight-gradient tile: 256 x 256 below this many 128 x 128 tiles (tuning bit 9: 256, the r02 rule)
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows

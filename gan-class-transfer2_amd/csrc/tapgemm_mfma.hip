@@ -1011,6 +1011,8 @@ bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {
 
 bool halo_convT_wanted(const gct2_ctx& c, int epi, const TapGemmParams& p);      // halo_mfma.hip
 int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s);
+bool halo_conv_wanted(const gct2_ctx& c, int epi, const TapGemmParams& p);       // halo_conv_mfma.hip
+int halo_conv(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s);
 
 // the ordered row reduction of the fused bias gradients, for the other translation units that leave partial rows
 int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, hipStream_t s) {
@@ -1026,6 +1028,7 @@ int tapgemm_mfma(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmP
     return dispatch<_Float16>(c, form, epi, p, s);
   }
   if (form == FORM_CONVT && c.tap_variant == 0 && halo_convT_wanted(c, epi, p)) return halo_convT(c, dtype, epi, p, s);
+  if (form == FORM_CONV && c.tap_variant == 0 && halo_conv_wanted(c, epi, p)) return halo_conv(c, dtype, epi, p, s);
   if (dtype == GCT2_BF16) return dispatch<__bf16>(c, form, epi, p, s);
   return dispatch<_Float16>(c, form, epi, p, s);
 }

@@ -78,6 +78,8 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * which moves UpShuffle_2 and DownShuffle_3/4 to the big tile: -14 us per step in two in-process A/Bs although DownShuffle_4 alone
  * is slower that way - one work-group per CU alternates better with the input-gradient chain on the other stream);
  * bits 10-11: the big tile only with at least 4 (0) / 8 (1) / 32 (2) 64-row steps per pixel split (A/B knob, all within 7 us);
+ * bit 12: Conv2D forward / Conv2DTranspose input gradient take the conv-form halo kernel (r03, halo_conv_mfma.hip) where the output
+ * grid tiles into 16x16 patches with full 256-channel tiles (off by default: measured 0..12 % slower than the tap GEMM);
  * bit 23: FOUR stage buffers instead of five (all 160 KiB of LDS, the default since r03: +3..7 % on the two largest layers) in the
  * 256x256 weight-gradient pipeline;
  * bit 31: halo-tile kernel with the DMA of the next round issued in FRONT of the current round's MFMAs (r02) instead of between

@@ -832,6 +832,72 @@ def test_conv_dgrad_halo_kernel(gpu, shape, use_ws, il):
         set_ws(None)
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 256), (1, 64, 32, 48, 72), (3, 32, 64, 16, 264), (1, 32, 32, 128, 8)])
+def test_conv_fwd_halo_kernel(gpu, dt, shape):
+    """conv-form halo kernel (r03) as the Conv2D forward: the 4x4 / stride-2 window through the space-to-depth view of its source
+    (18 x 18 block halo per 16-channel chunk, weights as T images); forced on (tuning bits 24-25 = 2) and the default path, each
+    compared with the oracle on a strided output view; shapes cover one and several patches per image in both directions, several
+    images, K = 16 .. 128 (one chunk, odd numbers of chunks), ragged and tiny N (idle channel quarters), more than one channel tile."""
+    B, H, W, Cin, Cout = shape
+    L = lib()
+    rng = np.random.default_rng(71)
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+    b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+    xd, wd, bd = dev(x, dt, gpu), dev(w, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
+    ref = np.maximum(O.conv4s2_fwd(x, w, b), 0)
+    outs = []
+    for mode in ((2 << 24), 0):                                  # conv-form halo forced / the tap GEMM (automatic choice)
+        set_tuning(mode)
+        try:
+            ld = Cout + 16
+            yt = torch.full((B, H // 2, W // 2, ld), 7.0, dtype=TDT[dt], device=gpu)
+            L.call("gct2_conv4s2_fwd", ctx(), dt, xd.data_ptr(), Cin, wd.data_ptr(), bd.data_ptr(), yt.data_ptr() + 8 * yt.element_size(), ld,
+                   B, H, W, Cin, Cout, 1, stream())
+            torch.cuda.synchronize()
+        finally:
+            set_tuning(0)
+        assert rel_l2(yt[..., 8:8 + Cout].double().cpu().numpy(), ref) <= TOL_OUT[dt], mode
+        assert float((yt[..., :8].float() - 7).abs().max()) == 0 and float((yt[..., 8 + Cout:].float() - 7).abs().max()) == 0
+        outs.append(yt)
+    assert rel_l2(outs[0].double().cpu().numpy(), outs[1].double().cpu().numpy()) <= TOL_OUT[dt]
+
+
+@pytest.mark.parametrize("use_ws", [False, True])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 256, 32), (1, 16, 32, 72, 48), (2, 32, 16, 520, 16)])
+def test_convT_dgrad_halo_kernel(gpu, shape, use_ws):
+    """the conv-form halo kernel as the Conv2DTranspose input gradient (mask, accumulation into a running buffer, fused bias
+    gradients with the split at db_split, partial rows with a workspace / atomics without): forced on and compared with the oracle."""
+    B, H, W, Cin, Cout = shape                     # dgrad output [B,H,W,Cin] (the SMALL grid, 16 x 16 patches); dz on [B,2H,2W,Cout]
+    dt = BF16
+    L = lib()
+    ws = torch.empty(8 << 18, dtype=torch.float32, device=gpu)
+    set_ws(ws if use_ws else None)
+    set_tuning(2 << 24)
+    try:
+        rng = np.random.default_rng(73)
+        x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+        wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+        dz = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+        prev = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+        contrib = O.convT4s2_bwd(x, wt, dz)[0] * (x > 0)
+        split = (Cin // 2) // 8 * 8
+        dxd, dzd, wd, xd = dev(prev, dt, gpu), dev(dz, dt, gpu), dev(wt, dt, gpu), dev(x, dt, gpu)
+        db = torch.full((split,), 3.0, device=gpu); db2 = torch.full((Cin - split,), -1.0, device=gpu)
+        L.call("gct2_convT4s2_dgrad", ctx(), dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin,
+               dxd.data_ptr(), Cin, B, H, W, Cin, Cout, 1, db.data_ptr(), split, db2.data_ptr(), 3, stream())
+        torch.cuda.synchronize()
+        cs = contrib.reshape(-1, Cin).sum(0)
+        scale = np.abs(contrib).reshape(-1, Cin).sum(0).max()
+        assert np.abs(db.cpu().numpy() - 3.0 - cs[:split]).max() <= 2e-3 * scale
+        assert np.abs(db2.cpu().numpy() + 1.0 - cs[split:]).max() <= 2e-3 * scale
+        assert rel_l2(dxd.double().cpu().numpy(), contrib + prev) <= TOL_OUT[dt]
+    finally:
+        set_tuning(0)
+        set_ws(None)
+
+
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64, 128), (2, 8, 8, 256, 512), (1, 16, 16, 3, 128)])
