@@ -186,7 +186,8 @@ int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   ctx->wgrad_fuse_adam = (v & 0x100) ? 1 : 0;
   ctx->wgrad_big_limit = (v & 0x200) ? 256 : 512;
   ctx->halo_conv_auto = (v & 0x1000) ? 1 : 0;
-  ctx->wgrad_big_minsteps = ((v >> 10) & 3) == 1 ? 8 : ((v >> 10) & 3) == 2 ? 32 : 4;
+  ctx->stagger = (v >> 13) & 7;
+  ctx->wgrad_big_minsteps = ((v >> 10) & 3) == 1 ? 4 : ((v >> 10) & 3) == 2 ? 32 : 8;
   return GCT2_OK;
 }
 int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes) {

@@ -44,8 +44,9 @@ struct gct2_ctx {
   int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 24;
   int wgrad_ring = 5;                              // stage buffers of the 256 x 256 weight-gradient pipeline (5 = all of the LDS; 4: A/B)
   int wgrad_fuse_adam = 0;                         // 1: one-owner weight-gradient tiles apply the fused optimizer step in their epilogue (measured +70 us per step: off)
+  int stagger = 0;                // one-work-group-per-CU kernels: start offset between CU groups, units of 2048 cycles (tuning bits 13-15)
   int halo_conv_auto = 0;         // 1: FORM_CONV launches with full 256-channel tiles take the conv-form halo kernel (tuning bit 12; off: measured slower)
-  int wgrad_big_minsteps = 4;     // ... and only with at least this many 64-row steps per pixel split (tuning bits 10-11: 8, 32)
+  int wgrad_big_minsteps = 8;     // ... and only with at least this many 64-row steps per pixel split (tuning bits 10-11: 4, 32)
   int wgrad_big_limit = 512;      // automatic weight-gradient tile: 256 x 256 below this many 128 x 128 tiles (tuning bit 9: 256, the r02 rule)
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
   int halo_il = 1;                                 // halo kernel: DMA pieces interleaved with the MFMA groups (0: in front of them, A/B)
@@ -219,6 +220,7 @@ struct TapGemmParams {
   float* dbws;                           // partial bias-gradient rows [m_tiles*phases | finalize rows][N] in the workspace, or null (atomics)
   HeadFuse head;                         // EPI_HEAD only
   int ks = 0;                            // FORM_S1 / FORM_S1T: kernel size (odd, <= 5)
+  int stagger = 0;                       // halo kernels: see stagger_start()
   int ws_shift = -1, hs_shift = -1;      // log2 of Ws / Hs when they are powers of two (filled by the launcher), else -1: the per-lane
                                          // pixel decode then uses shifts instead of four integer divisions per row
 #ifdef GCT2_STAMP
@@ -238,6 +240,16 @@ __device__ __forceinline__ void decode_pixel(int m, int Hs, int Ws, int hs_shift
     const int t = m / Ws;
     sh = t % Hs;
     b = t / Hs;
+  }
+}
+
+// One work-group per CU and equal tiles put the prologue loads and epilogue stores of ALL CUs in lockstep: the chip alternates between
+// an MFMA phase without HBM traffic and an HBM burst without MFMAs.  A start offset between four groups of CUs (first generation
+// only: the later work-groups inherit it) spreads the bursts; `units` x 2048 cycles per group index.
+__device__ __forceinline__ void stagger_start(int units) {
+  if (units > 0 && blockIdx.x < 256u) {                        // wave-uniform
+    const int n = (int)((blockIdx.x >> 3) & 3u) * units;
+    for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(32);
   }
 }
 
@@ -297,6 +309,7 @@ struct WgradParams {
   float* ws;                      // partial-tile slabs [rsplit][16*Cb][Cs] in the registered workspace, or null (atomics)
   int accumulate;                 // 1: dw += result (caller keeps a running / pre-zeroed gradient); 0: dw = result
   int ks = 0;                     // 0: the 4x4 / stride-2 layers; odd ks: 'same' stride-1 convolution (both tensors on one grid, ks*ks taps)
+  int stagger = 0;                // 256 x 256 pipeline: see stagger_start()
   AdamFuse adam;                  // one-owner tiles only (filled by wgrad_mfma when the caller asked for the fused optimizer step)
 #ifdef GCT2_STAMP
   unsigned long long* stamps = nullptr;   // diagnostic build: phase stamps of one wave per work-group (gct2_ctx_set_stamp_buffer)

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   const int tx_n = Ws >> 4, ty_n = Hs >> 4;
   int m_tile, n_tile;
   if (!xcd_tile((int)blockIdx.x, p.m_tiles, p.n_tiles, p.xcd_chunk, m_tile, n_tile)) return;
+  stagger_start(p.stagger);
   const int tx = m_tile % tx_n, tq = m_tile / tx_n, ty = tq % ty_n, b = tq / ty_n;
   const int sh0 = ty * 16, sw0 = tx * 16, n0 = n_tile * 64;
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x), rs_w = make_rsrc(p.w);
@@ -598,6 +599,7 @@ int halo_head(const gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* d
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   p.ksplit = 1;
   p.dbws = nullptr;
+  p.stagger = c.stagger;
   p.head.part = c.ws;
 #ifdef GCT2_STAMP
   p.stamps = c.stamps;
@@ -618,6 +620,7 @@ int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   p.ksplit = 1;
   p.dbws = nullptr;
+  p.stagger = c.stagger;
   float* deferred = nullptr;
   if (epi == EPI_MASK && (p.db || p.db2)) {      // partial bias-gradient rows at the tail of the workspace, one per work-group row
     const size_t ws_bytes = c.ws_bytes;

@@ -751,6 +751,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
   }
   const int gc0 = (tile / tiles_n) * 256, cs0 = (tile % tiles_n) * 256;
   const int steps_total = (R + 63) / 64;
+  stagger_start(p.stagger);
   const int steps_per = (steps_total + p.rsplit - 1) / p.rsplit;
   const int step_lo = split * steps_per;
   const int step_hi = min(steps_total, step_lo + steps_per);
@@ -999,8 +1000,9 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   // (going further down - the small tile with ~512 work-groups for DownShuffle_1/2 and UpShuffle_1, 32 MiB of slabs each - is faster
   // launch by launch (92 -> 80, 84 -> 80, 145 -> 143 us incl. the slab sum) and SLOWER in the step: +38 us in an in-process A/B, the
   // small work-groups interleave with the input-gradient chain's instead of alternating with them)
-  // r03: with the lean stage the big tile wins UpShuffle_2 too (140 -> 130 us) and the limit moved to 512 small tiles: DownShuffle_3/4
-  // come along (47 -> 52, 18 -> 35 us alone) and the step is still 14 us shorter (profiles/r03_step_ab.txt); tuning bit 9 = the r02 limit
+  // r03: with the lean stage the big tile wins UpShuffle_2 too (140 -> 130 us) and the limit moved to 512 small tiles: DownShuffle_3
+  // comes along (47 -> 52 us alone) and the step is still 11 us shorter (profiles/r03_step_ab.txt); tuning bit 9 = the r02 limit.
+  // DownShuffle_4 (16 steps of 64 rows) stays on the one-owner 128 x 128 tile: c.wgrad_big_minsteps = 8 steps per split
   const bool auto_tile = g_wgrad_variant == 0 || g_wgrad_variant == 6;
   const bool big_tile0 = !p.ks && (g_wgrad_variant == 2 || g_wgrad_variant == 4 || g_wgrad_variant == 5 || g_wgrad_variant == 8 || (auto_tile && tiles128 < c.wgrad_big_limit && blocks256 >= 192));
   // the five-stage pipeline runs the lean stage (wgrad256q_kernel, r03: -7..-16 % on the five big-tile layers) unless the tuning
@@ -1022,6 +1024,7 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   rsplit = (steps_total + per - 1) / per;            // every split non-empty (each one owns a slab)
   p.rsplit = rsplit;
   p.ws = nullptr;
+  p.stagger = c.stagger;
 #ifdef GCT2_STAMP
   p.stamps = c.stamps;
 #endif

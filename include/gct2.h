@@ -75,11 +75,13 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * (the gradient never leaves the registers: 8 B per parameter less traffic; measured +70 us per step - the epilogue's p/m/v round
  * trips hold the matrix-core work-groups - so off by default: the step runs the streaming Adam launch behind the gradient);
  * bit 9: automatic weight-gradient tile as in r02 (256x256 below 256 small tiles; default since r03 with the lean stage: below 512,
- * which moves UpShuffle_2 and DownShuffle_3/4 to the big tile: -14 us per step in two in-process A/Bs although DownShuffle_4 alone
- * is slower that way - one work-group per CU alternates better with the input-gradient chain on the other stream);
- * bits 10-11: the big tile only with at least 4 (0) / 8 (1) / 32 (2) 64-row steps per pixel split (A/B knob, all within 7 us);
+ * which moves UpShuffle_2 and DownShuffle_3 to the big tile: -11..-14 us per step in in-process A/Bs);
+ * bits 10-11: the big tile only with at least 8 (0, default) / 4 (1) / 32 (2) 64-row steps per pixel split (4 also moves
+ * DownShuffle_4 to the big tile: the step is within 3 us of the default, the launch moves 164 MB instead of 36 MB);
  * bit 12: Conv2D forward / Conv2DTranspose input gradient take the conv-form halo kernel (r03, halo_conv_mfma.hip) where the output
  * grid tiles into 16x16 patches with full 256-channel tiles (off by default: measured 0..12 % slower than the tap GEMM);
+ * bits 13-15: start offset between four groups of CUs in the one-work-group-per-CU kernels (halo tile, 256x256 weight gradients), units
+ * of 2048 cycles; 0 = off (measured: no gain, profiles/r03_stagger.txt);
  * bit 23: FOUR stage buffers instead of five (all 160 KiB of LDS, the default since r03: +3..7 % on the two largest layers) in the
  * 256x256 weight-gradient pipeline;
  * bit 31: halo-tile kernel with the DMA of the next round issued in FRONT of the current round's MFMAs (r02) instead of between

@@ -17,7 +17,7 @@ LAYERS = {  # name: (kind, H, W, Cin, Cout) with H, W = spatial size of the laye
 }
 def run(name, code, iters=20):
     kind, H, W, Cin, Cout = LAYERS[name]
-    CTX.set_tuning(code << 16)
+    CTX.set_tuning((code << 16) | int(os.environ.get("TUNE_OR", "0"), 0))   # TUNE_OR: bits outside 16-23 (e.g. the stagger units)
     bf = torch.bfloat16
     s = torch.cuda.current_stream().cuda_stream
     if kind == "conv":

@@ -7,7 +7,7 @@ Optional third pass (--pmc TCC_HIT_sum TCC_MISS_sum): the L2 hit rate of every e
 usage: python scripts/collect_traffic_layers.py <fetch_dir> <write_dir> <plan.json> <out.json> [<l2_dir>]"""
 import csv, glob, json, re, sys
 
-MAIN = re.compile(r"tapgemm_kernel|halo_convT_kernel|wgrad256p?_kernel|wgrad_kernel")
+MAIN = re.compile(r"tapgemm_kernel|halo_convT_kernel|halo_conv_kernel|wgrad256[pq]?_kernel|wgrad2x_kernel|wgrad_kernel")
 HELP = re.compile(r"tapgemm_finalize_kernel|dbpart_reduce_kernel|wgrad_reduce_kernel")
 
 def per_entry(d, counter, K, n):
