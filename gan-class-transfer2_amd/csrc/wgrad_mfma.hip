@@ -991,7 +991,10 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   // (fewer than 512 tiles): measured -10..-22 % on U0/U1/U2/D1/D2 (profiles/r01_wgrad_variants.txt)
   const int tiles128 = ((taps * p.Cb + 127) / 128) * ((p.Cs + 127) / 128);
   const int tiles256 = ((taps * p.Cb + 255) / 256) * ((p.Cs + 255) / 256);
-  const int blocks256 = tiles256 * std::max(1, std::min((g_wgrad_target + tiles256 - 1) / tiles256, ((R + 63) / 64) / c.wgrad_big_minsteps));
+  // (the r03 band of 256 .. 511 small tiles asks for c.wgrad_big_minsteps = 8 steps per split; below 256 the r02 rule - 4 - stays:
+  // a small-batch UpShuffle_0 would otherwise fall to 48 pixel splits of the small tile, i.e. to atomics)
+  const int minsteps = tiles128 < 256 ? std::min(4, c.wgrad_big_minsteps) : c.wgrad_big_minsteps;
+  const int blocks256 = tiles256 * std::max(1, std::min((g_wgrad_target + tiles256 - 1) / tiles256, ((R + 63) / 64) / minsteps));
   // ... and only if the big tiling still yields ~one work-group per CU (the 2x2 / 4x4 bottleneck levels have too few pixels)
   // ... and only below 256 small tiles: from there on the 128 x 128 tiling fills the chip with at most TWO pixel splits, and a
   // big-tile launch always leaves 256 work-groups x 256 KiB = 64 MiB of slabs (written here, read back by the optimizer), whatever
