@@ -10,7 +10,7 @@ import os
 
 F32, BF16, F16 = 0, 1, 2
 DTYPE_NAMES = {F32: "f32", BF16: "bf16", F16: "f16"}
-ABI_VERSION = 12
+ABI_VERSION = 13
 # gct2_diffusion_update modes (include/gct2.h; the sampler's objective switches, train.py:29-32)
 SAMPLE_X, SAMPLE_EPS, SAMPLE_SCALED_EPS, SAMPLE_ODE = 0, 1, 2, 3
 BUILD_STAMP = 1
@@ -50,6 +50,7 @@ SIGNATURES = {
     "gct2_ctx_set_tuning": [_vp, _i],
     "gct2_ctx_force_direct": [_vp, _i],
     "gct2_ctx_set_stamp_buffer": [_vp, _vp, _sz],
+    "gct2_ctx_set_relu_bits": [_vp, _vp, _i],
     "gct2_ctx_set_rowsum_buffer": [_vp, _vp, _sz],
     "gct2_rowsum_begin": [_vp],
     "gct2_rowsum_flush": [_vp, _vp, _vp, _vp, _i, _vp],
@@ -145,6 +146,11 @@ class Context:
         # bumped by every setter: whoever caches something that bakes in this context's pointers or tile choices (the sampler's
         # HIP graphs of the forward pass) keys its cache on it
         self.version = 0
+
+    def set_relu_bits(self, ptr, ld_bytes: int) -> None:
+        """ReLU bit plane for the NEXT forward (written) / input-gradient (read instead of act) call of this context; one-shot.
+        `ptr` is a device address inside a caller-owned uint8 tensor [pixels, ld_bytes] (None clears a pending plane)."""
+        call("gct2_ctx_set_relu_bits", self.handle, ptr, int(ld_bytes) if ptr is not None else 0)
 
     def set_stamp_buffer(self, tensor) -> None:
         """diagnostic builds only (gct2_build_flags() & BUILD_STAMP): where the next stamped launch writes its phase stamps."""

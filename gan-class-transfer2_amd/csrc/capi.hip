@@ -15,6 +15,8 @@ bool halo_head_supported(const gct2_ctx& c, int dtype, const TapGemmParams& p);
 int halo_head(const gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, float* loss, float* db_up, int accumulate, hipStream_t s);
 bool rgb_fwd_supported(int dtype, const TapGemmParams& p);
 int rgb_fwd(int dtype, const TapGemmParams& p, hipStream_t s);
+bool rgb_fwd_writes_bits(const TapGemmParams& p);
+int pw_relu_bits(int dtype, const void* y, int ldy, size_t pixels, int channels, unsigned char* bits, int ldbits, hipStream_t s);   // pointwise.hip
 bool rgb_wgrad_supported(int dtype, const WgradParams& p);
 int rgb_wgrad(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer);
 int pw_rng_uniform_int(uint64_t, uint64_t, uint64_t, int32_t*, size_t, int, int, hipStream_t);
@@ -78,6 +80,21 @@ int check_conv_args(const char* fn, int dtype, const void* a, const void* b, con
   return GCT2_OK;
 }
 inline const gct2_ctx& C(const gct2_ctx* c) { return c ? *c : g_default_ctx; }
+// the ReLU bit plane registered for THIS call (gct2_ctx_set_relu_bits is one-shot): moved into the launch parameters, cleared in the ctx
+int take_relu_bits(const gct2_ctx& c, const char* fn, int channels, TapGemmParams& p) {
+  unsigned char* bits = c.relu_bits;
+  const int ld = c.relu_ldbits;
+  c.relu_bits = nullptr; c.relu_ldbits = 0; c.relu_bits_done = 0;
+  if (!bits) return GCT2_OK;
+  if (channels % 8 || ld < channels / 8) return gct2_fail(GCT2_EINVAL, "%s: ReLU bit plane needs channels %% 8 == 0 and ld_bytes >= channels / 8 (got %d, %d)", fn, channels, ld);
+  p.bits = bits; p.ldbits = ld;
+  return GCT2_OK;
+}
+// forward calls: if the launch did not write the plane in its epilogue, derive it from the activation it stored
+int finish_relu_bits(const gct2_ctx& c, int dtype, const TapGemmParams& p, size_t pixels, void* stream) {
+  if (!p.bits || c.relu_bits_done) return GCT2_OK;
+  return pw_relu_bits(dtype, p.y, p.ldy, pixels, p.N, p.bits, p.ldbits, S(stream));
+}
 int run_tapgemm(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, void* stream) {
   if (!c.force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(c, dtype, form, epi, p, S(stream));
   return tapgemm_direct(dtype, form, epi, p, S(stream));
@@ -137,7 +154,7 @@ int adam_after_wgrad(const gct2_adam_args* a, float* dw, size_t nw, const WgradS
 
 extern "C" {
 
-int gct2_abi_version(void) { return 12; }
+int gct2_abi_version(void) { return 13; }
 int gct2_build_flags(void) {
 #ifdef GCT2_STAMP
   return GCT2_BUILD_STAMP;
@@ -177,7 +194,7 @@ int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   ctx->wgrad_variant = wv & 0xf;
   ctx->wgrad_pipe = (wv & 0x40) ? 0 : 1;
   ctx->wgrad_target = (wv & 0x10) ? 512 : 256;
-  ctx->wgrad_slab_max = (wv & 0x20) ? 64 : 24;
+  ctx->wgrad_slab_max = (wv & 0x20) ? 24 : 128;
   ctx->wgrad_ring = (wv & 0x80) ? 4 : 5;
   ctx->halo_mode = (v >> 24) & 3;
   ctx->xcd_order = (v >> 26) & 3;
@@ -188,6 +205,13 @@ int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   ctx->halo_conv_auto = (v & 0x1000) ? 1 : 0;
   ctx->stagger = (v >> 13) & 7;
   ctx->wgrad_big_minsteps = ((v >> 10) & 3) == 1 ? 4 : ((v >> 10) & 3) == 2 ? 32 : 8;
+  return GCT2_OK;
+}
+int gct2_ctx_set_relu_bits(gct2_ctx* ctx, void* bits, int ld_bytes) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_relu_bits: null ctx");
+  if (bits && ld_bytes <= 0) return gct2_fail(GCT2_EINVAL, "ctx_set_relu_bits: ld_bytes must be positive");
+  ctx->relu_bits = reinterpret_cast<unsigned char*>(bits);
+  ctx->relu_ldbits = bits ? ld_bytes : 0;
   return GCT2_OK;
 }
 int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes) {
@@ -248,8 +272,15 @@ int gct2_conv4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const voi
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: H=%d W=%d must be even (skip concat, train.py:114-119)", H, W);
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: ld smaller than channel count");
   TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H / 2, W / 2, Cin, Cout, relu, 0};
-  if (!c.force_direct && rgb_fwd_supported(dtype, p)) return rgb_fwd(dtype, p, S(stream));   // image layer (Cin <= 4)
-  return run_tapgemm(c, dtype, FORM_CONV, EPI_BIAS_ACT, p, stream);
+  if (int e = take_relu_bits(c, "conv4s2_fwd", Cout, p)) return e;
+  const size_t out_pixels = (size_t)B * (H / 2) * (W / 2);
+  if (!c.force_direct && rgb_fwd_supported(dtype, p)) {                                       // image layer (Cin <= 4)
+    if (int e = rgb_fwd(dtype, p, S(stream))) return e;
+    if (p.bits && rgb_fwd_writes_bits(p)) c.relu_bits_done = 1;
+    return finish_relu_bits(c, dtype, p, out_pixels, stream);
+  }
+  if (int e = run_tapgemm(c, dtype, FORM_CONV, EPI_BIAS_ACT, p, stream)) return e;
+  return finish_relu_bits(c, dtype, p, out_pixels, stream);
 }
 
 int gct2_conv4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
@@ -258,6 +289,8 @@ int gct2_conv4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: H=%d W=%d must be even", H, W);
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: ld smaller than channel count");
   TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H / 2, W / 2, Cout, Cin, 0, accumulate};
+  if (int e = take_relu_bits(C(ctx), "conv4s2_dgrad", Cin, p)) return e;
+  if (!act) p.bits = nullptr;                                   // the plane stands in for act: no mask asked for, none applied
   return run_dgrad(C(ctx), dtype, FORM_CONVT, p, (size_t)B * H * W, db, db_split, db2, db_accumulate, stream);
 }
 
@@ -287,7 +320,10 @@ int gct2_convT4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const vo
   if (int e = check_conv_args("convT4s2_fwd", dtype, x, w, y, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_fwd: ld smaller than channel count");
   TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H, W, Cin, Cout, relu, 0};
-  return run_tapgemm(C(ctx), dtype, FORM_CONVT, EPI_BIAS_ACT, p, stream);
+  const gct2_ctx& c = C(ctx);
+  if (int e = take_relu_bits(c, "convT4s2_fwd", Cout, p)) return e;
+  if (int e = run_tapgemm(c, dtype, FORM_CONVT, EPI_BIAS_ACT, p, stream)) return e;
+  return finish_relu_bits(c, dtype, p, (size_t)B * 4 * H * W, stream);
 }
 
 int gct2_convT4s2_fwd_head_train(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, const float* head_w,
@@ -315,6 +351,8 @@ int gct2_convT4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, cons
   if (int e = check_conv_args("convT4s2_dgrad", dtype, dz, w, dx, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "convT4s2_dgrad: ld smaller than channel count");
   TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H, W, Cout, Cin, 0, accumulate};
+  if (int e = take_relu_bits(C(ctx), "convT4s2_dgrad", Cin, p)) return e;
+  if (!act) p.bits = nullptr;
   return run_dgrad(C(ctx), dtype, FORM_CONV, p, (size_t)B * H * W, db, db_split, db2, db_accumulate, stream);
 }
 

@@ -41,7 +41,7 @@ struct gct2_ctx {
   float* ws = nullptr; size_t ws_bytes = 0;        // split-K slabs, partial rows (forward / input-gradient / head calls)
   float* wws = nullptr; size_t wws_bytes = 0;      // weight-gradient slabs (falls back to ws)
   int tap_variant = 0;                             // forward / input-gradient tile (0 = automatic)
-  int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 24;
+  int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 128;   // slabs (ordered sums) whenever the workspace holds them: atomics only without one
   int wgrad_ring = 5;                              // stage buffers of the 256 x 256 weight-gradient pipeline (5 = all of the LDS; 4: A/B)
   int wgrad_fuse_adam = 0;                         // 1: one-owner weight-gradient tiles apply the fused optimizer step in their epilogue (measured +70 us per step: off)
   int stagger = 0;                // one-work-group-per-CU kernels: start offset between CU groups, units of 2048 cycles (tuning bits 13-15)
@@ -55,6 +55,9 @@ struct gct2_ctx {
   int force_direct = 0;
   unsigned long long* stamps = nullptr; size_t stamps_bytes = 0;   // diagnostic builds only (gct2_ctx_set_stamp_buffer)
   mutable RowsumState rowsum;
+  // ReLU bit plane for the NEXT layer call (gct2_ctx_set_relu_bits): consumed - and cleared - by the next forward / input-gradient
+  // entry point; relu_bits_done: the launch that just ran wrote the plane in its epilogue (else the entry point derives it from y)
+  mutable unsigned char* relu_bits = nullptr; mutable int relu_ldbits = 0; mutable int relu_bits_done = 0;
   float* wgrad_scratch(size_t* bytes) const {
     if (wws) { *bytes = wws_bytes; return wws; }
     *bytes = ws_bytes; return ws;
@@ -169,6 +172,25 @@ template <typename T> __device__ __forceinline__ float unpack_hi(uint32_t u) {
   return to_f32<T>(__builtin_bit_cast(T, (uint16_t)(u >> 16)));
 }
 
+// ReLU bit planes (r03): one byte per 8 consecutive channels of a pixel.  bit k = (element k of the 8 packed 16-bit values > 0) - the
+// comparison the mask epilogues apply to the activation itself, so a plane written by a forward epilogue reproduces them exactly
+template <typename T> __device__ __forceinline__ unsigned relu_bits8(u32x4_t o) {
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    m |= (unpack_lo<T>(o[k]) > 0.f ? 1u : 0u) << (2 * k);
+    m |= (unpack_hi<T>(o[k]) > 0.f ? 1u : 0u) << (2 * k + 1);
+  }
+  return m;
+}
+__device__ __forceinline__ void apply_relu_bits8(unsigned m, f32x4_t& a, f32x4_t& c) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (!((m >> r) & 1u)) a[r] = 0.f;
+    if (!((m >> (4 + r)) & 1u)) c[r] = 0.f;
+  }
+}
+
 // ---- geometry of the two 4x4/stride-2 "tap GEMMs" ------------------------------------------------
 // FORM_CONV : out on the SMALL grid (Hs x Ws), source on the BIG grid (2Hs x 2Ws), 16 taps,
 //             weights [tap][k][n]   (Conv2D forward, Conv2DTranspose input-gradient)
@@ -221,6 +243,8 @@ struct TapGemmParams {
   HeadFuse head;                         // EPI_HEAD only
   int ks = 0;                            // FORM_S1 / FORM_S1T: kernel size (odd, <= 5)
   int stagger = 0;                       // halo kernels: see stagger_start()
+  unsigned char* bits = nullptr; int ldbits = 0;   // ReLU bit plane [pixel][ldbits bytes], bit k of byte c = (channel 8c + k of the view > 0):
+                                         // EPI_BIAS_ACT writes it beside y, EPI_MASK reads it instead of act (16-byte epilogues only)
   int ws_shift = -1, hs_shift = -1;      // log2 of Ws / Hs when they are powers of two (filled by the launcher), else -1: the per-lane
                                          // pixel decode then uses shifts instead of four integer divisions per row
 #ifdef GCT2_STAMP

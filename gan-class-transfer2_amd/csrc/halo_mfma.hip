@@ -478,7 +478,9 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #pragma unroll
       for (int ip = 0; ip < 2; ip++) {
         const int n = n0 + 32 * ip + 8 * eg;
-        if (n < N) dst[ip] = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
+        if (n >= N) continue;
+        if (p.bits) dst[ip][0] = p.bits[opix * p.ldbits + (n >> 3)];     // one byte instead of 16 (block-uniform choice)
+        else dst[ip] = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
       }
     }
   };
@@ -503,7 +505,8 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
           for (int r = 0; r < 4; r++) { v0[r] = fmaxf(v0[r], 0.f); v1[r] = fmaxf(v1[r], 0.f); }
         }
       } else {
-        if (actp) {
+        if (actp && p.bits) apply_relu_bits8(mk[ip][0], v0, v1);
+        else if (actp) {
           const u32x4_t a4 = mk[ip];
 #pragma unroll
           for (int h = 0; h < 2; h++) {
@@ -526,6 +529,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       }
       const u32x4_t o = {pack2<T>(v0[0], v0[1]), pack2<T>(v0[2], v0[3]), pack2<T>(v1[0], v1[1]), pack2<T>(v1[2], v1[3])};
       *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + n) = o;
+      if (EPI == EPI_BIAS_ACT && p.bits) p.bits[opix * p.ldbits + (n >> 3)] = (unsigned char)relu_bits8<T>(o);
     }
     mk[0] = mkn[0]; mk[1] = mkn[1];
     __builtin_amdgcn_sched_barrier(0);
@@ -649,6 +653,7 @@ int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream
     if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_MASK>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_MASK>), grid, dim3(512), 0, s, p);
   }
+  if (epi == EPI_BIAS_ACT && p.bits) c.relu_bits_done = 1;      // the epilogue wrote the ReLU bit plane
   if (deferred) rowsum_record(c, p, deferred, p.m_tiles);
   else if (p.dbws) {
     if (int e = tapgemm_dbpart_reduce(p.dbws, p.m_tiles, p, s)) return e;

@@ -1177,3 +1177,30 @@ int pw_ls_update(gct2_loss_scale_state* st, int growth_interval, hipStream_t s) 
   hipLaunchKernelGGL(ls_update_kernel, dim3(1), dim3(1), 0, s, st, growth_interval);
   return gct2_check_launch("loss_scale_update");
 }
+
+// ---- ReLU bit plane derived from a stored activation tensor (fall-back of gct2_ctx_set_relu_bits: launches whose epilogue cannot
+// write the plane - 8-byte epilogues, split-K finalize, the direct kernels): bit k of bits[pixel][c] = (y[pixel][8c + k] > 0)
+namespace {
+template <typename T>
+__global__ void relu_bits_kernel(const T* __restrict__ y, int ldy, size_t pixels, int groups, unsigned char* __restrict__ bits, int ldbits) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pixels * (size_t)groups) return;
+  const size_t pix = i / groups;
+  const int gidx = (int)(i - pix * groups);
+  const T* src = y + pix * ldy + 8 * gidx;
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) m |= ((float)src[k] > 0.f ? 1u : 0u) << k;
+  bits[pix * ldbits + gidx] = (unsigned char)m;
+}
+}  // namespace
+int pw_relu_bits(int dtype, const void* y, int ldy, size_t pixels, int channels, unsigned char* bits, int ldbits, hipStream_t s) {
+  const int groups = channels / 8;
+  const size_t n = pixels * (size_t)groups;
+  if (!n) return GCT2_OK;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == GCT2_F32) hipLaunchKernelGGL(relu_bits_kernel<float>, grid, dim3(256), 0, s, (const float*)y, ldy, pixels, groups, bits, ldbits);
+  else if (dtype == GCT2_BF16) hipLaunchKernelGGL(relu_bits_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)y, ldy, pixels, groups, bits, ldbits);
+  else hipLaunchKernelGGL(relu_bits_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)y, ldy, pixels, groups, bits, ldbits);
+  return gct2_check_launch("relu_bits");
+}

@@ -142,8 +142,11 @@ __global__ __launch_bounds__(256, 4) void rgb_fwd_kernel(TapGemmParams p) {   //
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const int pr = (tid >> 4) + 16 * k;
-        if (m0 + pr < M)
-          *reinterpret_cast<u32x4_t*>(y + (size_t)(m0 + pr) * p.ldy + n0 + c16 * 8) = lds_read128(smem, pr * 256 + ((c16 ^ (pr & 15)) << 4));
+        if (m0 + pr < M) {
+          const u32x4_t o = lds_read128(smem, pr * 256 + ((c16 ^ (pr & 15)) << 4));
+          *reinterpret_cast<u32x4_t*>(y + (size_t)(m0 + pr) * p.ldy + n0 + c16 * 8) = o;
+          if (p.bits) p.bits[(size_t)(m0 + pr) * p.ldbits + (n0 >> 3) + c16] = (unsigned char)relu_bits8<T>(o);   // 16 lanes: 16 consecutive bytes
+        }
       }
     }
     return;
@@ -267,6 +270,8 @@ bool rgb_fwd_supported(int dtype, const TapGemmParams& p) {
   if (p.bias && (uintptr_t)p.bias % 16) return false;
   return true;
 }
+// the staged 16-byte epilogue (whole 128-channel tiles) also writes the ReLU bit plane of p.bits
+bool rgb_fwd_writes_bits(const TapGemmParams& p) { return (uintptr_t)p.y % 16 == 0 && p.ldy % 8 == 0 && p.N % 128 == 0; }
 int rgb_fwd(int dtype, const TapGemmParams& p, hipStream_t s) {
   const int M = p.B * p.Hs * p.Ws;
   dim3 grid((M + 127) / 128, (p.N + 127) / 128);

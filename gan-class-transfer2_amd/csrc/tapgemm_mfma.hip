@@ -476,7 +476,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
 #pragma unroll
         for (int ip = 0; ip < 2; ip++) {
           const int n = n0 + nlane + 32 * ip;
-          if (n < N) dst[ip] = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
+          if (n >= N) continue;
+          if (p.bits) dst[ip][0] = p.bits[opix * p.ldbits + (n >> 3)];          // one byte instead of 16 (block-uniform choice)
+          else dst[ip] = *reinterpret_cast<const u32x4_t*>(actp + opix * p.ldact + n);
         }
       }
     };
@@ -514,7 +516,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
             for (int r = 0; r < 4; r++) { a[r] = fmaxf(a[r], 0.f); c[r] = fmaxf(c[r], 0.f); }
           }
         } else {
-          if (actp) {
+          if (actp && p.bits) apply_relu_bits8(mk[ip][0], a, c);
+          else if (actp) {
             const u32x4_t a4 = mk[ip];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -537,6 +540,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
         }
         const u32x4_t o = {pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(c[0], c[1]), pack2<T>(c[2], c[3])};
         *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + n) = o;
+        if (EPI == EPI_BIAS_ACT && p.bits) p.bits[opix * p.ldbits + (n >> 3)] = (unsigned char)relu_bits8<T>(o);
       }
       mk[0] = mkn[0]; mk[1] = mkn[1];
       __builtin_amdgcn_sched_barrier(0);
@@ -859,6 +863,7 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   if (p.ksplit > 1) {
     hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)fin_rows, (p.N + 127) / 128), dim3(256), 0, s, p, npix);
   }
+  if (EPI == EPI_BIAS_ACT && p.bits && p.wide && p.ksplit == 1) c.relu_bits_done = 1;   // the 16-byte epilogue wrote the ReLU bit plane
   if (deferred) rowsum_record(c, p, deferred, db_nrows);
   else if (p.dbws) {
     const int rows = p.ksplit > 1 ? (int)fin_rows : p.m_tiles * PH;

@@ -1034,8 +1034,9 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   const size_t n = (size_t)taps * p.Cb * p.Cs;
   size_t ws_bytes = 0;
   float* ws = c.wgrad_scratch(&ws_bytes);
-  // measured (scripts/bench_wgrad.py): slabs beat atomics up to ~24 splits; beyond that (UpShuffle_0: 16 tiles x 48
-  // splits) the many 1-MiB slabs cost more than the atomics they replace
+  // measured (scripts/bench_wgrad.py): slabs beat atomics up to ~24 splits; beyond that (a small-batch UpShuffle_0: 16 tiles x 48
+  // splits) the many 1-MiB slabs cost a little more than the atomics they replace - and are taken all the same since r03: atomics
+  // make the gradient depend on the arrival order (tuning bit 21 restores the r02 limit of 24)
   if (rsplit > 1 && rsplit <= ((big_tile || tile2x) ? 128 : g_wgrad_slab_max) && ws && n % 4 == 0 && (uintptr_t)p.dw % 16 == 0 && n * sizeof(float) * rsplit <= ws_bytes &&
       g_wgrad_variant != 7)
     p.ws = ws;

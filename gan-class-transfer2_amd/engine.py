@@ -171,6 +171,9 @@ class UNetEngine:
         self.use_fused_head = True     # False: dense_fwd + mse_fwd_bwd + dense_bwd as three kernels
         self.fuse_u0_head = True       # train step: the head runs in UpShuffle_0's forward epilogue (R_0 is never written)
         self.keep_pred = False         # train step: also store the prediction (buffers().pred); the loss does not need it
+        # train step: the forward epilogues of the large levels also write ReLU bit planes (1 bit per activation) and the input-gradient
+        # epilogues read their masks from them instead of re-reading the activations (gct2_ctx_set_relu_bits; -16 bits per element read)
+        self.relu_bits = True
         self.arena = ParamArena(topo, dtype, self.device)
         self.arena.glorot_init(seed)
         self.arena.refresh_shadow(self._stream())
@@ -284,6 +287,14 @@ class UNetEngine:
         # packed copy of the network input (3 channels + a zero slot): DownShuffle_0 and its weight gradient gather 4x4
         # windows from it instead of striding through R_0's 144-byte rows
         b.img = z(B, H, W, 4)
+        # ReLU bit planes of R_1 .. R_{n-1} (levels with >= 8192 pixels: below that the mask reads are noise and the bottleneck layers'
+        # split-K launches would need an extra launch to derive the plane)
+        b.bits = [None] * n
+        b.bits_valid = False
+        for i in range(1, n):
+            px = B * b.hw[i][0] * b.hw[i][1]
+            if self.dtype != F32 and px >= 8192 and b.ld[i] % 8 == 0 and t.fu(i) % 8 == 0:
+                b.bits[i] = torch.zeros(px, b.ld[i] // 8, dtype=torch.uint8, device=self.device)
         b.Dlast = z(B, b.hw[n][0], b.hw[n][1], t.fd(n - 1))
         b.dDlast = z(B, b.hw[n][0], b.hw[n][1], t.fd(n - 1))
         b.pred = z(B, H, W, 3, dtype=torch.float32)
@@ -361,11 +372,18 @@ class UNetEngine:
         b.R[0][..., t.fu(0):t.fu(0) + 3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
         b.img[..., :3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
 
-    def forward(self, b: _Buffers, head: bool = True, stop_before_u0: bool = False) -> torch.Tensor:
+    def forward(self, b: _Buffers, head: bool = True, stop_before_u0: bool = False, planes: bool = False) -> torch.Tensor:
         """Denoiser.call (train.py:206-215): R_0's image slice must already hold the network input.
         head=False stops before Dense(3) (the train step runs the fused head kernel instead); stop_before_u0 also leaves
-        UpShuffle_0 to the caller (u0_head_train: its forward carries the head in its epilogue)."""
+        UpShuffle_0 to the caller (u0_head_train: its forward carries the head in its epilogue); planes: also write the ReLU bit
+        planes of the large levels (the train step: backward() then reads its masks from them)."""
         t, n, s, dt, A, cx = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena, self.ctx.handle
+        planes = planes and self.relu_bits
+        b.bits_valid = planes
+
+        def plane(level: int, ch: int) -> None:                 # one-shot: applies to the layer call that follows
+            if planes and b.bits[level] is not None:
+                self.ctx.set_relu_bits(b.bits[level].data_ptr() + ch // 8, b.ld[level] // 8)
         for i in range(n):                                      # DownShuffle_i  (train.py:184)
             H, W = b.hw[i]
             if i < n - 1:
@@ -373,6 +391,8 @@ class UNetEngine:
             else:
                 y, ldy = b.Dlast.data_ptr(), t.fd(i)
             x, ldx = (b.img.data_ptr(), 4) if i == 0 else (self._slice_ptr(b.R[i], t.fu(i)), b.ld[i])
+            if i < n - 1:
+                plane(i + 1, t.fu(i + 1))
             call("gct2_conv4s2_fwd", cx, dt, x, ldx, A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"), y, ldy, b.B, H, W, t.cx(i), t.fd(i), 1, s)
         for i in reversed(range(n)):                            # UpShuffle_i    (train.py:188)
             Hi, Wi = b.hw[i + 1]
@@ -382,6 +402,8 @@ class UNetEngine:
                 x, ldx = b.Dlast.data_ptr(), t.fd(i)
             if i == 0 and stop_before_u0:
                 return b.pred
+            if i >= 1:
+                plane(i, 0)
             call("gct2_convT4s2_fwd", cx, dt, x, ldx, A.wptr(f"U{i}.w"), A.pptr(f"U{i}.b"), b.R[i].data_ptr(), b.ld[i],
                  b.B, Hi, Wi, t.up_in(i), t.fu(i), 1, s)
         if not head:
@@ -568,6 +590,8 @@ class UNetEngine:
                 db, split, db2 = A.gptr(f"D{i}.b"), t.fd(i), None
 
             def dgrad_u():
+                if i < n - 1 and b.bits_valid and b.bits[i + 1] is not None:        # mask of dR_{i+1} = (R_{i+1} > 0): the plane
+                    self.ctx.set_relu_bits(b.bits[i + 1].data_ptr(), b.ld[i + 1] // 8)
                 call("gct2_convT4s2_dgrad", cx, dt, dz, lddz, A.wptr(f"U{i}.w"), x, ldx, dx, lddx, b.B, Hi, Wi, t.up_in(i),
                      t.fu(i), 0, db, split, db2, 0, s)
 
@@ -591,6 +615,8 @@ class UNetEngine:
 
             def dgrad_d():
                 if i > 0:                                       # the image itself needs no gradient
+                    if b.bits_valid and b.bits[i] is not None:
+                        self.ctx.set_relu_bits(b.bits[i].data_ptr() + t.fu(i) // 8, b.ld[i] // 8)
                     call("gct2_conv4s2_dgrad", cx, dt, dz, lddz, A.wptr(f"D{i}.w"), x, ldx, self._slice_ptr(b.dR[i], t.fu(i)),
                          b.ld[i], b.B, H, W, t.cx(i), t.fd(i), 1, A.gptr(f"D{i - 1}.b"), t.cx(i), None, 1, s)
 
@@ -691,10 +717,10 @@ class UNetEngine:
         weighted = self.objective_weighted()
         fused = self.fused_head_ok()
         if fused and self.fused_u0_head_ok(b):
-            self.forward(b, head=False, stop_before_u0=True)
+            self.forward(b, head=False, stop_before_u0=True, planes=True)
             loss = self.u0_head_train(b, target)
         else:
-            self.forward(b, head=not fused)
+            self.forward(b, head=not fused, planes=True)
             if weighted:
                 loss = self.weighted_loss_and_dpred(b, target, w)
             else:

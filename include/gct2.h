@@ -37,7 +37,7 @@ enum {
 };
 
 /* library / device identification ------------------------------------------------------------ */
-int gct2_abi_version(void);                 /* bumps when a signature below changes (v12: diffusion_update modes, build flags) */
+int gct2_abi_version(void);                 /* bumps when a signature below changes (v12: diffusion_update modes, build flags; v13: ReLU bit planes) */
 /* how the library was built: 0 for the product build; bit 0 (GCT2_BUILD_STAMP) = diagnostic build with in-kernel phase stamps
  * (make EXTRA=-DGCT2_STAMP).  Product hosts (the Python binding, bench.py, the tests) refuse a library whose flags are not 0. */
 enum { GCT2_BUILD_STAMP = 1 };
@@ -65,6 +65,9 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles);
  * bits 16-19: weight-gradient tile, 0 = automatic, 1/3 = 128x128 with 1/2 buffers, 2 (or 5) = 256x256, 4 = 256x128 at two
  * work-groups per CU, 7 = atomics, 6 / 8 = as 0 / 2 with the r02 stage code of the 256x256 pipeline instead of the lean stage;
+ * bit 20: aim at 512 instead of 256 work-groups on the 256x256 weight-gradient tile; bit 21: at most 24 pixel splits as ordered
+ * slabs on the 128x128 weight-gradient tile (r02; more splits then use atomics - arrival-order dependent; default since r03: slabs
+ * whenever the workspace holds them);
  * bit 22: 256x256 weight-gradient tile with two 64-row buffers instead of the four-stage pipeline;
  * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D dgrad), 0 = automatic, 1 = never, 2 = wherever the shape allows;
  * bits 26-27: tile -> XCD order of the forward / input-gradient GEMMs, 0 = automatic, 1 = bands of output pixels per XCD,
@@ -89,6 +92,15 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
 int gct2_ctx_set_tuning(gct2_ctx* ctx, int v);
 /* test hook: non-zero routes every convolution of this ctx through the direct (non-MFMA) kernels */
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on);
+/* ReLU bit plane for the NEXT layer call of this ctx (r03, ABI v13; one-shot: the call consumes and clears it).
+ * bits: device bytes [pixels][ld_bytes], bit k of byte c <-> channel 8c + k of the call's output view.
+ *  - before gct2_conv4s2_fwd / gct2_convT4s2_fwd: the call ALSO writes bits = (y > 0) for its Cout channels (in the epilogue of the
+ *    16-byte-store kernels; derived from the stored y by one extra launch on the other paths) - beside y, which is unchanged;
+ *  - before gct2_conv4s2_dgrad / gct2_convT4s2_dgrad with act != NULL: the call MAY read its ReLU mask from the plane instead of
+ *    act (1 byte instead of 16 per 8 channels: the mask read is a third of the epilogue traffic of these calls).  The plane must
+ *    equal (act > 0) over the Cin channels of the call - which of the two a given kernel reads is unspecified.
+ * Channels must be a multiple of 8, ld_bytes >= channels / 8.  bits = NULL clears a pending plane. */
+int gct2_ctx_set_relu_bits(gct2_ctx* ctx, void* bits, int ld_bytes);
 /* diagnostic builds only (gct2_build_flags() & GCT2_BUILD_STAMP): device buffer that receives the s_memrealtime phase stamps of
  * one wave per work-group of the next stamped launch of this ctx (layout: scripts/stamp_*.py).  GCT2_EINVAL in a product build. */
 int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes);

@@ -41,12 +41,14 @@ def run(name, variant, iters=20):
     elif kind == "convT_dgrad":
         dz = torch.randn(B, 2 * H, 2 * W, Cout, device=dev).to(bf); w = (torch.randn(4, 4, Cout, Cin, device=dev) * .05).to(bf)
         act = torch.randn(B, H, W, Cin, device=dev).to(bf); dx = torch.empty_like(act)
-        f = lambda: L.call("gct2_convT4s2_dgrad", CTX.handle, 1, dz.data_ptr(), Cout, w.data_ptr(), act.data_ptr(), Cin, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 0, None, 0, None, 0, s)
+        actp = None if os.environ.get("NOMASK") else act.data_ptr()     # NOMASK=1: what the ReLU-mask read costs
+        f = lambda: L.call("gct2_convT4s2_dgrad", CTX.handle, 1, dz.data_ptr(), Cout, w.data_ptr(), actp, Cin, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 0, None, 0, None, 0, s)
         flops = 2.0 * B * H * W * Cin * 16 * Cout
     else:
         dz = torch.randn(B, H // 2, W // 2, Cout, device=dev).to(bf); w = (torch.randn(4, 4, Cin, Cout, device=dev) * .05).to(bf)
         act = torch.randn(B, H, W, Cin, device=dev).to(bf); dx = torch.zeros_like(act)
-        f = lambda: L.call("gct2_conv4s2_dgrad", CTX.handle, 1, dz.data_ptr(), Cout, w.data_ptr(), act.data_ptr(), Cin, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 1, None, 0, None, 0, s)
+        actp = None if os.environ.get("NOMASK") else act.data_ptr()
+        f = lambda: L.call("gct2_conv4s2_dgrad", CTX.handle, 1, dz.data_ptr(), Cout, w.data_ptr(), actp, Cin, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 1, None, 0, None, 0, s)
         flops = 2.0 * B * H * W * Cin * 4 * Cout
     for _ in range(3): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

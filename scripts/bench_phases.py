@@ -17,7 +17,7 @@ b = eng.buffers(64, 128, 128)
 def fwd():
     eng.begin_step()
     eng.sample_and_noise_into_r0(b, x, keep_eps=False)
-    eng.forward(b, head=False, stop_before_u0=True)
+    eng.forward(b, head=False, stop_before_u0=True, planes=True)
     return eng.u0_head_train(b, x)
 
 

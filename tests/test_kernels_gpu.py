@@ -61,6 +61,10 @@ def ctx():
     return _CTX[0].handle
 
 
+def ctx_obj():
+    return _CTX[0]
+
+
 def set_ws(t):
     _CTX[0].set_workspace(t)
 
@@ -827,6 +831,128 @@ def test_conv_dgrad_halo_kernel(gpu, shape, use_ws, il):
         assert np.abs(db.cpu().numpy() - 3.0 - cs[:split]).max() <= 2e-3 * scale
         assert np.abs(db2.cpu().numpy() + 1.0 - cs[split:]).max() <= 2e-3 * scale
         assert rel_l2(dxd.double().cpu().numpy(), contrib + prev) <= TOL_OUT[dt]
+    finally:
+        set_tuning(0)
+        set_ws(None)
+
+
+def _packbits(y, C):
+    """bit k of byte c <-> channel 8c + k (include/gct2.h, gct2_ctx_set_relu_bits)"""
+    return np.packbits((y[..., :C] > 0).reshape(-1, C), axis=1, bitorder="little")
+
+
+@pytest.mark.parametrize("case", ["conv_wide", "conv_narrow_view", "conv_splitk", "conv_rgb_staged", "conv_rgb_small", "conv_f32",
+                                  "convT_halo", "convT_tap", "convT_splitk"])
+def test_relu_bit_plane_written_by_forward_calls(gpu, case):
+    """gct2_ctx_set_relu_bits before a forward call: the call also leaves bits = (y > 0), one byte per 8 channels, written by the
+    16-byte epilogues (tap GEMM, halo kernel, image layer) or derived from the stored y on the other paths (8-byte epilogue of an
+    unaligned view, split-K finalize, fp32 direct kernels); y itself is what the call without a plane produces, bit for bit; the
+    plane is one-shot (a second call without a new registration leaves the bytes alone); bytes outside the view stay untouched."""
+    L = lib()
+    dt = F32 if case == "conv_f32" else BF16
+    kind = "convT" if case.startswith("convT") else "conv"
+    B, H, W, Cin, Cout, ld_extra, tuning = {
+        "conv_wide": (2, 32, 32, 64, 128, 8, 0), "conv_narrow_view": (2, 16, 16, 64, 64, 4, 0), "conv_splitk": (2, 8, 8, 128, 256, 0, 0),
+        "conv_rgb_staged": (2, 32, 32, 3, 128, 0, 0), "conv_rgb_small": (2, 32, 32, 3, 64, 0, 0), "conv_f32": (1, 16, 16, 16, 32, 0, 0),
+        "convT_halo": (2, 16, 16, 64, 64, 8, 2 << 24), "convT_tap": (2, 16, 16, 64, 128, 0, 1 << 24), "convT_splitk": (2, 4, 4, 256, 128, 0, 0),
+    }[case]
+    rng = np.random.default_rng(91)
+    ldx = 4 if Cin == 3 else Cin
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    xd = torch.zeros(B, H, W, ldx, dtype=TDT[dt], device=gpu)
+    xd[..., :Cin] = dev(x, dt, gpu)
+    wshape = (4, 4, Cin, Cout) if kind == "conv" else (4, 4, Cout, Cin)
+    wd = dev(rnd(rng.standard_normal(wshape) * 0.1, dt), dt, gpu)
+    bd = torch.tensor(rng.standard_normal(Cout), dtype=torch.float32, device=gpu)
+    Ho, Wo = (H // 2, W // 2) if kind == "conv" else (2 * H, 2 * W)
+    ld = Cout + ld_extra
+    off = ld_extra // 2 if ld_extra == 4 else ld_extra          # narrow view: starts 2 elements in (4-byte aligned only)
+    ldb = Cout // 8 + 3
+    outs = []
+    ws = torch.empty(4 << 18, dtype=torch.float32, device=gpu)
+    set_ws(ws)
+    set_tuning(tuning)
+    try:
+        for with_bits in (False, True):
+            y = torch.full((B, Ho, Wo, ld), 7.0, dtype=TDT[dt], device=gpu)
+            bits = torch.full((B * Ho * Wo, ldb), 0xA5, dtype=torch.uint8, device=gpu)
+            for rep in range(2):                                # second call: no new registration -> the plane is not touched
+                if with_bits and rep == 0:
+                    ctx_obj().set_relu_bits(bits.data_ptr() + 1, ldb)
+                if rep == 1:
+                    bits_before = bits.clone()
+                L.call("gct2_conv4s2_fwd" if kind == "conv" else "gct2_convT4s2_fwd", ctx(), dt, xd.data_ptr(), ldx, wd.data_ptr(), bd.data_ptr(),
+                       y.data_ptr() + off * y.element_size(), ld, B, H, W, Cin, Cout, 1, stream())
+                torch.cuda.synchronize()
+                if rep == 1:
+                    assert torch.equal(bits, bits_before)
+            outs.append(y)
+            if with_bits:
+                got = bits.cpu().numpy()
+                ref = _packbits(y[..., off:off + Cout].float().cpu().numpy(), Cout)
+                assert np.array_equal(got[:, 1:1 + Cout // 8], ref), case
+                assert (got[:, 0] == 0xA5).all() and (got[:, 1 + Cout // 8:] == 0xA5).all()
+                assert 0.2 < np.unpackbits(ref).mean() < 0.8    # a real mask, not all zeros / ones
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        set_tuning(0)
+        set_ws(None)
+
+
+@pytest.mark.parametrize("case", ["conv_dgrad_halo", "conv_dgrad_tap", "convT_dgrad_tap", "convT_dgrad_big", "conv_dgrad_narrow"])
+def test_relu_bit_plane_read_by_input_gradient_calls(gpu, case):
+    """gct2_ctx_set_relu_bits before an input-gradient call: the 16-byte epilogues (tap GEMM, halo kernel) take their ReLU mask from
+    the plane - proven by handing them an all-positive act with the REAL mask in the plane - and give, with the real act and a
+    consistent plane, the bits of the call without a plane; kernels that cannot read planes (8-byte epilogue) keep using act."""
+    L = lib()
+    dt = BF16
+    kind = "convT" if case.startswith("convT") else "conv"
+    B, H, W, Cin, Cout, tuning, narrow = {
+        "conv_dgrad_halo": (2, 32, 32, 64, 32, 2 << 24, False), "conv_dgrad_tap": (2, 32, 32, 64, 32, 1 << 24, False),
+        "convT_dgrad_tap": (2, 16, 16, 128, 32, 0, False), "convT_dgrad_big": (4, 32, 32, 256, 64, 5, False),
+        "conv_dgrad_narrow": (2, 16, 16, 64, 32, 0, True),
+    }[case]
+    rng = np.random.default_rng(93)
+    x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+    if kind == "conv":
+        w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+        dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+        ref = O.conv4s2_bwd(x, w, dz)[0] * (x > 0)
+    else:
+        w = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+        dz = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+        ref = O.convT4s2_bwd(x, w, dz)[0] * (x > 0)
+    lda = Cin + (4 if narrow else 0)
+    xd = torch.zeros(B, H, W, lda, dtype=TDT[dt], device=gpu)
+    xd[..., :Cin] = dev(x, dt, gpu)
+    ones = torch.ones_like(xd)
+    wd, dzd = dev(w, dt, gpu), dev(dz, dt, gpu)
+    ldb = Cin // 8 + 2
+    bits = torch.zeros(B * H * W, ldb, dtype=torch.uint8, device=gpu)
+    bits[:, 2:] = torch.tensor(_packbits(x, Cin), device=gpu)
+    fn = "gct2_conv4s2_dgrad" if kind == "conv" else "gct2_convT4s2_dgrad"
+    ws = torch.empty(4 << 18, dtype=torch.float32, device=gpu)
+    use_ws = kind == "conv"          # the small conv-form problems would take split-K with a workspace: its finalize kernel reads act
+    set_ws(ws if use_ws else None)
+    set_tuning(tuning)
+    res = {}
+    same = (lambda a, b: torch.equal(a, b)) if use_ws else (lambda a, b: torch.allclose(a, b, rtol=1e-4, atol=1e-3))   # bias sums: atomics without a workspace
+    try:
+        for name, act, use_bits in (("act", xd, False), ("act+bits", xd, True), ("ones+bits", ones, True)):
+            dx = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
+            db = torch.zeros(Cin, device=gpu)
+            if use_bits:
+                ctx_obj().set_relu_bits(bits.data_ptr() + 2, ldb)
+            L.call(fn, ctx(), dt, dzd.data_ptr(), Cout, wd.data_ptr(), act.data_ptr(), lda, dx.data_ptr(), Cin, B, H, W, Cin, Cout, 0,
+                   db.data_ptr(), Cin, None, 0, stream())
+            torch.cuda.synchronize()
+            res[name] = (dx, db)
+        assert rel_l2(res["act"][0].double().cpu().numpy(), ref) <= TOL_OUT[dt]
+        assert torch.equal(res["act"][0], res["act+bits"][0]) and same(res["act"][1], res["act+bits"][1])
+        if narrow:      # 8-byte epilogue: the plane is ignored, the all-positive act masks nothing
+            assert rel_l2(res["ones+bits"][0].double().cpu().numpy(), ref) > 0.3
+        else:
+            assert torch.equal(res["act"][0], res["ones+bits"][0]) and same(res["act"][1], res["ones+bits"][1])
     finally:
         set_tuning(0)
         set_ws(None)
