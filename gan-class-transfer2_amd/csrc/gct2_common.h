@@ -157,6 +157,18 @@ __device__ __forceinline__ float rows4_sum(float t) {
   return a + b;
 }
 
+// OR over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: the swaps of rows4_sum on integers
+__device__ __forceinline__ unsigned rows4_or(unsigned t) {
+  unsigned a = t, b = t;
+  asm volatile("" : "+v"(b));
+  asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  t = a | b;
+  a = t; b = t;
+  asm volatile("" : "+v"(b));
+  asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a | b;
+}
+
 __device__ __forceinline__ u32x4_t gload128(const void* p) {
   return *reinterpret_cast<const u32x4_t*>(p);
 }
@@ -243,6 +255,7 @@ struct TapGemmParams {
   HeadFuse head;                         // EPI_HEAD only
   int ks = 0;                            // FORM_S1 / FORM_S1T: kernel size (odd, <= 5)
   int stagger = 0;                       // halo kernels: see stagger_start()
+  int bits_words = 0;                    // 1: plane and strides are 4-byte aligned and N % 32 == 0 -> the four lane rows of a pixel merge their bytes into ONE 32-bit store
   unsigned char* bits = nullptr; int ldbits = 0;   // ReLU bit plane [pixel][ldbits bytes], bit k of byte c = (channel 8c + k of the view > 0):
                                          // EPI_BIAS_ACT writes it beside y, EPI_MASK reads it instead of act (16-byte epilogues only)
   int ws_shift = -1, hs_shift = -1;      // log2 of Ws / Hs when they are powers of two (filled by the launcher), else -1: the per-lane

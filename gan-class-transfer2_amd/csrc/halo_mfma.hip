@@ -490,6 +490,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
     u32x4_t mkn[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
     if (j + 1 < 8) load_masks(j + 1, mkn);
     const size_t opix = out_pixel(j);
+    unsigned wbits[2] = {0u, 0u};
 #pragma unroll
     for (int ip = 0; ip < 2; ip++) {                           // fragments 2 ip, 2 ip + 1: channels n .. n + 7 of this lane
       const int n = n0 + 32 * ip + 8 * eg;
@@ -529,7 +530,15 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       }
       const u32x4_t o = {pack2<T>(v0[0], v0[1]), pack2<T>(v0[2], v0[3]), pack2<T>(v1[0], v1[1]), pack2<T>(v1[2], v1[3])};
       *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + n) = o;
-      if (EPI == EPI_BIAS_ACT && p.bits) p.bits[opix * p.ldbits + (n >> 3)] = (unsigned char)relu_bits8<T>(o);
+      if (EPI == EPI_BIAS_ACT && p.bits && !p.bits_words) p.bits[opix * p.ldbits + (n >> 3)] = (unsigned char)relu_bits8<T>(o);
+      if (EPI == EPI_BIAS_ACT && p.bits_words) wbits[ip] = relu_bits8<T>(o) << (8 * eg);
+    }
+    if (EPI == EPI_BIAS_ACT && p.bits_words) {                   // block-uniform: every lane takes part in the row exchange
+#pragma unroll
+      for (int ip = 0; ip < 2; ip++) {
+        const unsigned wd = rows4_or(wbits[ip]);                 // the 32 channels n0 + 32 ip .. of this lane's pixel
+        if (eg == 0 && n0 + 32 * ip < N) *reinterpret_cast<unsigned*>(p.bits + opix * p.ldbits + ((n0 + 32 * ip) >> 3)) = wd;
+      }
     }
     mk[0] = mkn[0]; mk[1] = mkn[1];
     __builtin_amdgcn_sched_barrier(0);
@@ -625,6 +634,7 @@ int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream
   p.ksplit = 1;
   p.dbws = nullptr;
   p.stagger = c.stagger;
+  p.bits_words = (p.bits && (uintptr_t)p.bits % 4 == 0 && p.ldbits % 4 == 0 && p.N % 32 == 0) ? 1 : 0;
   float* deferred = nullptr;
   if (epi == EPI_MASK && (p.db || p.db2)) {      // partial bias-gradient rows at the tail of the workspace, one per work-group row
     const size_t ws_bytes = c.ws_bytes;

@@ -501,6 +501,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       }
       size_t opix;
       const bool row_ok = out_pixel(j, opix);
+      unsigned wbits[2] = {0u, 0u};
 #pragma unroll
       for (int ip = 0; ip < 2; ip++) {
         const int n = n0 + nlane + 32 * ip;
@@ -540,7 +541,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
         }
         const u32x4_t o = {pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(c[0], c[1]), pack2<T>(c[2], c[3])};
         *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + n) = o;
-        if (EPI == EPI_BIAS_ACT && p.bits) p.bits[opix * p.ldbits + (n >> 3)] = (unsigned char)relu_bits8<T>(o);
+        if (EPI == EPI_BIAS_ACT && p.bits && !p.bits_words) p.bits[opix * p.ldbits + (n >> 3)] = (unsigned char)relu_bits8<T>(o);
+        if (EPI == EPI_BIAS_ACT && p.bits_words) wbits[ip] = relu_bits8<T>(o) << (((n >> 3) & 3) * 8);
+      }
+      if (EPI == EPI_BIAS_ACT && p.bits_words) {                 // block-uniform: every lane takes part in the row exchange
+#pragma unroll
+        for (int ip = 0; ip < 2; ip++) {
+          const unsigned wd = rows4_or(wbits[ip]);               // the 32 channels n0 + 64 wn + 32 ip .. of this lane's pixel
+          const int n32 = n0 + wn * 64 + 32 * ip;
+          if (eg == 0 && row_ok && n32 < N) *reinterpret_cast<unsigned*>(p.bits + opix * p.ldbits + (n32 >> 3)) = wd;
+        }
       }
       mk[0] = mkn[0]; mk[1] = mkn[1];
       __builtin_amdgcn_sched_barrier(0);
@@ -852,6 +862,7 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   const int slices = p.n_tiles * PH * p.ksplit;
   p.wstat = (c.xcd_order == 2 || (c.xcd_order == 0 && w_bytes >= 3 * src_bytes)) && slices >= 8 ? 1 : 0;   // measured per layer: profiles/r02_layers.txt
   dim3 grid(p.wstat ? 8 * ((slices + 7) / 8) * p.m_tiles : 8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
+  p.bits_words = (p.bits && (uintptr_t)p.bits % 4 == 0 && p.ldbits % 4 == 0 && p.N % 32 == 0) ? 1 : 0;
   auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF, WM>;
   p.dbws = db_rows ? ws + (ws_bytes - dbws_bytes) / sizeof(float) / 4 * 4 : nullptr;
   // an open row-sum deferral (gct2_rowsum_begin): the partial rows go to the caller's row-sum buffer and stay there until the flush

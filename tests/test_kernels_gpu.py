@@ -841,13 +841,15 @@ def _packbits(y, C):
     return np.packbits((y[..., :C] > 0).reshape(-1, C), axis=1, bitorder="little")
 
 
+@pytest.mark.parametrize("words", [False, True])
 @pytest.mark.parametrize("case", ["conv_wide", "conv_narrow_view", "conv_splitk", "conv_rgb_staged", "conv_rgb_small", "conv_f32",
                                   "convT_halo", "convT_tap", "convT_splitk"])
-def test_relu_bit_plane_written_by_forward_calls(gpu, case):
+def test_relu_bit_plane_written_by_forward_calls(gpu, case, words):
     """gct2_ctx_set_relu_bits before a forward call: the call also leaves bits = (y > 0), one byte per 8 channels, written by the
     16-byte epilogues (tap GEMM, halo kernel, image layer) or derived from the stored y on the other paths (8-byte epilogue of an
     unaligned view, split-K finalize, fp32 direct kernels); y itself is what the call without a plane produces, bit for bit; the
-    plane is one-shot (a second call without a new registration leaves the bytes alone); bytes outside the view stay untouched."""
+    plane is one-shot (a second call without a new registration leaves the bytes alone); bytes outside the view stay untouched.
+    words: a 4-byte aligned plane (the engine's): the four lane rows of a pixel merge their bytes into one 32-bit store."""
     L = lib()
     dt = F32 if case == "conv_f32" else BF16
     kind = "convT" if case.startswith("convT") else "conv"
@@ -867,7 +869,7 @@ def test_relu_bit_plane_written_by_forward_calls(gpu, case):
     Ho, Wo = (H // 2, W // 2) if kind == "conv" else (2 * H, 2 * W)
     ld = Cout + ld_extra
     off = ld_extra // 2 if ld_extra == 4 else ld_extra          # narrow view: starts 2 elements in (4-byte aligned only)
-    ldb = Cout // 8 + 3
+    ldb, boff = (Cout // 8 + 3, 1) if not words else ((Cout // 8 + 7) // 4 * 4, 4)
     outs = []
     ws = torch.empty(4 << 18, dtype=torch.float32, device=gpu)
     set_ws(ws)
@@ -878,7 +880,7 @@ def test_relu_bit_plane_written_by_forward_calls(gpu, case):
             bits = torch.full((B * Ho * Wo, ldb), 0xA5, dtype=torch.uint8, device=gpu)
             for rep in range(2):                                # second call: no new registration -> the plane is not touched
                 if with_bits and rep == 0:
-                    ctx_obj().set_relu_bits(bits.data_ptr() + 1, ldb)
+                    ctx_obj().set_relu_bits(bits.data_ptr() + boff, ldb)
                 if rep == 1:
                     bits_before = bits.clone()
                 L.call("gct2_conv4s2_fwd" if kind == "conv" else "gct2_convT4s2_fwd", ctx(), dt, xd.data_ptr(), ldx, wd.data_ptr(), bd.data_ptr(),
@@ -890,8 +892,8 @@ def test_relu_bit_plane_written_by_forward_calls(gpu, case):
             if with_bits:
                 got = bits.cpu().numpy()
                 ref = _packbits(y[..., off:off + Cout].float().cpu().numpy(), Cout)
-                assert np.array_equal(got[:, 1:1 + Cout // 8], ref), case
-                assert (got[:, 0] == 0xA5).all() and (got[:, 1 + Cout // 8:] == 0xA5).all()
+                assert np.array_equal(got[:, boff:boff + Cout // 8], ref), case
+                assert (got[:, :boff] == 0xA5).all() and (got[:, boff + Cout // 8:] == 0xA5).all()
                 assert 0.2 < np.unpackbits(ref).mean() < 0.8    # a real mask, not all zeros / ones
         assert torch.equal(outs[0], outs[1])
     finally:
