@@ -383,6 +383,37 @@ def test_fused_adam_equals_separate_adam(gpu):
             assert torch.equal(getattr(a.arena, name), getattr(other.arena, name)), name
 
 
+def test_relu_bit_planes_do_not_change_the_step(gpu):
+    """engine.relu_bits (r03): the forward epilogues write 1-bit ReLU planes for the large levels and the input-gradient epilogues
+    read their masks from them instead of the activations - the same comparison on the same stored values, so three steps with and
+    without planes leave identical parameters, Adam slots and losses, bit for bit (reference widths, planes on three levels)."""
+    import gan_class_transfer2_amd as g
+    topo = g.Topology(128, 512, 4)
+    gen = torch.Generator().manual_seed(18)
+    xs = [(torch.randint(0, 256, (32, 64, 64, 3), generator=gen).float() / 128 - 1).to(gpu) for _ in range(3)]
+    ts = [torch.randint(1, 201, (32,), generator=gen, dtype=torch.int32) for _ in range(3)]
+    es = [torch.randn(32, 64, 64, 3, generator=gen) for _ in range(3)]
+    res = []
+    for planes in (False, True):
+        eng = g.UNetEngine(topo, g.BF16, gpu, seed=78)
+        eng.relu_bits = planes
+        losses = [float(eng.train_step(x, t, e)[0]) for x, t, e in zip(xs, ts, es)]
+        torch.cuda.synchronize()
+        b = eng.buffers(32, 64, 64)
+        assert sum(p is not None for p in b.bits) == 2 and b.bits_valid == planes        # 32 x 32 and 16 x 16 levels (>= 8192 pixels)
+        res.append((eng, losses))
+    (a, la), (b_, lb) = res
+    assert la == lb
+    for name in ("p", "m", "v", "shadow"):
+        assert torch.equal(getattr(a.arena, name), getattr(b_.arena, name)), name
+    # the planes hold exactly the signs of the activations they belong to
+    bufs = b_.buffers(32, 64, 64)
+    for i, plane in enumerate(bufs.bits):
+        if plane is not None:
+            act = bufs.R[i].reshape(-1, bufs.ld[i]).float().cpu().numpy()
+            assert np.array_equal(plane.cpu().numpy(), np.packbits(act > 0, axis=1, bitorder="little")), i
+
+
 @pytest.mark.parametrize("size,batch", [(64, 3), (192, 2), (128, 5), (256, 1)])
 def test_dispatch_sweep_default_vs_plain_kernels(gpu, size, batch):
     """shapes the oracle tests do not reach (odd batches, 3 x 64 pixels, 256 pixels): the default dispatch (halo kernel, 256-wide
