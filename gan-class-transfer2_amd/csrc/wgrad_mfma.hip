@@ -15,6 +15,7 @@
 // The reduction over r is split across work-groups (XCD-aware 1-D grid); partial tiles go to workspace slabs summed in a
 // fixed order by wgrad_reduce_kernel (reproducible), to their single owner (read-add-write), or to fp32 atomics.
 #include "gct2_common.h"
+#include <type_traits>
 #include <algorithm>
 
 namespace {
@@ -915,6 +916,223 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
   }
 }
 
+// ---- the lean pipeline with the fragments of the NEXT stage read during the MFMAs of the current one (r03) ---------------------
+// wgrad256r_kernel's stage is [DMA issue + address updates] -> [24 transposed reads, drained] -> [32 MFMAs] -> [wait, barrier], in
+// lock step on all 8 waves: the LDS pipe and the matrix cores take turns (tests/hw_probe/probe_wavetile.hip: that structure tops
+// out at 1.51-1.59 PFLOP/s with no global traffic at all).  Here a wave keeps TWO fragment sets in registers: while the MFMAs of
+// stage s run on one, the reads of stage s + 1 (already landed and barrier-visible) fill the other - in two halves so that the
+// second half reuses the registers the first 16 MFMAs have freed.  The ring is the same five buffers: the buffer of stage s is free
+// as soon as every wave holds its fragments (the barrier that ends stage s - 1), so stage s + 5 is issued into it during stage s:
+// still four stages in flight.  Same multiplies in the same order per accumulator: bit-identical to wgrad256p / wgrad256q.
+// (original comment of the lean stage follows)
+// wgrad256p_kernel's stage carries ~80 vector instructions besides its 32 MFMAs and 24 transposed reads (the ISA shows exec-masked
+// branches around three 64-bit multiply-adds per gathered piece, ~40 instructions that rebuild the 12 fragment addresses, a chain of
+// scalar branches for the wait count): with two lock-stepped waves per SIMD that is more than the issue slots the MFMAs leave free.
+// Here: (a) the gather addresses advance incrementally (adds and selects, no multiply, no branch: one stage = 32 rows further, with
+// carries into the next image row / image), tap validity from four precomputed per-lane flags; (b) the fragment addresses are
+// lane offsets computed ONCE, plus the stage's compile-time base; (c) ONE LDS array (the DMA is hidden inline asm, so hipcc has
+// nothing to drain); (d) a constant vmcnt in the steady state.  Same arithmetic in the same order: bit-identical results.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void wgrad256r_kernel(WgradParams p) {
+  constexpr int NST = 5;
+  constexpr int IMG = 32 * 256;                                   // one T image of a stage: 32 r-rows x 128 columns
+  constexpr int STAGE = 4 * IMG;
+  constexpr int NDMA = 4;
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wm = wave >> 2;
+  const int Hs = p.Hs, Ws = p.Ws, Cb = p.Cb, Cs = p.Cs;
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  const int R = p.B * Hs * Ws;
+  const int GC = 16 * Cb;
+  const int tiles_n = (Cs + 255) / 256;
+  const int tiles = ((GC + 255) / 256) * tiles_n;
+  int tile, split;
+  if (p.rsplit >= 8) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % tiles;
+    split = (j / tiles) * 8 + xcd;
+    if (split >= p.rsplit) return;
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
+  const int gc0 = (tile / tiles_n) * 256, cs0 = (tile % tiles_n) * 256;
+  const int steps_total = (R + 63) / 64;
+  stagger_start(p.stagger);
+  const int steps_per = (steps_total + p.rsplit - 1) / p.rsplit;
+  const int step_lo = split * steps_per;
+  const int step_hi = min(steps_total, step_lo + steps_per);
+  if (step_lo >= step_hi) return;
+  const int st_lo = 2 * step_lo, st_hi = 2 * step_hi;
+
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(p.big), rs_s = make_rsrc(p.small);
+  const int row0 = 4 * wave + (lane >> 4);
+  const int lc = ((((lane & 15) >> 1) ^ timg_swz(row0)) << 1) | (lane & 1);
+  const int ldb2 = p.ldbig * 2, lds2b = p.ldsmall * 2;
+  // per image g of the big operand: byte offset of tap (kh, kw) / channel cb relative to pixel (2 sh, 2 sw), and the four cases in
+  // which the tap leaves the image: kh = 0 at the top row, kh = 3 at the bottom row, kw = 0 / 3 at the left / right column
+  // (bit masks, not bools: chains of && on per-lane conditions compile to exec-masked branches - 20 scalar branches per stage)
+  int dg[2];
+  unsigned edge[2];                                                // bit 0: kh = 0, 1: kh = 3, 2: kw = 0, 3: kw = 3; bit 4: the image is out of range
+  unsigned s_bad[2];                                               // small operand: column block out of range
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const int gc = gc0 + 128 * g + lc * 8;
+    const bool ok = gc < GC;
+    const int tap = ok ? gc / Cb : 0;
+    const int cb = ok ? gc - tap * Cb : 0;
+    const int kh = tap >> 2, kw = tap & 3;
+    dg[g] = ((kh - 1) * Wb + (kw - 1)) * ldb2 + cb * 2;
+    edge[g] = (kh == 0 ? 1u : 0u) | (kh == 3 ? 2u : 0u) | (kw == 0 ? 4u : 0u) | (kw == 3 ? 8u : 0u) | (ok ? 0u : 16u);
+    s_bad[g] = (cs0 + 128 * g + lc * 8) < Cs ? 0u : 16u;
+  }
+  // this lane's row of the current issue stage: r, its (image, row, column) on the small grid, the byte offsets of pixel (2 sh, 2 sw)
+  // of the big tensor and of row r of the small one; advanced by 32 rows per issued stage
+  const int adv_w = 32 % Ws, q1 = 32 / Ws, adv_h = q1 % Hs, adv_b = q1 / Hs;
+  const int pixA = adv_w * 2 * ldb2, pixB = Wb * ldb2, pixCD = (adv_h * 2 * Wb + adv_b * Hb * Wb) * ldb2;
+  int r = st_lo * 32 + row0;
+  int rw = r % Ws, rh, rb;
+  { const int t = r / Ws; rh = t % Hs; rb = t / Hs; }
+  unsigned pix = (unsigned)(((rb * Hb + 2 * rh) * Wb + 2 * rw) * ldb2);
+  unsigned soff = (unsigned)(r * lds2b + (cs0 + lc * 8) * 2);
+  auto issue = [&](char* base) {                                  // stages are issued in increasing order
+    // where this row sits: bit 0 top row, 1 bottom row, 2 left column, 3 right column; bit 4: beyond the last row (always "bad")
+    const unsigned pos = (rh == 0 ? 1u : 0u) | (rh == Hs - 1 ? 2u : 0u) | (rw == 0 ? 4u : 0u) | (rw == Ws - 1 ? 8u : 0u) | (r < R ? 0u : 16u);
+    char* piece = base + wave * 1024;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const unsigned badb = (edge[g] & pos & 15u) | ((edge[g] | pos) & 16u);
+      const unsigned bads = (s_bad[g] | pos) & 16u;
+      dma16_hidden(rs_b, piece + g * IMG, badb ? OOB : pix + (unsigned)dg[g]);
+      dma16_hidden(rs_s, piece + (2 + g) * IMG, bads ? OOB : soff + (unsigned)(g * 256));
+    }
+    // 32 rows further
+    r += 32; soff += (unsigned)(32 * lds2b);
+    rw += adv_w; pix += (unsigned)pixA;
+    const bool cw = rw >= Ws;
+    rw -= cw ? Ws : 0; rh += cw ? 1 : 0; pix += cw ? (unsigned)pixB : 0u;
+    rh += adv_h; rb += adv_b; pix += (unsigned)pixCD;
+    const bool ch = rh >= Hs;                                     // (into the next image: the byte offset is already right, Hb = 2 Hs)
+    rh -= ch ? Hs : 0; rb += ch ? 1 : 0;
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: lane offsets inside a stage buffer, computed once (k0 = 8 (lane>>4) + ((lane>>2)&3), two transposed reads
+  // 4 rows apart: the swizzle of row k0 + 4 equals that of row k0)
+  // (fragment index i or j enters the offset as (idx ^ swz) << 5 = base ^ (idx << 5): ONE register per operand, one XOR per fragment)
+  int sf_off0, bf_off0;
+  {
+    const int g4 = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    const int k0 = 8 * g4 + q;
+    const int swz = timg_swz(k0);
+    sf_off0 = (2 + (wn >> 1)) * IMG + k0 * 256 + (((4 * (wn & 1)) ^ swz) << 5) + pq * 8;
+    bf_off0 = wm * IMG + k0 * 256 + (swz << 5) + pq * 8;
+  }
+  auto sf_off_ = [&](int j) { return sf_off0 ^ (j << 5); };
+  auto bf_off_ = [&](int i) { return bf_off0 ^ (i << 5); };
+  auto frag = [&](const char* base, int off) -> u32x4_t {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + off));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + off + 4 * 256));
+    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+    return u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+  };
+  // Registers: 128 accumulators + two small-operand sets (2 x 16) + a rolling window of FOUR big-operand fragments (16): the big
+  // fragment of row i + 3 is read while row i is multiplied - across the stage boundary too (rows 5..7 fetch rows 0..2 of the next
+  // stage, whose buffer is already visible), the next small set in the middle of the stage.  Two full sets (96) + 128 do not fit 256.
+  u32x4_t sfr[2][4], bfw[4];
+  auto wait_groups = [&](int g) {                                 // at most g DMA groups (stages) of this wave still in flight
+    if (g >= 3) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(3 * NDMA));
+    else if (g == 2) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
+    else if (g == 1) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
+    else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
+  };
+  // stage st: small set x and big rows 0..2 in registers; buffer `cur` holds stage st, `nxt` stage st + 1 (landed, visible), `tgt`
+  // held stage st - 1 (every read of it was consumed before the last barrier): stage st + 4 goes there
+  auto stage_r = [&](auto fast_c, int st, int x, const char* cur, const char* nxt, char* tgt) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    const bool more = FAST || st + NST - 1 < st_hi;                // a stage st + 4 to issue
+    const bool next = FAST || st + 1 < st_hi;                      // a stage st + 1 to read
+    if (more) issue(tgt);
+    // opaque copies of the two lane offsets: without them the XOR-ed fragment addresses are loop-invariant, get hoisted out of the
+    // trip and spilled - and every reload from scratch drains vmcnt, i.e. the whole DMA pipeline
+    int so = sf_off0, bo = bf_off0;
+    asm volatile("" : "+v"(so), "+v"(bo));
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 3 < 8) bfw[(i + 3) & 3] = frag(cur, bo ^ ((i + 3) << 5));
+      else if (next) bfw[(i + 3) & 3] = frag(nxt, bo ^ ((i + 3 - 8) << 5));
+      if (i == 3 && next) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) sfr[1 - x][j] = frag(nxt, so ^ (j << 5));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(sfr[x][j], bfw[i & 3], acc[i][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (FAST) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));   // stage st + 2 has landed; st + 3, st + 4 stay in flight
+    else wait_groups(min(max(st_hi - 1 - (st + 2), 0), 2));
+    __builtin_amdgcn_s_barrier();
+  };
+  // prologue: four stages in flight, small set 0 and big rows 0..2 of stage st_lo in registers, stage st_lo + 1 visible
+  issue(lds);
+  if (st_lo + 1 < st_hi) issue(lds + STAGE);
+  if (st_lo + 2 < st_hi) issue(lds + 2 * STAGE);
+  if (st_lo + 3 < st_hi) issue(lds + 3 * STAGE);
+  wait_groups(min(st_hi - 1 - st_lo, 3));
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; j++) sfr[0][j] = frag(lds, sf_off0 ^ (j << 5));
+#pragma unroll
+  for (int i = 0; i < 3; i++) bfw[i] = frag(lds, bf_off0 ^ (i << 5));
+  wait_groups(min(max(st_hi - 1 - (st_lo + 1), 0), 2));
+  __builtin_amdgcn_s_barrier();
+#define GCT2_WR_STAGE(FAST, K)                                                                                        \
+  {                                                                                                                   \
+    if (!FAST && st + (K) >= st_hi) break;                                                                            \
+    stage_r(std::integral_constant<bool, FAST>{}, st + (K), (K) & 1, lds + ((K) % 5) * STAGE, lds + (((K) + 1) % 5) * STAGE, \
+            lds + (((K) + 4) % 5) * STAGE);                                                                            \
+  }
+#define GCT2_WR_TRIP(FAST)                                                                                            \
+  GCT2_WR_STAGE(FAST, 0) GCT2_WR_STAGE(FAST, 1) GCT2_WR_STAGE(FAST, 2) GCT2_WR_STAGE(FAST, 3) GCT2_WR_STAGE(FAST, 4)     \
+  GCT2_WR_STAGE(FAST, 5) GCT2_WR_STAGE(FAST, 6) GCT2_WR_STAGE(FAST, 7) GCT2_WR_STAGE(FAST, 8) GCT2_WR_STAGE(FAST, 9)
+  int st = st_lo;
+  for (; st + 9 + NST - 1 < st_hi; st += 10) { GCT2_WR_TRIP(true) }   // every stage of the trip still issues a stage (st + 9 + 4 < st_hi)
+  for (; st < st_hi; st += 10) { GCT2_WR_TRIP(false) }           // the last trips (same roles: st - st_lo is a multiple of 10)
+#undef GCT2_WR_TRIP
+#undef GCT2_WR_STAGE
+  float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
+  const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
+  int elane = lane;
+  asm volatile("" : "+v"(elane));
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int row = gc0 + wm * 128 + i * 16 + (elane & 15);
+    if (row >= GC) continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int col = cs0 + wn * 64 + j * 16 + 4 * (elane >> 4);
+      if (col >= Cs) continue;
+      float* q = out + (size_t)row * Cs + col;
+      if (mode == 2) *reinterpret_cast<f32x4_t*>(q) = acc[i][j];
+      else if (mode == 1) { if (p.accumulate) *reinterpret_cast<f32x4_t*>(q) += acc[i][j]; else *reinterpret_cast<f32x4_t*>(q) = acc[i][j]; }
+      else {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) atomicAdd(q + rr, acc[i][j][rr]);
+      }
+    }
+  }
+}
+
 // dw[e] += sum_s slab[s][e], 4 elements per thread, slabs added in index order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n4, int nsplit,
                                                             int accumulate) {
@@ -1007,7 +1225,7 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   // comes along (47 -> 52 us alone) and the step is still 11 us shorter (profiles/r03_step_ab.txt); tuning bit 9 = the r02 limit.
   // DownShuffle_4 (16 steps of 64 rows) stays on the one-owner 128 x 128 tile: c.wgrad_big_minsteps = 8 steps per split
   const bool auto_tile = g_wgrad_variant == 0 || g_wgrad_variant == 6;
-  const bool big_tile0 = !p.ks && (g_wgrad_variant == 2 || g_wgrad_variant == 4 || g_wgrad_variant == 5 || g_wgrad_variant == 8 || (auto_tile && tiles128 < c.wgrad_big_limit && blocks256 >= 192));
+  const bool big_tile0 = !p.ks && (g_wgrad_variant == 2 || g_wgrad_variant == 4 || g_wgrad_variant == 5 || g_wgrad_variant == 8 || g_wgrad_variant == 9 || (auto_tile && tiles128 < c.wgrad_big_limit && blocks256 >= 192));
   // the five-stage pipeline runs the lean stage (wgrad256q_kernel, r03: -7..-16 % on the five big-tile layers) unless the tuning
   // word asks for the r02 stage code (variants 6 = automatic tile choice, 8 = 256 x 256 everywhere) or for four stages (bit 23)
   const bool lean_stage = g_wgrad_variant != 6 && g_wgrad_variant != 8 && c.wgrad_ring == 5;
@@ -1060,6 +1278,9 @@ int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, Wgrad
   } else if (tile2x) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad2x_kernel<__bf16>, grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL(wgrad2x_kernel<_Float16>, grid, dim3(512), 0, s, p);
+  } else if (big_tile && g_wgrad_pipe && g_wgrad_variant == 9) {   // fragments of the next stage read during the MFMAs (A/B)
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256r_kernel<__bf16>, grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(wgrad256r_kernel<_Float16>, grid, dim3(512), 0, s, p);
   } else if (big_tile && g_wgrad_pipe && lean_stage) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256q_kernel<__bf16>, grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL(wgrad256q_kernel<_Float16>, grid, dim3(512), 0, s, p);

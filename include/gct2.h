@@ -64,7 +64,8 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * bits 0-7: dgrad/forward tile, 0 = automatic, 1/2 = 128x128 with 1/2 LDS buffers, 3 = 256x128 8 waves 3 buffers,
  * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles);
  * bits 16-19: weight-gradient tile, 0 = automatic, 1/3 = 128x128 with 1/2 buffers, 2 (or 5) = 256x256, 4 = 256x128 at two
- * work-groups per CU, 7 = atomics, 6 / 8 = as 0 / 2 with the r02 stage code of the 256x256 pipeline instead of the lean stage;
+ * work-groups per CU, 7 = atomics, 6 / 8 = as 0 / 2 with the r02 stage code of the 256x256 pipeline instead of the lean stage,
+ * 9 = 256x256 with the fragment reads of the next rows / next stage issued under the MFMAs (wgrad256r_kernel: same speed);
  * bit 20: aim at 512 instead of 256 work-groups on the 256x256 weight-gradient tile; bit 21: at most 24 pixel splits as ordered
  * slabs on the 128x128 weight-gradient tile (r02; more splits then use atomics - arrival-order dependent; default since r03: slabs
  * whenever the workspace holds them);

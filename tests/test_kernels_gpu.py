@@ -222,7 +222,7 @@ def test_wgrad_reduction_modes_agree(gpu, shape):
 
 
 @pytest.mark.parametrize("use_ws", [False, True])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 0x42, 0x82])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 9, 0x42, 0x82])
 @pytest.mark.parametrize("shape", [(4, 32, 32, 64, 128), (1, 12, 20, 72, 136), (2, 8, 8, 256, 512)])
 def test_wgrad_tile_variants(gpu, variant, shape, use_ws):
     """weight-gradient tile variants: 1 = 128x128 single buffer, 2 = 256x256 (8 waves of 128x64) with the spanning pipeline (counted
@@ -270,7 +270,7 @@ def test_wgrad_lean_stage_equals_pipeline_bit_for_bit(gpu, shape):
     set_ws(ws)
     res = {}
     try:
-        for variant in (2, 8):
+        for variant in (2, 8, 9):
             set_tuning(variant << 16)
             dw = torch.zeros(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)
             dwt = torch.zeros(4, 4, Cout, Cin, dtype=torch.float32, device=gpu)
@@ -279,6 +279,7 @@ def test_wgrad_lean_stage_equals_pipeline_bit_for_bit(gpu, shape):
             torch.cuda.synchronize()
             res[variant] = (dw, dwt)
         assert torch.equal(res[2][0], res[8][0]) and torch.equal(res[2][1], res[8][1])
+        assert torch.equal(res[2][0], res[9][0]) and torch.equal(res[2][1], res[9][1])      # 9: rolling fragment window (wgrad256r_kernel)
         assert rel_l2(res[2][0].cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
         assert rel_l2(res[2][1].cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
     finally:
