@@ -48,6 +48,18 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_pie
   }
 }
 
+// the same with a wave-uniform byte offset in an SGPR (tap / k-chunk part of the address; the bounds check sees the per-lane offset)
+template <bool HIDDEN>
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff, unsigned soff) {
+  if constexpr (HIDDEN) {
+    const unsigned lds_addr = (unsigned)(uintptr_t)(lds_void_t*)lds_piece;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory", "m0");
+  } else {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, (int)soff, 0, 0);
+  }
+}
+
 // bias gradient = column sums of the masked gradient a dgrad launch produces: db[n] (+)= sum over pixels.  Channels
 // [0, db_split) go to p.db, the rest to p.db2 (the output of an UpShuffle dgrad spans two layers' pre-activations).
 __device__ __forceinline__ float* db_target(const TapGemmParams& p, int n) {
@@ -220,7 +232,56 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   const int nk = (K + BKS - 1) / BKS;
   const int niter = (S1 ? p.ks * p.ks : NTAPS) * nk;
 
+  // ---- lean issue (r03; the 4x4 / stride-2 forms): the r02 code below spent ~45 vector and ~60 scalar instructions per step on
+  // its 8 pieces (a scalar division for (tap, chunk), compare / select chains per piece).  Here: (tap, chunk) are counters (the steps
+  // are issued in order), the source descriptor is based ONE row + ONE pixel in front of the tensor so that the per-lane origin
+  // offsets are non-negative and the tap / chunk part of the address can go into the instruction's scalar offset, tap validity is
+  // a shift of the inverted mask into bit 31 of the per-lane offset (out of range -> zeros), the weight offsets are loop-invariant.
+  const unsigned shift_x = (unsigned)((Wsrc + 1) * ldx2);
+  const __amdgpu_buffer_rsrc_t rs_xs = make_rsrc(reinterpret_cast<const char*>(p.x) - (S1 ? 0 : shift_x));
+  unsigned a_voff[NA], a_nmask[NA], w_voff[NW];
+#pragma unroll
+  for (int i = 0; i < NA; i++) { a_voff[i] = a_mask[i] ? a_off[i] + shift_x : 0u; a_nmask[i] = ~a_mask[i]; }
+#pragma unroll
+  for (int i = 0; i < NW; i++) w_voff[i] = w_nok[i] ? w_off[i] : OOB;
+  int c_tap = 0, c_kc = 0;                          // (tap, k-chunk) of the next step to issue: set below, once it_lo is known
   auto issue = [&](int it, char* abase) {
+    if constexpr (!S1) {
+      const int tap = c_tap, c0 = c_kc * BKS;
+      int tap16, dh, dw;
+      if (FORM == FORM_CONV) { tap16 = tap; dh = tap >> 2; dw = tap & 3; }
+      else {
+        const int a = tap >> 1, c = tap & 1;
+        dh = 1 - a; dw = 1 - c;
+        tap16 = (1 - ph + 2 * a) * 4 + (1 - pw + 2 * c);
+      }
+      const int abit = (FORM == FORM_CONVT) ? dh * 2 + dw : tap;
+      const unsigned s_a = (unsigned)((dh * Wsrc + dw) * ldx2 + c0 * 2);
+      const unsigned s_w = WT ? (unsigned)(((tap16 * K + c0) * N) * 2) : (unsigned)((tap16 * N * K + c0) * 2);
+      char* wbase = abase + A_BYTES;
+      if (c0 + BKS <= K) {                          // block-uniform: a full chunk needs no per-lane channel check
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+          dma16s<NBUF >= 3>(rs_xs, abase + (wave + NWV * i) * 1024, a_voff[i] | ((a_nmask[i] >> abit) << 31), s_a);
+#pragma unroll
+        for (int i = 0; i < NW; i++)
+          dma16s<NBUF >= 3>(rs_w, wbase + ((RING && WT) ? i * (32 * 256) + wave * 1024 : (wave + NWV * i) * 1024), w_voff[i], s_w);
+      } else {                                      // the ragged last chunk (K % 64 != 0)
+        asm volatile("" ::: "memory");              // keeps hipcc from turning this branch into selects in the full-chunk path
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+          const unsigned v = a_voff[i] | ((a_nmask[i] >> abit) << 31);
+          dma16s<NBUF >= 3>(rs_xs, abase + (wave + NWV * i) * 1024, (c0 + a_lchunk * 8) < K ? v : OOB, s_a);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++)
+          dma16s<NBUF >= 3>(rs_w, wbase + ((RING && WT) ? i * (32 * 256) + wave * 1024 : (wave + NWV * i) * 1024),
+                            (c0 + w_k[i]) < K ? w_voff[i] : OOB, s_w);
+      }
+      c_kc++;
+      if (c_kc == nk) { c_kc = 0; c_tap++; }
+      return;
+    }
     const int tap = it / nk, c0 = (it - tap * nk) * BKS;
     int tap16, dh, dw;
     if (FORM == FORM_CONV) { tap16 = tap; dh = tap >> 2; dw = tap & 3; }
@@ -260,6 +321,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   // split-K: this workgroup reduces iterations [it_lo, it_hi) only and leaves an fp32 partial slab
   const int it_per = (niter + p.ksplit - 1) / p.ksplit;
   const int it_lo = kslice * it_per, it_hi = min(niter, it_lo + it_per);
+  c_tap = it_lo / nk;
+  c_kc = it_lo - c_tap * nk;
   auto compute = [&](const char* a_img) {
     const char* w_img = a_img + A_BYTES;
 #pragma unroll
