@@ -174,6 +174,7 @@ class UNetEngine:
         # train step: the forward epilogues of the large levels also write ReLU bit planes (1 bit per activation) and the input-gradient
         # epilogues read their masks from them instead of re-reading the activations (gct2_ctx_set_relu_bits; -16 bits per element read)
         self.relu_bits = True
+        self.relu_bits_min_bytes = 32 << 20     # planes only for activation tensors of at least this size (see buffers())
         self.arena = ParamArena(topo, dtype, self.device)
         self.arena.glorot_init(seed)
         self.arena.refresh_shadow(self._stream())
@@ -287,13 +288,14 @@ class UNetEngine:
         # packed copy of the network input (3 channels + a zero slot): DownShuffle_0 and its weight gradient gather 4x4
         # windows from it instead of striding through R_0's 144-byte rows
         b.img = z(B, H, W, 4)
-        # ReLU bit planes of R_1 .. R_{n-1} (levels with >= 8192 pixels: below that the mask reads are noise and the bottleneck layers'
-        # split-K launches would need an extra launch to derive the plane)
+        # ReLU bit planes of R_1 .. R_{n-1}, for tensors of >= relu_bits_min_bytes (32 MiB: the three big levels of config 3 / 5;
+        # below that the mask reads are noise and the small layers' split-K launches need an extra launch to derive the plane -
+        # measured at 3x64x64, batch 32: +9 us per step with planes on every level, -45 us at config 3)
         b.bits = [None] * n
         b.bits_valid = False
         for i in range(1, n):
             px = B * b.hw[i][0] * b.hw[i][1]
-            if self.dtype != F32 and px >= 8192 and b.ld[i] % 8 == 0 and t.fu(i) % 8 == 0:
+            if self.dtype != F32 and px * b.ld[i] * 2 >= self.relu_bits_min_bytes and b.ld[i] % 8 == 0 and t.fu(i) % 8 == 0:
                 b.bits[i] = torch.zeros(px, b.ld[i] // 8, dtype=torch.uint8, device=self.device)
         b.Dlast = z(B, b.hw[n][0], b.hw[n][1], t.fd(n - 1))
         b.dDlast = z(B, b.hw[n][0], b.hw[n][1], t.fd(n - 1))

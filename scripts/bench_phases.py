@@ -10,8 +10,9 @@ from gan_class_transfer2_amd.engine import Topology, UNetEngine, BF16
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dev = torch.device("cuda", 0)
 eng = UNetEngine(Topology(128, 512, 6), BF16, dev)
-x = torch.rand(64, 128, 128, 3, device=dev) * 2 - 1
-b = eng.buffers(64, 128, 128)
+BATCH, SIZE = int(os.environ.get("AB_BATCH", "64")), int(os.environ.get("AB_SIZE", "128"))     # config 3 unless told otherwise
+x = torch.rand(BATCH, SIZE, SIZE, 3, device=dev) * 2 - 1
+b = eng.buffers(BATCH, SIZE, SIZE)
 
 
 def fwd():
