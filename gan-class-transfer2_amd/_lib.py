@@ -10,7 +10,7 @@ import os
 
 F32, BF16, F16 = 0, 1, 2
 DTYPE_NAMES = {F32: "f32", BF16: "bf16", F16: "f16"}
-ABI_VERSION = 13
+ABI_VERSION = 14
 # gct2_diffusion_update modes (include/gct2.h; the sampler's objective switches, train.py:29-32)
 SAMPLE_X, SAMPLE_EPS, SAMPLE_SCALED_EPS, SAMPLE_ODE = 0, 1, 2, 3
 BUILD_STAMP = 1
@@ -51,9 +51,8 @@ SIGNATURES = {
     "gct2_ctx_force_direct": [_vp, _i],
     "gct2_ctx_set_stamp_buffer": [_vp, _vp, _sz],
     "gct2_ctx_set_relu_bits": [_vp, _vp, _i],
-    "gct2_ctx_set_rowsum_buffer": [_vp, _vp, _sz],
-    "gct2_rowsum_begin": [_vp],
-    "gct2_rowsum_flush": [_vp, _vp, _vp, _vp, _i, _vp],
+    "gct2_ctx_log_launches": [_vp, _i],
+    "gct2_ctx_read_launch_log": [_vp, _vp, _sz],
     "gct2_diffusion_mix": [_i, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _sz, _i, _vp],
     "gct2_diffusion_update": [_i, _vp, _vp, _d, _d, _vp, _vp, _sz, _vp],
     "gct2_noise_edits": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -142,7 +141,7 @@ class Context:
         h = C.c_void_p()
         call("gct2_ctx_create", C.byref(h))
         self.handle = h.value
-        self._keep = [None, None, None, None]
+        self._keep = [None, None, None]
         # bumped by every setter: whoever caches something that bakes in this context's pointers or tile choices (the sampler's
         # HIP graphs of the forward pass) keys its cache on it
         self.version = 0
@@ -159,12 +158,15 @@ class Context:
         call("gct2_ctx_set_stamp_buffer", self.handle, tensor.data_ptr() if tensor is not None else None,
              tensor.numel() * tensor.element_size() if tensor is not None else 0)
 
-    def set_rowsum_buffer(self, tensor) -> None:
-        """scratch for the deferred bias-gradient row sums of a whole reverse pass (gct2_rowsum_begin / gct2_rowsum_flush)."""
-        self._keep[3] = tensor
-        self.version += 1
-        call("gct2_ctx_set_rowsum_buffer", self.handle, tensor.data_ptr() if tensor is not None else None,
-             tensor.numel() * tensor.element_size() if tensor is not None else 0)
+    def log_launches(self, on: bool = True) -> None:
+        """launch log of this context (include/gct2.h): clears it and switches it on / off."""
+        call("gct2_ctx_log_launches", self.handle, int(bool(on)))
+
+    def read_launch_log(self) -> list:
+        """the kernels the layer calls of this context selected since the last read, as text tokens"""
+        buf = C.create_string_buffer(1 << 16)
+        call("gct2_ctx_read_launch_log", self.handle, C.cast(buf, C.c_void_p), len(buf))
+        return [t for t in buf.value.decode().split(";") if t]
 
     def set_workspace(self, tensor) -> None:
         self._keep[0] = tensor

@@ -6,13 +6,13 @@
 
 // implemented in the kernel translation units
 bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p);
-int tapgemm_mfma(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
+int tapgemm_mfma(gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
 int tapgemm_direct(int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s);
 bool wgrad_mfma_supported(int dtype, const WgradParams& p);
-int wgrad_mfma(const gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer);
+int wgrad_mfma(gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs* defer);
 int wgrad_direct(int dtype, const WgradParams& p, hipStream_t s);
 bool halo_head_supported(const gct2_ctx& c, int dtype, const TapGemmParams& p);
-int halo_head(const gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, float* loss, float* db_up, int accumulate, hipStream_t s);
+int halo_head(gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, float* loss, float* db_up, int accumulate, hipStream_t s);
 bool rgb_fwd_supported(int dtype, const TapGemmParams& p);
 int rgb_fwd(int dtype, const TapGemmParams& p, hipStream_t s);
 bool rgb_fwd_writes_bits(const TapGemmParams& p);
@@ -40,8 +40,6 @@ int pw_diffusion_mix(int, const float*, const float*, float, float*, void*, int,
 int pw_diffusion_update(int, const float*, const float*, double, double, float*, float*, size_t, hipStream_t);
 int pw_noise_edits(const float*, const float*, int, float*, int, int, int, hipStream_t);
 int pw_image_prepare(const uint8_t*, const int64_t*, const int32_t*, float*, int, int, hipStream_t);
-int rowsum_flush_launch(const gct2_ctx& c, const gct2_adam_args* adam, const float* g_base, const int64_t* bias_ranges, int nranges,
-                        hipStream_t s);   // tapgemm_mfma.hip
 int pw_adam(float*, float*, float*, float*, void*, int, size_t, float, float, float, float, float, const gct2_loss_scale_state*, int, hipStream_t,
             const float* slabs = nullptr, int nslab = 0, size_t slab_stride = 0, size_t n_slab = 0);
 int pw_cast(int, const float*, void*, size_t, hipStream_t);
@@ -50,9 +48,10 @@ int pw_ls_begin(gct2_loss_scale_state*, float, int, float, float, hipStream_t);
 int pw_ls_check(const float*, size_t, gct2_loss_scale_state*, hipStream_t);
 int pw_ls_update(gct2_loss_scale_state*, int, hipStream_t);
 
-// the only static storage of the library: the per-thread text of the last error, and an immutable default context for ctx = NULL
+// the only static storage of the library, all of it per host thread: the text of the last error, and the context that stands in
+// for ctx = NULL (no scratch, automatic tiles; reset at every use)
 static thread_local char g_err[512] = "";
-static const gct2_ctx g_default_ctx{};
+static thread_local gct2_ctx g_null_ctx{};
 
 int gct2_fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -60,6 +59,16 @@ int gct2_fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+void gct2_log(gct2_ctx& c, const char* fmt, ...) {
+  if (!c.log_on) return;
+  char buf[160];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  c.log += buf;
+  c.log += ';';
 }
 int gct2_check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
@@ -79,34 +88,48 @@ int check_conv_args(const char* fn, int dtype, const void* a, const void* b, con
   if ((size_t)B * H * W * 4 >= ((size_t)1 << 31)) return gct2_fail(GCT2_EINVAL, "%s: B*H*W too large for 32-bit pixel indices", fn);
   return GCT2_OK;
 }
-inline const gct2_ctx& C(const gct2_ctx* c) { return c ? *c : g_default_ctx; }
-// the ReLU bit plane registered for THIS call (gct2_ctx_set_relu_bits is one-shot): moved into the launch parameters, cleared in the ctx
-int take_relu_bits(const gct2_ctx& c, const char* fn, int channels, TapGemmParams& p) {
-  unsigned char* bits = c.relu_bits;
-  const int ld = c.relu_ldbits;
-  c.relu_bits = nullptr; c.relu_ldbits = 0; c.relu_bits_done = 0;
-  if (!bits) return GCT2_OK;
-  if (channels % 8 || ld < channels / 8) return gct2_fail(GCT2_EINVAL, "%s: ReLU bit plane needs channels %% 8 == 0 and ld_bytes >= channels / 8 (got %d, %d)", fn, channels, ld);
-  p.bits = bits; p.ldbits = ld;
-  return GCT2_OK;
+inline gct2_ctx& C(gct2_ctx* c) {
+  if (c) return *c;
+  g_null_ctx = gct2_ctx{};
+  return g_null_ctx;
 }
+// The ReLU bit plane registered for THIS call (gct2_ctx_set_relu_bits is one-shot).  Every layer entry point constructs one of these
+// FIRST THING - before any argument check - so that a plane never outlives the call it was registered for, whatever that call
+// returns (r03 consumed it behind the checks: a rejected call leaked its plane to the next layer call).
+struct PlaneTaken {
+  unsigned char* bits; int ld;
+  explicit PlaneTaken(gct2_ctx& c) : bits(c.relu_bits), ld(c.relu_ldbits) { c.relu_bits = nullptr; c.relu_ldbits = 0; c.relu_bits_done = 0; }
+  // entry points that cannot use a plane: a pending one is a caller error
+  int none(const char* fn) const {
+    return bits ? gct2_fail(GCT2_EINVAL, "%s: a ReLU bit plane was registered (gct2_ctx_set_relu_bits), but this call neither writes nor reads one", fn) : GCT2_OK;
+  }
+  int into(const char* fn, int channels, TapGemmParams& p) const {
+    if (!bits) return GCT2_OK;
+    if (channels % 8 || ld < channels / 8) return gct2_fail(GCT2_EINVAL, "%s: ReLU bit plane needs channels %% 8 == 0 and ld_bytes >= channels / 8 (got %d, %d)", fn, channels, ld);
+    p.bits = bits; p.ldbits = ld;
+    return GCT2_OK;
+  }
+};
 // forward calls: if the launch did not write the plane in its epilogue, derive it from the activation it stored
-int finish_relu_bits(const gct2_ctx& c, int dtype, const TapGemmParams& p, size_t pixels, void* stream) {
+int finish_relu_bits(gct2_ctx& c, int dtype, const TapGemmParams& p, size_t pixels, void* stream) {
   if (!p.bits || c.relu_bits_done) return GCT2_OK;
+  gct2_log(c, "relu_bits:derived");
   return pw_relu_bits(dtype, p.y, p.ldy, pixels, p.N, p.bits, p.ldbits, S(stream));
 }
-int run_tapgemm(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, void* stream) {
+int run_tapgemm(gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, void* stream) {
   if (!c.force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(c, dtype, form, epi, p, S(stream));
+  gct2_log(c, "direct:tap");
   return tapgemm_direct(dtype, form, epi, p, S(stream));
 }
 // input-gradient launch with optional fused bias gradient: db (+)= column sums of the masked gradient THIS call produces
 // (channels [0, split) -> db, the rest -> db2).  MFMA path: fused into the epilogue / split-K finalize.  Direct path:
 // column sums of the output view after the launch, minus those before it when the launch accumulates.
-int run_dgrad(const gct2_ctx& c, int dtype, int form, TapGemmParams p, size_t out_pixels, float* db, int split, float* db2, int db_acc,
+int run_dgrad(gct2_ctx& c, int dtype, int form, TapGemmParams p, size_t out_pixels, float* db, int split, float* db2, int db_acc,
               void* stream) {
   if (split < 0 || split > p.N) return gct2_fail(GCT2_EINVAL, "dgrad: db_split out of range");
   p.db = db; p.db_split = split; p.db2 = db2; p.db_acc = db_acc;
   if (!c.force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(c, dtype, form, EPI_MASK, p, S(stream));
+  gct2_log(c, "direct:tap");
   zero_overwritten_db(p, S(stream));        // the column-sum kernels below add with atomics
   const size_t es = esize(dtype);
   auto sums = [&](float sign) -> int {
@@ -119,9 +142,10 @@ int run_dgrad(const gct2_ctx& c, int dtype, int form, TapGemmParams p, size_t ou
   if (int e = tapgemm_direct(dtype, form, EPI_MASK, p, S(stream))) return e;
   return (db || db2) ? sums(1.f) : GCT2_OK;
 }
-int run_wgrad(const gct2_ctx& c, int dtype, const WgradParams& p, void* stream, WgradSlabs* defer = nullptr) {
+int run_wgrad(gct2_ctx& c, int dtype, const WgradParams& p, void* stream, WgradSlabs* defer = nullptr) {
   if (!c.force_direct && wgrad_mfma_supported(dtype, p)) return wgrad_mfma(c, dtype, p, S(stream), defer);
   if (defer) *defer = WgradSlabs{nullptr, 0, 0};
+  gct2_log(c, "direct:wgrad");
   return wgrad_direct(dtype, p, S(stream));
 }
 // bias gradient of a weight-gradient call: db (+)= column sums of dz (atomics: an overwritten target starts from zero)
@@ -139,14 +163,6 @@ int check_adam_args(const gct2_adam_args* a, const float* dw, size_t nw) {
   return GCT2_OK;
 }
 int adam_after_wgrad(const gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& sl, void* stream) {
-  if (sl.adam_done) {
-    // the weight-gradient launch updated the kernel in its epilogue: what is left of the layer's range is the bias (behind the
-    // kernel, gradient in the arena behind dw)
-    if (a->n == nw) return GCT2_OK;
-    const size_t es = a->shadow_dtype == GCT2_F32 ? 4 : 2;
-    return pw_adam(a->p + nw, a->m + nw, a->v + nw, dw + nw, a->shadow ? (char*)a->shadow + nw * es : nullptr, a->shadow_dtype, a->n - nw,
-                   a->alpha, a->beta1, a->beta2, a->eps, a->grad_mul, nullptr, 0, S(stream));
-  }
   return pw_adam(a->p, a->m, a->v, dw, a->shadow, a->shadow_dtype, a->n, a->alpha, a->beta1, a->beta2, a->eps, a->grad_mul, nullptr, 0,
                  S(stream), sl.base, sl.nslab, sl.stride, sl.nslab ? nw : 0);
 }
@@ -154,7 +170,7 @@ int adam_after_wgrad(const gct2_adam_args* a, float* dw, size_t nw, const WgradS
 
 extern "C" {
 
-int gct2_abi_version(void) { return 13; }
+int gct2_abi_version(void) { return 14; }
 int gct2_build_flags(void) {
 #ifdef GCT2_STAMP
   return GCT2_BUILD_STAMP;
@@ -189,22 +205,14 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes) {
 }
 int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_tuning: null ctx");
-  ctx->tap_variant = v & 0xff;
-  const int wv = (v >> 16) & 0xff;
-  ctx->wgrad_variant = wv & 0xf;
-  ctx->wgrad_pipe = (wv & 0x40) ? 0 : 1;
-  ctx->wgrad_target = (wv & 0x10) ? 512 : 256;
-  ctx->wgrad_slab_max = (wv & 0x20) ? 24 : 128;
-  ctx->wgrad_ring = (wv & 0x80) ? 4 : 5;
+  const int tap = v & 0xff, wg = (v >> 16) & 0xff, known = 0xff | (0xff << 16) | (0x7f << 24);
+  if ((v & ~known) || (tap != 0 && tap != 2 && tap != 5) || (wg != 0 && wg != 2 && wg != 3 && wg != 7) || ((v >> 24) & 3) == 3 || ((v >> 26) & 3) == 3)
+    return gct2_fail(GCT2_EINVAL, "ctx_set_tuning: unknown tuning word 0x%x (include/gct2.h)", v);
+  ctx->tap_variant = tap;
+  ctx->wgrad_variant = wg;
   ctx->halo_mode = (v >> 24) & 3;
   ctx->xcd_order = (v >> 26) & 3;
   ctx->wgrad_split = (v >> 28) & 7;
-  ctx->halo_il = (int)(((unsigned)v >> 31) & 1u) ? 0 : 1;
-  ctx->wgrad_fuse_adam = (v & 0x100) ? 1 : 0;
-  ctx->wgrad_big_limit = (v & 0x200) ? 256 : 512;
-  ctx->halo_conv_auto = (v & 0x1000) ? 1 : 0;
-  ctx->stagger = (v >> 13) & 7;
-  ctx->wgrad_big_minsteps = ((v >> 10) & 3) == 1 ? 4 : ((v >> 10) & 3) == 2 ? 32 : 8;
   return GCT2_OK;
 }
 int gct2_ctx_set_relu_bits(gct2_ctx* ctx, void* bits, int ld_bytes) {
@@ -226,29 +234,19 @@ int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes) {
   return gct2_fail(GCT2_EINVAL, "ctx_set_stamp_buffer: this is the product build (rebuild with make EXTRA=-DGCT2_STAMP for in-kernel stamps)");
 #endif
 }
-int gct2_ctx_set_rowsum_buffer(gct2_ctx* ctx, void* buf, size_t bytes) {
-  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_rowsum_buffer: null ctx");
-  if (buf && ((uintptr_t)buf % 16)) return gct2_fail(GCT2_EINVAL, "ctx_set_rowsum_buffer: pointer must be 16-byte aligned");
-  if (ctx->rowsum.open) return gct2_fail(GCT2_EINVAL, "ctx_set_rowsum_buffer: a row-sum deferral is open (flush it first)");
-  ctx->rowsum.buf = buf ? reinterpret_cast<float*>(buf) : nullptr;
-  ctx->rowsum.bytes = buf ? bytes : 0;
+int gct2_ctx_log_launches(gct2_ctx* ctx, int on) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_log_launches: null ctx");
+  ctx->log_on = on != 0;
+  ctx->log.clear();
   return GCT2_OK;
 }
-int gct2_rowsum_begin(gct2_ctx* ctx) {
-  if (!ctx || !ctx->rowsum.buf) return gct2_fail(GCT2_EINVAL, "rowsum_begin: needs a ctx with a row-sum buffer (gct2_ctx_set_rowsum_buffer)");
-  if (!ctx->ws) return gct2_fail(GCT2_EINVAL, "rowsum_begin: needs a ctx workspace (without one the bias gradients are summed with atomics)");
-  ctx->rowsum.open = true; ctx->rowsum.used = 0; ctx->rowsum.overflow = false;
-  ctx->rowsum.table.ntargets = 0; ctx->rowsum.table.nblocks = 0;
+int gct2_ctx_read_launch_log(gct2_ctx* ctx, char* buf, size_t bytes) {
+  if (!ctx || !buf || bytes == 0) return gct2_fail(GCT2_EINVAL, "ctx_read_launch_log: null ctx / buffer");
+  const size_t n = ctx->log.size() < bytes - 1 ? ctx->log.size() : bytes - 1;
+  memcpy(buf, ctx->log.data(), n);
+  buf[n] = 0;
+  ctx->log.clear();
   return GCT2_OK;
-}
-int gct2_rowsum_flush(gct2_ctx* ctx, const gct2_adam_args* adam, const float* g_base, const int64_t* bias_ranges, int nranges, void* stream) {
-  if (!ctx || !ctx->rowsum.open) return gct2_fail(GCT2_EINVAL, "rowsum_flush: no deferral open on this ctx (gct2_rowsum_begin)");
-  if (adam && (!adam->p || !adam->m || !adam->v || !g_base || nranges < 0 || (nranges > 0 && !bias_ranges)))
-    return gct2_fail(GCT2_EINVAL, "rowsum_flush: the fused bias optimizer needs the p / m / v arena bases, the gradient arena base and the bias ranges");
-  for (int r = 0; adam && r < nranges; r++)
-    if (bias_ranges[2 * r] < 0 || bias_ranges[2 * r + 1] <= 0 || (size_t)(bias_ranges[2 * r] + bias_ranges[2 * r + 1]) > adam->n)
-      return gct2_fail(GCT2_EINVAL, "rowsum_flush: bias range %d lies outside the arena of %zu elements", r, adam->n);
-  return rowsum_flush_launch(*ctx, adam, g_base, bias_ranges, nranges, S(stream));
 }
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on) {
   if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_force_direct: null ctx");
@@ -267,14 +265,16 @@ int gct2_device_check(void) {
 
 int gct2_conv4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
                      int Cin, int Cout, int relu, void* stream) {
-  const gct2_ctx& c = C(ctx);
+  gct2_ctx& c = C(ctx);
+  const PlaneTaken plane(c);
   if (int e = check_conv_args("conv4s2_fwd", dtype, x, w, y, B, H, W, Cin, Cout)) return e;
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: H=%d W=%d must be even (skip concat, train.py:114-119)", H, W);
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_fwd: ld smaller than channel count");
   TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H / 2, W / 2, Cin, Cout, relu, 0};
-  if (int e = take_relu_bits(c, "conv4s2_fwd", Cout, p)) return e;
+  if (int e = plane.into("conv4s2_fwd", Cout, p)) return e;
   const size_t out_pixels = (size_t)B * (H / 2) * (W / 2);
   if (!c.force_direct && rgb_fwd_supported(dtype, p)) {                                       // image layer (Cin <= 4)
+    gct2_log(c, "rgb:fwd");
     if (int e = rgb_fwd(dtype, p, S(stream))) return e;
     if (p.bits && rgb_fwd_writes_bits(p)) c.relu_bits_done = 1;
     return finish_relu_bits(c, dtype, p, out_pixels, stream);
@@ -285,18 +285,21 @@ int gct2_conv4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const voi
 
 int gct2_conv4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
                        int H, int W, int Cin, int Cout, int accumulate, float* db, int db_split, float* db2, int db_accumulate, void* stream) {
+  gct2_ctx& c = C(ctx);
+  const PlaneTaken plane(c);
   if (int e = check_conv_args("conv4s2_dgrad", dtype, dz, w, dx, B, H, W, Cin, Cout)) return e;
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: H=%d W=%d must be even", H, W);
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "conv4s2_dgrad: ld smaller than channel count");
   TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H / 2, W / 2, Cout, Cin, 0, accumulate};
-  if (int e = take_relu_bits(C(ctx), "conv4s2_dgrad", Cin, p)) return e;
+  if (int e = plane.into("conv4s2_dgrad", Cin, p)) return e;
   if (!act) p.bits = nullptr;                                   // the plane stands in for act: no mask asked for, none applied
-  return run_dgrad(C(ctx), dtype, FORM_CONVT, p, (size_t)B * H * W, db, db_split, db2, db_accumulate, stream);
+  return run_dgrad(c, dtype, FORM_CONVT, p, (size_t)B * H * W, db, db_split, db2, db_accumulate, stream);
 }
 
 int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
                        int Cin, int Cout, int accumulate, const gct2_adam_args* adam, void* stream) {
-  const gct2_ctx& c = C(ctx);
+  gct2_ctx& c = C(ctx);
+  if (int e = PlaneTaken(c).none("conv4s2_wgrad")) return e;
   if (int e = check_conv_args("conv4s2_wgrad", dtype, x, dz, dw, B, H, W, Cin, Cout)) return e;
   if ((H & 1) || (W & 1)) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: H=%d W=%d must be even", H, W);
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "conv4s2_wgrad: ld smaller than channel count");
@@ -305,8 +308,8 @@ int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const v
   p.accumulate = accumulate ? 1 : 0;
   WgradSlabs sl{nullptr, 0, 0};
   if (adam) if (int e = check_adam_args(adam, dw, (size_t)16 * Cin * Cout)) return e;
-  sl.want_adam = adam;
   if (!c.force_direct && rgb_wgrad_supported(dtype, p)) {
+    gct2_log(c, "rgb:wgrad");
     if (int e = rgb_wgrad(c, dtype, p, S(stream), adam ? &sl : nullptr)) return e;
   } else if (int e = run_wgrad(c, dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)
@@ -317,11 +320,12 @@ int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const v
 
 int gct2_convT4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
                       int Cin, int Cout, int relu, void* stream) {
+  gct2_ctx& c = C(ctx);
+  const PlaneTaken plane(c);
   if (int e = check_conv_args("convT4s2_fwd", dtype, x, w, y, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_fwd: ld smaller than channel count");
   TapGemmParams p{x, ldx, w, bias, nullptr, 0, y, ldy, B, H, W, Cin, Cout, relu, 0};
-  const gct2_ctx& c = C(ctx);
-  if (int e = take_relu_bits(c, "convT4s2_fwd", Cout, p)) return e;
+  if (int e = plane.into("convT4s2_fwd", Cout, p)) return e;
   if (int e = run_tapgemm(c, dtype, FORM_CONVT, EPI_BIAS_ACT, p, stream)) return e;
   return finish_relu_bits(c, dtype, p, (size_t)B * 4 * H * W, stream);
 }
@@ -330,13 +334,14 @@ int gct2_convT4s2_fwd_head_train(gct2_ctx* ctx, int dtype, const void* x, int ld
                                  const float* head_b, const float* target, float* pred, void* dy, int lddy, float* head_dw, float* head_db,
                                  float* loss, int B, int H, int W, int Cin, int Cout, int head_Cin, int head_Cout,
                                  const float* loss_scale_ptr, float* db, const void* x2, int ldx2, int accumulate, void* stream) {
+  gct2_ctx& c = C(ctx);
+  if (int e = PlaneTaken(c).none("convT4s2_fwd_head_train")) return e;
   if (int e = check_conv_args("convT4s2_fwd_head_train", dtype, x, w, dy, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (!head_w || !target || !head_dw || !loss) return gct2_fail(GCT2_EINVAL, "convT4s2_fwd_head_train: null pointer");
   if (ldx < Cin || lddy < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_fwd_head_train: ld smaller than channel count");
   const int nimg = head_Cin - Cout;
   if (head_Cout < 1 || head_Cout > 3 || nimg < 0 || nimg > 3 || (nimg > 0 && (!x2 || ldx2 < 4 || ldx2 % 4 || (uintptr_t)x2 % 8)))
     return gct2_fail(GCT2_EINVAL, "convT4s2_fwd_head_train: head needs <= 3 outputs and <= 3 image channels in a packed x2 (8-byte rows)");
-  const gct2_ctx& c = C(ctx);
   TapGemmParams p{x, ldx, w, bias, nullptr, 0, dy, lddy, B, H, W, Cin, Cout, 1, 0};
   p.head = HeadFuse{head_w, head_b, target, pred, x2, ldx2, nullptr, loss_scale_ptr, head_Cin, head_Cout,
                     (float)((double)B * 2 * H * 2 * W * head_Cout)};
@@ -348,16 +353,20 @@ int gct2_convT4s2_fwd_head_train(gct2_ctx* ctx, int dtype, const void* x, int ld
 
 int gct2_convT4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
                         int H, int W, int Cin, int Cout, int accumulate, float* db, int db_split, float* db2, int db_accumulate, void* stream) {
+  gct2_ctx& c = C(ctx);
+  const PlaneTaken plane(c);
   if (int e = check_conv_args("convT4s2_dgrad", dtype, dz, w, dx, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "convT4s2_dgrad: ld smaller than channel count");
   TapGemmParams p{dz, lddz, w, nullptr, act, ldact, dx, lddx, B, H, W, Cout, Cin, 0, accumulate};
-  if (int e = take_relu_bits(C(ctx), "convT4s2_dgrad", Cin, p)) return e;
+  if (int e = plane.into("convT4s2_dgrad", Cin, p)) return e;
   if (!act) p.bits = nullptr;
-  return run_dgrad(C(ctx), dtype, FORM_CONV, p, (size_t)B * H * W, db, db_split, db2, db_accumulate, stream);
+  return run_dgrad(c, dtype, FORM_CONV, p, (size_t)B * H * W, db, db_split, db2, db_accumulate, stream);
 }
 
 int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
                         int Cin, int Cout, int accumulate, const gct2_adam_args* adam, void* stream) {
+  gct2_ctx& c = C(ctx);
+  if (int e = PlaneTaken(c).none("convT4s2_wgrad")) return e;
   if (int e = check_conv_args("convT4s2_wgrad", dtype, x, dz, dw, B, 2 * H, 2 * W, Cin, Cout)) return e;
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: ld smaller than channel count");
   if (adam && accumulate) return gct2_fail(GCT2_EINVAL, "convT4s2_wgrad: the fused optimizer step needs accumulate = 0");
@@ -365,8 +374,7 @@ int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const 
   p.accumulate = accumulate ? 1 : 0;
   WgradSlabs sl{nullptr, 0, 0};
   if (adam) if (int e = check_adam_args(adam, dw, (size_t)16 * Cin * Cout)) return e;
-  sl.want_adam = adam;
-  if (int e = run_wgrad(C(ctx), dtype, p, stream, adam ? &sl : nullptr)) return e;
+  if (int e = run_wgrad(c, dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)
     if (int e = wgrad_db(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, accumulate, stream)) return e;
   if (adam) return adam_after_wgrad(adam, dw, (size_t)16 * Cin * Cout, sl, stream);
@@ -381,7 +389,8 @@ static int check_s1(const char* fn, int dtype, const void* a, const void* b, con
 }
 int gct2_conv2d_s1_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
                        int Cin, int Cout, int KS, int relu, void* stream) {
-  const gct2_ctx& c = C(ctx);
+  gct2_ctx& c = C(ctx);
+  if (int e = PlaneTaken(c).none("conv2d_s1_fwd")) return e;
   if (int e = check_s1("conv2d_s1_fwd", dtype, x, w, y, B, H, W, Cin, Cout, KS)) return e;
   if (ldx < Cin || ldy < Cout) return gct2_fail(GCT2_EINVAL, "conv2d_s1_fwd: ld smaller than channel count");
   {   // matrix-core form (third tap-GEMM form: ks x ks taps on one grid) where the 16-bit layouts allow it, else one thread per output
@@ -393,7 +402,8 @@ int gct2_conv2d_s1_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const v
 }
 int gct2_conv2d_s1_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const void* w, const void* act, int ldact, void* dx, int lddx, int B,
                          int H, int W, int Cin, int Cout, int KS, int accumulate, void* stream) {
-  const gct2_ctx& c = C(ctx);
+  gct2_ctx& c = C(ctx);
+  if (int e = PlaneTaken(c).none("conv2d_s1_dgrad")) return e;
   if (int e = check_s1("conv2d_s1_dgrad", dtype, dz, w, dx, B, H, W, Cin, Cout, KS)) return e;
   if (lddz < Cout || lddx < Cin || (act && ldact < Cin)) return gct2_fail(GCT2_EINVAL, "conv2d_s1_dgrad: ld smaller than channel count");
   {
@@ -405,7 +415,8 @@ int gct2_conv2d_s1_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, con
 }
 int gct2_conv2d_s1_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
                          int Cin, int Cout, int KS, int accumulate, void* stream) {
-  const gct2_ctx& c = C(ctx);
+  gct2_ctx& c = C(ctx);
+  if (int e = PlaneTaken(c).none("conv2d_s1_wgrad")) return e;
   if (int e = check_s1("conv2d_s1_wgrad", dtype, x, dz, dw, B, H, W, Cin, Cout, KS)) return e;
   if (ldx < Cin || lddz < Cout) return gct2_fail(GCT2_EINVAL, "conv2d_s1_wgrad: ld smaller than channel count");
   WgradParams p{x, ldx, dz, lddz, dw, B, H, W, Cin, Cout, 1};
@@ -452,6 +463,8 @@ int gct2_dense_bwd(int dtype, const void* x, int ldx, const float* w, const floa
 int gct2_dense_head_train(gct2_ctx* ctx, int dtype, const void* x, int ldx, const float* w, const float* b, const float* target, float* pred,
                           void* dx, int lddx, float* dw, float* db, float* loss, float* partials, int M, int Cin, int Cout, int Cmask,
                           const float* loss_scale_ptr, float* db_dx, const void* x2, int ldx2, int accumulate, void* stream) {
+  gct2_ctx& c = C(ctx);
+  if (int e = PlaneTaken(c).none("dense_head_train")) return e;
   if ((dtype != GCT2_BF16 && dtype != GCT2_F16) || !x || !w || !target || !dx || !dw || !loss || !partials)
     return gct2_fail(GCT2_EINVAL, "dense_head_train: 16-bit dtypes only / null pointer (use dense_fwd + mse_fwd_bwd + dense_bwd)");
   if (x2 && (ldx2 < Cin - Cmask || ldx2 % 4 || (uintptr_t)x2 % 8 || Cin - Cmask > 4))
@@ -462,7 +475,7 @@ int gct2_dense_head_train(gct2_ctx* ctx, int dtype, const void* x, int ldx, cons
   if ((uintptr_t)x % 16 || (uintptr_t)dx % 16) return gct2_fail(GCT2_EINVAL, "dense_head_train: views must be 16-byte aligned");
   if ((size_t)256 * ldx * 2 + (size_t)256 * Cmask * 2 + 256 * 16 + (size_t)ldx * 16 > 160 * 1024)
     return gct2_fail(GCT2_EINVAL, "dense_head_train: ldx=%d too large for the LDS tile", ldx);
-  return pw_dense_head_train(C(ctx), dtype, x, ldx, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, loss_scale_ptr,
+  return pw_dense_head_train(c, dtype, x, ldx, w, b, target, pred, dx, lddx, dw, db, loss, partials, M, Cin, Cout, Cmask, loss_scale_ptr,
                              db_dx, x2, ldx2, accumulate, S(stream));
 }
 

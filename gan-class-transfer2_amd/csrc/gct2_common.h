@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <string>
 #include "../../include/gct2.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -17,52 +18,31 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 int gct2_fail(int code, const char* fmt, ...);
 int gct2_check_launch(const char* what);
 
-// Deferred bias-gradient row sums (gct2_rowsum_begin / gct2_rowsum_flush, include/gct2.h): while a deferral is open, the input-gradient
-// launches of a reverse pass leave their partial rows in the caller's row-sum buffer and only RECORD where each bias gradient comes
-// from; the flush is ONE launch that sums every target's sources in recording order (and can apply Keras Adam to those biases).
-constexpr int ROWSUM_MAX_TARGETS = 16, ROWSUM_MAX_SRC = 2;
-struct RowsumSrc { const float* part; int rows; int ld; int col0; };           // part[r * ld + col0 + c], r < rows
-struct RowsumTarget { float* dst; int ncols; int nsrc; int add; int blk0; int adam; RowsumSrc src[ROWSUM_MAX_SRC]; };   // adam: the flush applies the optimizer to it
-struct RowsumTable {
-  int ntargets = 0, nblocks = 0;
-  RowsumTarget t[ROWSUM_MAX_TARGETS];
-};
-struct RowsumState {
-  float* buf = nullptr; size_t bytes = 0;          // the caller's buffer (gct2_ctx_set_rowsum_buffer)
-  bool open = false;                               // between gct2_rowsum_begin and gct2_rowsum_flush
-  size_t used = 0;                                 // bump pointer (floats)
-  bool overflow = false;                           // a launch did not fit any more: it reduced its rows itself (still correct)
-  RowsumTable table;
-};
-
-// the call context of include/gct2.h: caller-owned scratch + tile-selection knobs.  Host memory, read-only during a call (except
-// the row-sum record, which the input-gradient entry points append to while a deferral is open).
+// the call context of include/gct2.h: caller-owned scratch + tile-selection knobs.  Host memory, used by ONE host thread at a time
+// (the one-shot ReLU plane and the launch log are written by the layer entry points).
 struct gct2_ctx {
   float* ws = nullptr; size_t ws_bytes = 0;        // split-K slabs, partial rows (forward / input-gradient / head calls)
   float* wws = nullptr; size_t wws_bytes = 0;      // weight-gradient slabs (falls back to ws)
-  int tap_variant = 0;                             // forward / input-gradient tile (0 = automatic)
-  int wgrad_variant = 0, wgrad_pipe = 1, wgrad_target = 256, wgrad_slab_max = 128;   // slabs (ordered sums) whenever the workspace holds them: atomics only without one
-  int wgrad_ring = 5;                              // stage buffers of the 256 x 256 weight-gradient pipeline (5 = all of the LDS; 4: A/B)
-  int wgrad_fuse_adam = 0;                         // 1: one-owner weight-gradient tiles apply the fused optimizer step in their epilogue (measured +70 us per step: off)
-  int stagger = 0;                // one-work-group-per-CU kernels: start offset between CU groups, units of 2048 cycles (tuning bits 13-15)
-  int halo_conv_auto = 0;         // 1: FORM_CONV launches with full 256-channel tiles take the conv-form halo kernel (tuning bit 12; off: measured slower)
-  int wgrad_big_minsteps = 8;     // ... and only with at least this many 64-row steps per pixel split (tuning bits 10-11: 4, 32)
-  int wgrad_big_limit = 512;      // automatic weight-gradient tile: 256 x 256 below this many 128 x 128 tiles (tuning bit 9: 256, the r02 rule)
+  int tap_variant = 0;                             // forward / input-gradient tile: 0 = automatic, 2 = 128 x 128, 5 = 256 x 128
+  int wgrad_variant = 0;                           // weight-gradient tile: 0 = automatic, 2 = 256 x 256, 3 = 128 x 128, 7 = 128 x 128 with atomics
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
-  int halo_il = 1;                                 // halo kernel: DMA pieces interleaved with the MFMA groups (0: in front of them, A/B)
   int xcd_order = 0;                               // tile -> XCD order: 0 = automatic, 1 = m-tile bands, 2 = weight slices
   int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile: 0 = automatic, v: 2^(v-1)
   int force_direct = 0;
   unsigned long long* stamps = nullptr; size_t stamps_bytes = 0;   // diagnostic builds only (gct2_ctx_set_stamp_buffer)
-  mutable RowsumState rowsum;
-  // ReLU bit plane for the NEXT layer call (gct2_ctx_set_relu_bits): consumed - and cleared - by the next forward / input-gradient
-  // entry point; relu_bits_done: the launch that just ran wrote the plane in its epilogue (else the entry point derives it from y)
-  mutable unsigned char* relu_bits = nullptr; mutable int relu_ldbits = 0; mutable int relu_bits_done = 0;
+  // ReLU bit plane for the NEXT layer call (gct2_ctx_set_relu_bits): every layer entry point takes it out of the ctx first thing
+  // (consumed by the forward / input-gradient calls, an error on the others); relu_bits_done: the launch that just ran wrote the
+  // plane in its epilogue (else the forward entry point derives it from y)
+  unsigned char* relu_bits = nullptr; int relu_ldbits = 0; int relu_bits_done = 0;
+  // launch log (gct2_ctx_log_launches): which kernel every layer call selected, as text tokens - for tests that must know
+  bool log_on = false; std::string log;
   float* wgrad_scratch(size_t* bytes) const {
     if (wws) { *bytes = wws_bytes; return wws; }
     *bytes = ws_bytes; return ws;
   }
 };
+// appends "token;" to the launch log of the ctx when it is enabled (capi.hip)
+void gct2_log(gct2_ctx& c, const char* fmt, ...);
 
 template <typename T> struct is16 { static constexpr bool value = sizeof(T) == 2; };
 
@@ -96,11 +76,6 @@ __device__ __forceinline__ int timg_off(int k, int chunk16) {
   return k * 256 + ((((chunk16 >> 1) ^ timg_swz(k))) << 5) + ((chunk16 & 1) << 4);
 }
 
-// "ring image" of the deep-pipelined 256 x 256 tap GEMM: [rows][32 x 16-bit] = 64-byte rows (half a 64-channel step), 16-byte chunk c
-//  of row r stored at chunk c ^ ring_swz((r>>2)&3): ds_read_b128 of 16 consecutive rows (row = base + (lane&15), chunk = lane>>4) is
-//  conflict-free for bases that are multiples of 16 (exhaustive check against the ds_read_b128 lane groups of MI355X_MICROARCH.md).
-__device__ __forceinline__ int ring_swz(int x) { return (4 - x) & 3; }       // {0, 3, 2, 1}
-
 __device__ __forceinline__ u32x4_t lds_read128(const char* lds, int off) {
   return *reinterpret_cast<const u32x4_t*>(lds + off);
 }
@@ -110,10 +85,6 @@ __device__ __forceinline__ void lds_write128(char* lds, int off, u32x4_t v) {
 // fragment (8 consecutive reduction elements for this lane's row/col) out of an N image
 __device__ __forceinline__ u32x4_t nimg_frag(const char* img, int rowbase, int kk, int lane) {
   return lds_read128(img, nimg_off(rowbase + (lane & 15), 4 * kk + (lane >> 4)));
-}
-// fragment (8 consecutive reduction elements of the 32-deep stage) out of a ring image; rowbase is a multiple of 16
-__device__ __forceinline__ u32x4_t ring_frag(const char* img, int rowbase, int lane) {
-  return lds_read128(img, (rowbase + (lane & 15)) * 64 + (((lane >> 4) ^ ring_swz((lane >> 2) & 3)) << 4));
 }
 // same fragment out of a T image (column block `colbase`, multiple of 16) via two transposed reads
 __device__ __forceinline__ u32x4_t timg_frag(const char* img, int colbase, int kk, int lane) {
@@ -254,7 +225,6 @@ struct TapGemmParams {
   float* dbws;                           // partial bias-gradient rows [m_tiles*phases | finalize rows][N] in the workspace, or null (atomics)
   HeadFuse head;                         // EPI_HEAD only
   int ks = 0;                            // FORM_S1 / FORM_S1T: kernel size (odd, <= 5)
-  int stagger = 0;                       // halo kernels: see stagger_start()
   int bits_words = 0;                    // 1: plane and strides are 4-byte aligned and N % 32 == 0 -> the four lane rows of a pixel merge their bytes into ONE 32-bit store
   unsigned char* bits = nullptr; int ldbits = 0;   // ReLU bit plane [pixel][ldbits bytes], bit k of byte c = (channel 8c + k of the view > 0):
                                          // EPI_BIAS_ACT writes it beside y, EPI_MASK reads it instead of act (16-byte epilogues only)
@@ -280,16 +250,6 @@ __device__ __forceinline__ void decode_pixel(int m, int Hs, int Ws, int hs_shift
   }
 }
 
-// One work-group per CU and equal tiles put the prologue loads and epilogue stores of ALL CUs in lockstep: the chip alternates between
-// an MFMA phase without HBM traffic and an HBM burst without MFMAs.  A start offset between four groups of CUs (first generation
-// only: the later work-groups inherit it) spreads the bursts; `units` x 2048 cycles per group index.
-__device__ __forceinline__ void stagger_start(int units) {
-  if (units > 0 && blockIdx.x < 256u) {                        // wave-uniform
-    const int n = (int)((blockIdx.x >> 3) & 3u) * units;
-    for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(32);
-  }
-}
-
 // XCD-aware work-group -> tile map.  The dispatcher deals consecutive work-group ids round-robin over the 8
 // XCDs (private L2 each; observed, speed only - MI355X_MICROARCH.md "Workgroup dispatch"), so ids with equal
 // id % 8 share an L2.  Each XCD walks a CONTIGUOUS band of `chunk` m-tiles, and for every m-tile runs all of
@@ -302,24 +262,18 @@ __device__ __forceinline__ bool xcd_tile(int id, int m_tiles, int inner, int chu
   return (j / inner) < chunk && m_tile < m_tiles;
 }
 
-// row-sum deferral: rows x N floats for the partial rows of one input-gradient launch, or null (no deferral open / buffer full)
-float* rowsum_alloc(const gct2_ctx& c, size_t rows, int N);
-// ... and the record of what those rows are: channels [0, db_split) of the launch feed p.db, the rest p.db2 (tapgemm_mfma.hip)
-void rowsum_record(const gct2_ctx& c, const TapGemmParams& p, const float* part, int rows);
-
 // the atomic fall-backs of the fused bias gradients add into their targets: overwritten targets start from zero
 inline void zero_overwritten_db(const TapGemmParams& p, hipStream_t s) {
   if (p.db && !(p.db_acc & 1) && p.db_split > 0) (void)hipMemsetAsync(p.db, 0, (size_t)p.db_split * sizeof(float), s);
   if (p.db2 && !(p.db_acc & 2) && p.N > p.db_split) (void)hipMemsetAsync(p.db2, 0, (size_t)(p.N - p.db_split) * sizeof(float), s);
 }
 
-// Keras ResourceApplyAdam on one element (epsilon added to sqrt(v)); ONE definition for the optimizer kernel and
-// for the weight-gradient epilogues that apply it in place, so that both round identically (fused == separate, bit for bit)
+// Keras ResourceApplyAdam on one element (epsilon added to sqrt(v)); ONE definition for every kernel that applies it
 __device__ __forceinline__ void adam_keras_update(float& p, float& m, float& v, float g, float alpha, float b1, float ob1, float b2,
                                                   float ob2, float eps) {
-  // no FMA contraction here: which products hipcc fuses depends on the code around the call (the row-sum flush kernel fused
-  // differently from the optimizer kernel and the results differed in the last bit); plain IEEE multiplies and adds in this order
-  // are the same everywhere - and what an unfused TensorFlow kernel computes
+  // no FMA contraction here: which products hipcc fuses depends on the code around the call (two kernels sharing this function once
+  // differed in the last bit); plain IEEE multiplies and adds in this order are the same everywhere - and what an unfused
+  // TensorFlow kernel computes
 #pragma clang fp contract(off)
   const float m1 = b1 * m, m2 = ob1 * g;
   m = m1 + m2;
@@ -328,14 +282,6 @@ __device__ __forceinline__ void adam_keras_update(float& p, float& m, float& v, 
   const float num = alpha * m, den = sqrtf(v) + eps;
   p = p - num / den;
 }
-// optimizer step fused into the epilogue of a weight-gradient launch whose tiles have ONE owner (no split of the pixel range):
-// the gradient never leaves the registers - no write and no re-read of dW (8 B per parameter) and no separate Adam launch
-struct AdamFuse {
-  float* p = nullptr; float* m = nullptr; float* v = nullptr;   // fp32 arenas at the start of the kernel tensor (p == null: off)
-  void* shadow = nullptr;                                        // compute-dtype copy of p (same element type as the operands) or null
-  float alpha = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gmul = 1.f;
-};
-
 // wgrad: dw[tap][cb][cs] += sum_r big[pix_big(r,tap)][cb] * small[r][cs], r over the SMALL grid.
 struct WgradParams {
   const void* big; int ldbig;     // tensor on the BIG grid (2Hs x 2Ws), Cb channels
@@ -346,13 +292,10 @@ struct WgradParams {
   float* ws;                      // partial-tile slabs [rsplit][16*Cb][Cs] in the registered workspace, or null (atomics)
   int accumulate;                 // 1: dw += result (caller keeps a running / pre-zeroed gradient); 0: dw = result
   int ks = 0;                     // 0: the 4x4 / stride-2 layers; odd ks: 'same' stride-1 convolution (both tensors on one grid, ks*ks taps)
-  int stagger = 0;                // 256 x 256 pipeline: see stagger_start()
-  AdamFuse adam;                  // one-owner tiles only (filled by wgrad_mfma when the caller asked for the fused optimizer step)
 #ifdef GCT2_STAMP
   unsigned long long* stamps = nullptr;   // diagnostic build: phase stamps of one wave per work-group (gct2_ctx_set_stamp_buffer)
 #endif
 };
 // wgrad_mfma(): when `defer` is non-null and the launch left its result as workspace slabs, the slab reduction is NOT launched and
 // the slabs are described here (the caller folds them into the optimizer read); nslab = 0 means dw holds the gradient
-struct WgradSlabs { const float* base; int nslab; size_t stride; bool adam_done = false;   // adam_done: the launch applied Adam to the kernel itself
-                    const gct2_adam_args* want_adam = nullptr; };                            // in: the caller's fused-optimizer request
+struct WgradSlabs { const float* base; int nslab; size_t stride; };

@@ -59,10 +59,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 #else
 #define STAMP(k)
 #endif
-// IL: the DMA pieces of the next round (and of the next halo) are issued BETWEEN the MFMA groups of the current round instead of in
+// The DMA pieces of the next round (and of the next halo) are issued BETWEEN the MFMA groups of the current round instead of in
 // front of them: a piece costs 60-185 cycles of issue time (MI355X_MICROARCH.md), during which the wave issues nothing else, and the
-// two waves of a SIMD reach that block together
-template <typename T, int EPI, bool IL = false>
+// two waves of a SIMD reach that block together (r03: -3..-6 % against the r02 order, which is gone)
+template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #ifdef GCT2_STAMP
   unsigned long long st[6];
@@ -84,7 +84,6 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   const int tx_n = Ws >> 4, ty_n = Hs >> 4;
   int m_tile, n_tile;
   if (!xcd_tile((int)blockIdx.x, p.m_tiles, p.n_tiles, p.xcd_chunk, m_tile, n_tile)) return;
-  stagger_start(p.stagger);
   const int tx = m_tile % tx_n, tq = m_tile / tx_n, ty = tq % ty_n, b = tq / ty_n;
   const int sh0 = ty * 16, sw0 = tx * 16, n0 = n_tile * 64;
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x), rs_w = make_rsrc(p.w);
@@ -197,51 +196,11 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       }
     }
   };
-  auto compute = [&](int round, const char* hbuf, const char* wbuf) {
-    const int a = (round >> 1) & 1, c = round & 1;
-    // an opaque copy of the lane's pixel column: without it every fragment address of all 8 unrolled rounds is loop-invariant,
-    // gets hoisted out of the K loop and spills (128 address registers)
-    int ql = q;
-    asm volatile("" : "+v"(ql));
-    // source pixel of output (sh, sw), phase (ph, pw), tap (a, c) = (sh + ph - a, sw + pw - c); halo origin = (sh0-1, sw0-1)
-    const int row0 = (mhalf * 8 + ph - a + 1) * HP + (pw - c + 1) + ql;
-    const int key = halo_swz(pw - c + 1 + ql);                 // keyed on the halo column (HP is even: the row parity is the column's)
-    const char* wimg = wbuf + phase * 8192;
-#pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
-      u32x4_t wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int n = w_row(i, ql);
-        wf[i] = lds_read128(wimg, n * 128 + (((4 * kk + g) ^ w_swz(n)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int row = row0 + j * HP;
-        const u32x4_t af = lds_read128(hbuf, row * 128 + (((4 * kk + g) ^ key) << 4));
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc[i][j] = mfma16<T>(wf[i], af, acc[i][j]);
-      }
-    }
-  };
-
   // ---- main loop: 8 rounds (two k-chunks) per trip so that every buffer role is a compile-time constant --------------
   issue_halo(0, halo0);
   issue_w(0, wb0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-#define GCT2_HALO_ROUND(R, HCUR, WCUR, WNEXT, HNEXT)                                         \
-  {                                                                                          \
-    const int r_ = (R);                                                                      \
-    if (r_ + 1 < nround) {                                                                   \
-      issue_w(r_ + 1, WNEXT);                                                                \
-      if (((r_ + 1) & 3) == 0) issue_halo((r_ + 1) >> 2, HNEXT);                             \
-    }                                                                                        \
-    compute(r_, HCUR, WCUR);                                                                 \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
-    __syncthreads();                                                                         \
-    if (r_ + 1 >= nround) break;                                                             \
-  }
 #define GCT2_LEAN_ROUND(FAST, R, IDX, HCUR, HNEXT, WCUR, WNEXT)                              \
   {                                                                                          \
     lean_round(std::integral_constant<bool, FAST>{}, (R), IDX, HCUR, HNEXT, WCUR, WNEXT);    \
@@ -258,25 +217,13 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   GCT2_LEAN_ROUND(FAST, r + 5, 5, HALO_BYTES, 0, WB_BYTES, 0)                                \
   GCT2_LEAN_ROUND(FAST, r + 6, 6, HALO_BYTES, 0, 0, WB_BYTES)                                \
   GCT2_LEAN_ROUND(FAST, r + 7, 7, HALO_BYTES, 0, WB_BYTES, 0)
-  if constexpr (IL) {
+  {
     int r = 0;
     for (; r + 8 < kfull4; r += 8) { GCT2_LEAN_TRIP(true) }   // every round of the trip issues a full next round
     for (; r < nround; r += 8) { GCT2_LEAN_TRIP(false) }      // the last trips: runtime tail logic, same buffer roles
-  } else {
-    for (int r = 0; r < nround; r += 8) {
-      GCT2_HALO_ROUND(r + 0, halo0, wb0, wb1, halo1)
-      GCT2_HALO_ROUND(r + 1, halo0, wb1, wb0, halo1)
-      GCT2_HALO_ROUND(r + 2, halo0, wb0, wb1, halo1)
-      GCT2_HALO_ROUND(r + 3, halo0, wb1, wb0, halo1)
-      GCT2_HALO_ROUND(r + 4, halo1, wb0, wb1, halo0)
-      GCT2_HALO_ROUND(r + 5, halo1, wb1, wb0, halo0)
-      GCT2_HALO_ROUND(r + 6, halo1, wb0, wb1, halo0)
-      GCT2_HALO_ROUND(r + 7, halo1, wb1, wb0, halo0)
-    }
   }
 #undef GCT2_LEAN_TRIP
 #undef GCT2_LEAN_ROUND
-#undef GCT2_HALO_ROUND
 
   // ---- epilogue: lane holds out[pixel (row mhalf*8 + j, col q)][n = n0 + 32 (i>>1) + 8 g + 4 (i&1) + r], phase (ph, pw) ----
   // EPI_BIAS_ACT: bias + ReLU (Conv2DTranspose forward).  EPI_MASK: ReLU mask of the tensor the gradient belongs to, optional
@@ -605,58 +552,40 @@ bool halo_head_supported(const gct2_ctx& c, int dtype, const TapGemmParams& p) {
   const size_t rows = (size_t)p.B * (p.Hs >> 4) * (p.Ws >> 4);
   return c.ws && c.ws_bytes >= rows * HEAD_ROW * sizeof(float);
 }
-int halo_head(const gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, float* loss, float* db_up, int accumulate,
+int halo_head(gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, float* loss, float* db_up, int accumulate,
               hipStream_t s) {
   p.m_tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4);
   p.n_tiles = 1;
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   p.ksplit = 1;
   p.dbws = nullptr;
-  p.stagger = c.stagger;
   p.head.part = c.ws;
 #ifdef GCT2_STAMP
   p.stamps = c.stamps;
 #endif
   dim3 grid(8 * p.xcd_chunk);
-  if (c.halo_il) {
-    if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_HEAD, true>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_HEAD, true>), grid, dim3(512), 0, s, p);
-  } else if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_HEAD>), grid, dim3(512), 0, s, p);
+  gct2_log(c, "halo:convT:head");
+  if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_HEAD>), grid, dim3(512), 0, s, p);
   else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_HEAD>), grid, dim3(512), 0, s, p);
   if (int e = gct2_check_launch("halo_head")) return e;
   return pw_head_finish(c.ws, p.m_tiles, dw, db, loss, db_up, p.head.Cin * p.head.Cout, p.head.Cout, 1.0f / p.head.count, accumulate, s);
 }
 
-int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) {
+int halo_convT(gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) {
   p.m_tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4);
   p.n_tiles = (p.N + 63) / 64;
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   p.ksplit = 1;
   p.dbws = nullptr;
-  p.stagger = c.stagger;
   p.bits_words = (p.bits && (uintptr_t)p.bits % 4 == 0 && p.ldbits % 4 == 0 && p.N % 32 == 0) ? 1 : 0;
-  float* deferred = nullptr;
   if (epi == EPI_MASK && (p.db || p.db2)) {      // partial bias-gradient rows at the tail of the workspace, one per work-group row
-    const size_t ws_bytes = c.ws_bytes;
-    float* ws = c.ws;
     const size_t need = (size_t)p.m_tiles * p.N * sizeof(float);
-    if (ws && ws_bytes >= need + 16) p.dbws = ws + (ws_bytes - need) / sizeof(float) / 4 * 4;
-    if (p.dbws) {     // an open row-sum deferral: the rows stay in the caller's row-sum buffer until gct2_rowsum_flush
-      deferred = rowsum_alloc(c, (size_t)p.m_tiles, p.N);
-      if (deferred) p.dbws = deferred;
-    }
+    if (c.ws && c.ws_bytes >= need + 16) p.dbws = c.ws + (c.ws_bytes - need) / sizeof(float) / 4 * 4;
     if (!p.dbws) zero_overwritten_db(p, s);
   }
   dim3 grid(8 * p.xcd_chunk * p.n_tiles);
-  if (c.halo_il) {
-    if (epi == EPI_BIAS_ACT) {
-      if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_BIAS_ACT, true>), grid, dim3(512), 0, s, p);
-      else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_BIAS_ACT, true>), grid, dim3(512), 0, s, p);
-    } else {
-      if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_MASK, true>), grid, dim3(512), 0, s, p);
-      else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_MASK, true>), grid, dim3(512), 0, s, p);
-    }
-  } else if (epi == EPI_BIAS_ACT) {
+  gct2_log(c, "halo:convT:%s%s", epi == EPI_BIAS_ACT ? "bias_act" : "mask", p.bits ? ":bits" : "");
+  if (epi == EPI_BIAS_ACT) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_BIAS_ACT>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_BIAS_ACT>), grid, dim3(512), 0, s, p);
   } else {
@@ -664,8 +593,7 @@ int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream
     else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_MASK>), grid, dim3(512), 0, s, p);
   }
   if (epi == EPI_BIAS_ACT && p.bits) c.relu_bits_done = 1;      // the epilogue wrote the ReLU bit plane
-  if (deferred) rowsum_record(c, p, deferred, p.m_tiles);
-  else if (p.dbws) {
+  if (p.dbws) {
     if (int e = tapgemm_dbpart_reduce(p.dbws, p.m_tiles, p, s)) return e;
   }
   return gct2_check_launch("halo_convT");

@@ -33,31 +33,13 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)OOB, 0x00020000);
 }
-// HIDDEN = false: the builtin; hipcc counts the DMA in its own vmcnt bookkeeping (and drains it to 0 at the head of a
-// loop that keeps more than one step in flight).  HIDDEN = true: the same instruction from inline asm, invisible to
-// that bookkeeping; every wait for it is then placed by hand (the 3-buffer loop).  M0 = LDS address of the piece is
-// written in the same statement that uses it (cdna_hip_programming.md §5.7).
-template <bool HIDDEN>
+// M0 = LDS address of the piece is written by the builtin in the same statement that uses it (cdna_hip_programming.md §5.7)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff) {
-  if constexpr (HIDDEN) {
-    const unsigned lds_addr = (unsigned)(uintptr_t)(lds_void_t*)lds_piece;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
-                 : "memory", "m0");
-  } else {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
-  }
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, 0, 0, 0);
 }
-
 // the same with a wave-uniform byte offset in an SGPR (tap / k-chunk part of the address; the bounds check sees the per-lane offset)
-template <bool HIDDEN>
 __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff, unsigned soff) {
-  if constexpr (HIDDEN) {
-    const unsigned lds_addr = (unsigned)(uintptr_t)(lds_void_t*)lds_piece;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory", "m0");
-  } else {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, (int)soff, 0, 0);
-  }
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, (int)soff, 0, 0);
 }
 
 // bias gradient = column sums of the masked gradient a dgrad launch produces: db[n] (+)= sum over pixels.  Channels
@@ -68,11 +50,10 @@ __device__ __forceinline__ float* db_target(const TapGemmParams& p, int n) {
 // whether the target of channel n is added to (db_accumulate bits of include/gct2.h) or overwritten
 __device__ __forceinline__ bool db_adds(const TapGemmParams& p, int n) { return (p.db_acc >> (n < p.db_split ? 0 : 1)) & 1; }
 
-// NBUF = 2: 4 waves (256 threads), 2 work-groups per CU cover each other's DMA latency, vmcnt(0) per step.
-// NBUF = 3: 8 waves (512 threads, 256 x 128 tile), 1 work-group per CU, the DMA of step t+2 stays in flight
-//           across the barrier that publishes step t+1 (counted vmcnt + raw s_barrier).
-// WM = 64 : every wave owns a 64 (m) x 64 (n) sub-tile;  WM = 128: 128 (m) x 64 (n), used by the 256 x 256 tile
-//           (8 waves; 96 LDS bytes per MFMA instead of 128, half the L2->LDS bytes per flop of the 128 x 128 tile).
+// NBUF = 2: two LDS buffers, the DMA of step t+1 is issued before the MFMAs of step t; NBUF = 1: issue, wait, multiply.  Either way
+// vmcnt(0) + barrier per step, and 2 (or 4) independent work-groups per CU cover each other's waits - the arrangement that measured
+// best on this chip (the three-buffer, 256 x 256 and five-stage-ring tiles of r01-r03 were 12-35 % slower and are gone).
+// Every wave owns a 64 (m) x 64 (n) sub-tile.
 #ifdef GCT2_STAMP
 // diagnostic build (make EXTRA=-DGCT2_STAMP, scripts/stamp_layer.py): s_memrealtime at the phase boundaries of one wave per work-group,
 // written to the buffer handed over with gct2_ctx_set_stamp_buffer (never part of the product build: gct2_build_flags())
@@ -87,39 +68,28 @@ __device__ __forceinline__ unsigned long long tg_stamp() {
 #else
 #define TG_STAMP(k)
 #endif
-template <typename T, int FORM, int BM, int BN, int EPI, int NBUF, int WM = 64>
-__global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64) ? 4 : (WM == 64 ? 2 : 1)) void tapgemm_kernel(TapGemmParams p) {
-  constexpr int NWV = (BM / WM) * (BN / 64);       // waves, each a WM x 64 sub-tile
+template <typename T, int FORM, int BM, int BN, int EPI, int NBUF>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void tapgemm_kernel(TapGemmParams p) {
+  constexpr int WM = 64;
+  constexpr int NWV = (BM / WM) * (BN / 64);       // waves, each a 64 x 64 sub-tile
   constexpr int MF = WM / 16;                      // 16-pixel fragments per wave
+  static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");
   static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
   constexpr bool S1 = (FORM == FORM_S1 || FORM == FORM_S1T);   // stride-1 'same' convolution: p.ks x p.ks taps on the output's own grid
   constexpr bool WT = (FORM == FORM_CONV || FORM == FORM_S1);   // weights [tap][k][n] (T image); otherwise [tap][n][k] (N image)
   static_assert(!WT || BN % 128 == 0, "T images are 128 columns wide");
   constexpr int WAVES_N = BN / 64;
-  // RING (NBUF = 5): the deep pipeline of wgrad256p_kernel for the forward / input-gradient GEMMs.  A stage is HALF a 64-channel
-  // step (32 channels of one tap: 16 KiB of pixels + 16 KiB of weights for the 256 x 256 tile), five stage buffers fill the CU's
-  // 160 KiB of LDS, the DMA of stage s+4 is issued while stage s is multiplied and only stage s+1 is waited for (counted vmcnt,
-  // raw s_barrier): FOUR stages = 128 KiB stay in flight across every barrier, against one step drained to zero at every barrier
-  // in the other variants.  These loops are bound by the latency of the staging requests that miss the XCD's L2.
-  constexpr bool RING = NBUF >= 5;             // NBUF = 6: the ring with the DMA pieces interleaved into the MFMA groups
-  constexpr bool RING_IL = NBUF == 6;
-  static_assert(!RING || (NWV == 8 && !S1), "the ring pipeline is built for the 8-wave 4x4 / stride-2 forms");
-  constexpr int BKS = RING ? 32 : BK;              // reduction elements per stage
-  constexpr int NA = RING ? BM / 16 / NWV : BM / 8 / NWV;   // 1-KiB pieces per wave, activation tile (8 rows of 128 B, or 16 rows of 64 B)
-  constexpr int NW = RING ? (WT ? 8 * (BN / 128) : BN / 16) / NWV : (WT ? 16 * (BN / 128) : BN / 8) / NWV;
-  constexpr int NDMA = NA + NW;                    // DMA instructions per wave per step
-  constexpr int A_BYTES = RING ? BM * 64 : BM * 128;
-  constexpr int W_BYTES = RING ? (WT ? 32 * 256 * (BN / 128) : BN * 64)
-                               : (WT ? 64 * 256 * (BN / 128) : BN * 128);   // T images: BN/128 of them side by side
+  constexpr int BKS = BK;                          // reduction elements per step
+  constexpr int NA = BM / 8 / NWV;                 // 1-KiB pieces per wave, activation tile (8 rows of 128 B)
+  constexpr int NW = (WT ? 16 * (BN / 128) : BN / 8) / NWV;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int W_BYTES = WT ? 64 * 256 * (BN / 128) : BN * 128;   // T images: BN/128 of them side by side
   constexpr int NTAPS = (FORM == FORM_CONV) ? 16 : 4;              // (the stride-1 forms: p.ks * p.ks, run-time)
 
   // DISTINCT LDS objects: lets hipcc prove that the DMA into one buffer does not alias the ds_reads of another,
   // so it does not drain vmcnt before every read (cdna_hip_programming.md, "Three .s-level traps" (a))
   __shared__ __attribute__((aligned(16))) char lds0[A_BYTES + W_BYTES];
   __shared__ __attribute__((aligned(16))) char lds1[NBUF >= 2 ? A_BYTES + W_BYTES : 16];
-  __shared__ __attribute__((aligned(16))) char lds2[NBUF >= 3 ? A_BYTES + W_BYTES : 16];
-  __shared__ __attribute__((aligned(16))) char lds3[RING ? A_BYTES + W_BYTES : 16];
-  __shared__ __attribute__((aligned(16))) char lds4[RING ? A_BYTES + W_BYTES : 16];
 
 #ifdef GCT2_STAMP
   unsigned long long st[5];
@@ -160,16 +130,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   // ---- per-lane DMA descriptors (fixed over the whole K loop) ------------------------------------------
   // activation tile (N image): piece q = wave + 4 i holds rows 8q .. 8q+7; lane -> row 8q + (lane>>3),
   // physical chunk lane&7 = logical chunk ^ ((row>>1)&7)
-  // RING: 64-byte rows (32 channels), piece q = wave + 8 i holds rows 16q .. 16q+15; lane -> row 16q + (lane>>2), physical chunk
-  // lane&3 = logical chunk ^ ring_swz((row>>2)&3) (conflict-free for ds_read_b128 of 16 consecutive rows: checked exhaustively
-  // against the lane groups of MI355X_MICROARCH.md, LDS table)
-  const int a_lchunk = RING ? ((lane & 3) ^ ring_swz((lane >> 4) & 3))
-                            : ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7));   // 4*NWV*i is a multiple of 8
+  const int a_lchunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);   // 4*NWV*i is a multiple of 8
   unsigned a_off[NA];                              // byte offset of (row's tap-origin pixel, logical chunk)
   unsigned a_mask[NA];                             // bit t: tap t reads inside the image for this row
 #pragma unroll
   for (int i = 0; i < NA; i++) {
-    const int m = RING ? m0 + 16 * (wave + NWV * i) + (lane >> 2) : m0 + 8 * (wave + NWV * i) + (lane >> 3);
+    const int m = m0 + 8 * (wave + NWV * i) + (lane >> 3);
     a_off[i] = 0; a_mask[i] = 0;
     if (m < M) {
       int sw, sh, b;
@@ -201,19 +167,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
   int w_k[NW];                                     // FORM_CONV: k row inside the 64-step; FORM_CONVT: unused
 #pragma unroll
   for (int i = 0; i < NW; i++) {
-    if (RING && WT) {                              // 32-row T images: piece `wave` of image i = k-rows 4 wave .. 4 wave + 3
-      const int k = 4 * wave + (lane >> 4);
-      const int lc = ((((lane & 15) >> 1) ^ timg_swz(k)) << 1) | (lane & 1);
-      const int nn = n0 + i * 128 + lc * 8;
-      w_k[i] = k;
-      w_nok[i] = nn < N;
-      w_off[i] = (unsigned)((k * N + nn) * 2);
-    } else if (RING) {                             // 64-byte-row N image of the weights: piece = 16 n-rows x 4 chunks
-      const int n = 16 * (wave + NWV * i) + (lane >> 2);
-      w_k[i] = a_lchunk * 8;
-      w_nok[i] = (n0 + n) < N;
-      w_off[i] = (unsigned)(((n0 + n) * K + a_lchunk * 8) * 2);
-    } else if (WT) {                               // T image: piece = 4 k-rows x 16 chunks
+    if (WT) {                                      // T image: piece = 4 k-rows x 16 chunks
       const int q = wave + NWV * i;                // pieces 0..15 fill image 0 (columns n0..n0+127), 16..31 image 1
       const int k = 4 * (q & 15) + (lane >> 4);
       const int lc = ((((lane & 15) >> 1) ^ timg_swz(k)) << 1) | (lane & 1);
@@ -262,20 +216,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       if (c0 + BKS <= K) {                          // block-uniform: a full chunk needs no per-lane channel check
 #pragma unroll
         for (int i = 0; i < NA; i++)
-          dma16s<NBUF >= 3>(rs_xs, abase + (wave + NWV * i) * 1024, a_voff[i] | ((a_nmask[i] >> abit) << 31), s_a);
+          dma16s(rs_xs, abase + (wave + NWV * i) * 1024, a_voff[i] | ((a_nmask[i] >> abit) << 31), s_a);
 #pragma unroll
         for (int i = 0; i < NW; i++)
-          dma16s<NBUF >= 3>(rs_w, wbase + ((RING && WT) ? i * (32 * 256) + wave * 1024 : (wave + NWV * i) * 1024), w_voff[i], s_w);
+          dma16s(rs_w, wbase + (wave + NWV * i) * 1024, w_voff[i], s_w);
       } else {                                      // the ragged last chunk (K % 64 != 0)
         asm volatile("" ::: "memory");              // keeps hipcc from turning this branch into selects in the full-chunk path
 #pragma unroll
         for (int i = 0; i < NA; i++) {
           const unsigned v = a_voff[i] | ((a_nmask[i] >> abit) << 31);
-          dma16s<NBUF >= 3>(rs_xs, abase + (wave + NWV * i) * 1024, (c0 + a_lchunk * 8) < K ? v : OOB, s_a);
+          dma16s(rs_xs, abase + (wave + NWV * i) * 1024, (c0 + a_lchunk * 8) < K ? v : OOB, s_a);
         }
 #pragma unroll
         for (int i = 0; i < NW; i++)
-          dma16s<NBUF >= 3>(rs_w, wbase + ((RING && WT) ? i * (32 * 256) + wave * 1024 : (wave + NWV * i) * 1024),
+          dma16s(rs_w, wbase + (wave + NWV * i) * 1024,
                             (c0 + w_k[i]) < K ? w_voff[i] : OOB, s_w);
       }
       c_kc++;
@@ -300,15 +254,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
 #pragma unroll
     for (int i = 0; i < NA; i++) {
       const bool ok = a_cok && ((a_mask[i] >> abit) & 1u);
-      dma16<NBUF >= 3>(rs_x, abase + (wave + NWV * i) * 1024, ok ? a_off[i] + tapoff : OOB);
+      dma16(rs_x, abase + (wave + NWV * i) * 1024, ok ? a_off[i] + tapoff : OOB);
     }
     char* wbase = abase + A_BYTES;
     const unsigned wtap = WT ? (unsigned)(((tap16 * K + c0) * N) * 2) : (unsigned)((tap16 * N * K + c0) * 2);
 #pragma unroll
     for (int i = 0; i < NW; i++) {
       const bool ok = w_nok[i] && (c0 + w_k[i]) < K;
-      // (RING + T image: piece `wave` of image i at i * 8 KiB; every other layout: consecutive pieces)
-      dma16<NBUF >= 3>(rs_w, wbase + ((RING && WT) ? i * (32 * 256) + wave * 1024 : (wave + NWV * i) * 1024), ok ? w_off[i] + wtap : OOB);
+      dma16(rs_w, wbase + (wave + NWV * i) * 1024, ok ? w_off[i] + wtap : OOB);
     }
   };
 
@@ -340,22 +293,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
         for (int j = 0; j < MF; j++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
     }
   };
-  // RING: one 32-deep MFMA step per stage; fragments of the 64-byte-row images / the 32-row T images
-  auto compute_ring = [&](const char* a_img) {
-    const char* w_img = a_img + A_BYTES;
-    int ql = lane;                                 // opaque copy: keeps the fragment addresses of the five unrolled stages out of
-    asm volatile("" : "+v"(ql));                   // the loop preamble (they would be hoisted and spill, as in wgrad256p_kernel)
-    u32x4_t wf[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      wf[i] = WT ? timg_frag(w_img + (wn >> 1) * (32 * 256), (wn & 1) * 64 + i * 16, 0, ql) : ring_frag(w_img, wn * 64 + i * 16, ql);
-#pragma unroll
-    for (int j = 0; j < MF; j++) {
-      const u32x4_t af = ring_frag(a_img, wm * WM + j * 16, ql);
-#pragma unroll
-      for (int i = 0; i < 4; i++) acc[i][j] = mfma16<T>(wf[i], af, acc[i][j]);
-    }
-  };
   // `live` is always true (ksplit >= 1) but opaque to hipcc: a code-generation fence.  With the multiplies unconditional the
   // unrolled steps of a trip are merged into one scheduling region and the register allocator spills (wgrad256p_kernel: 440
   // spilled registers, 10x slower; here: the 256 x 256 and three-buffer variants); behind the guard each step stays its own region.
@@ -384,118 +321,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / 64) * 64, (NBUF == 1 && WM == 64)
       if (live) compute(lds1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-    }
-  } else if constexpr (RING) {
-    // wait until at most `ahead` whole stages (the youngest ones) are still in flight
-    auto wait_ahead = [&](int ahead) {
-      if (ahead >= 3) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(3 * NDMA));
-      else if (ahead == 2) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(2 * NDMA));
-      else if (ahead == 1) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(NDMA));
-      else __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(0));
-    };
-    // stage s: issue s+4 into the buffer stage s-1 has just left (every wave is past the barrier that ended it), multiply s, wait
-    // until stage s+1 has landed (everything older than the newest `ahead` stages), raw barrier: s+1 is read only after it
-    // one DMA piece of a stage (q < NA: activation piece q, else weight piece q - NA): the interleaved form issues the four
-    // pieces of stage s+4 BETWEEN the four MFMA groups of stage s, so that a piece's issue time (60-185 cycles each beside other
-    // memory instructions, MI355X_MICROARCH.md) is covered by the eight MFMAs in front of it instead of idling the matrix pipe
-    auto issue_piece = [&](int it, char* abase, int q) {
-      const int tap = it / nk, c0 = (it - tap * nk) * BKS;
-      int tap16, dh, dw;
-      if (FORM == FORM_CONV) { tap16 = tap; dh = tap >> 2; dw = tap & 3; }
-      else {
-        const int a = tap >> 1, c = tap & 1;
-        dh = 1 - a; dw = 1 - c;
-        tap16 = (1 - ph + 2 * a) * 4 + (1 - pw + 2 * c);
-      }
-      if (q < NA) {
-        const int abit = (FORM == FORM_CONVT) ? dh * 2 + dw : tap;
-        const unsigned tapoff = (unsigned)((dh * Wsrc + dw) * ldx2 + c0 * 2);
-        const bool ok = (c0 + a_lchunk * 8) < K && ((a_mask[q] >> abit) & 1u);
-        dma16<true>(rs_x, abase + (wave + NWV * q) * 1024, ok ? a_off[q] + tapoff : OOB);
-      } else {
-        const int i = q - NA;
-        const unsigned wtap = WT ? (unsigned)(((tap16 * K + c0) * N) * 2) : (unsigned)((tap16 * N * K + c0) * 2);
-        const bool ok = w_nok[i] && (c0 + w_k[i]) < K;
-        dma16<true>(rs_w, abase + A_BYTES + (WT ? i * (32 * 256) + wave * 1024 : (wave + NWV * i) * 1024), ok ? w_off[i] + wtap : OOB);
-      }
-    };
-    auto stage_il = [&](int it, const char* cur, char* tgt) {
-      const bool more = it + 4 < it_hi;
-      const char* w_img = cur + A_BYTES;
-      int ql = lane;
-      asm volatile("" : "+v"(ql));
-      u32x4_t wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        wf[i] = WT ? timg_frag(w_img + (wn >> 1) * (32 * 256), (wn & 1) * 64 + i * 16, 0, ql) : ring_frag(w_img, wn * 64 + i * 16, ql);
-#pragma unroll
-      for (int q = 0; q < MF / 2; q++) {
-        const u32x4_t af0 = ring_frag(cur, wm * WM + (2 * q) * 16, ql), af1 = ring_frag(cur, wm * WM + (2 * q + 1) * 16, ql);
-        if (more && q < NDMA) issue_piece(it + 4, tgt, q);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; i++) { acc[i][2 * q] = mfma16<T>(wf[i], af0, acc[i][2 * q]); acc[i][2 * q + 1] = mfma16<T>(wf[i], af1, acc[i][2 * q + 1]); }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      wait_ahead(min(it + 4, it_hi - 1) - (it + 1));
-      __builtin_amdgcn_s_barrier();
-    };
-    auto stage = [&](int it, const char* cur, char* tgt) {
-      if constexpr (RING_IL) {
-        if (live) stage_il(it, cur, tgt);
-        return;
-      }
-      if (it + 4 < it_hi) issue(it + 4, tgt);
-      if (live) compute_ring(cur);
-      wait_ahead(min(it + 4, it_hi - 1) - (it + 1));
-      __builtin_amdgcn_s_barrier();
-    };
-    if (it_lo < it_hi) {
-      issue(it_lo, lds0);
-      if (it_lo + 1 < it_hi) issue(it_lo + 1, lds1);
-      if (it_lo + 2 < it_hi) issue(it_lo + 2, lds2);
-      if (it_lo + 3 < it_hi) issue(it_lo + 3, lds3);
-      wait_ahead(min(it_lo + 3, it_hi - 1) - it_lo);
-    }
-    __builtin_amdgcn_s_barrier();
-    for (int it = it_lo; it < it_hi; it += 5) {    // five stages per trip: buffer roles are compile-time
-      stage(it, lds0, lds4);
-      if (it + 1 >= it_hi) break;
-      stage(it + 1, lds1, lds0);
-      if (it + 2 >= it_hi) break;
-      stage(it + 2, lds2, lds1);
-      if (it + 3 >= it_hi) break;
-      stage(it + 3, lds3, lds2);
-      if (it + 4 >= it_hi) break;
-      stage(it + 4, lds4, lds3);
-    }
-  } else {
-    // step t: issue the DMA of step t+2, run the MFMAs of step t, then wait until only those NDMA newest DMAs are
-    // outstanding (=> this wave's pieces of step t+1 have landed) and meet the other waves at a raw barrier
-    // (a __syncthreads() here would drain vmcnt to 0).  Step t+1 is read only after that barrier.
-    auto step = [&](int it, const char* cur, char* tgt) {
-      const bool more = it + 2 < it_hi;
-      if (more) issue(it + 2, tgt);
-      if (live) compute(cur);
-      if (more) __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(NDMA));   // the builtin (not asm) so hipcc's own vmcnt bookkeeping sees it
-      else __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(0));
-      __builtin_amdgcn_s_barrier();
-    };
-    if (it_lo < it_hi) issue(it_lo, lds0);
-    if (it_lo + 1 < it_hi) {
-      issue(it_lo + 1, lds1);
-      __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(NDMA));
-    } else {
-      __builtin_amdgcn_s_waitcnt(VMCNT_ONLY(0));
-    }
-    __builtin_amdgcn_s_barrier();
-    for (int it = it_lo; it < it_hi; it += 3) {    // three steps per trip: buffer roles are compile-time
-      step(it, lds0, lds2);
-      if (it + 1 >= it_hi) break;
-      step(it + 1, lds1, lds0);
-      if (it + 2 >= it_hi) break;
-      step(it + 2, lds2, lds1);
     }
   }
 
@@ -745,65 +570,6 @@ __global__ __launch_bounds__(1024) void dbpart_reduce_kernel(const float* __rest
   }
 }
 
-// ---- deferred row sums: ONE launch for every bias gradient of a reverse pass (gct2_rowsum_flush) -----------------------------------
-// Block = 32 columns of ONE target x 128 row lanes (the geometry and the summation order of dbpart_reduce_kernel, so a deferred
-// bias gradient has the bits of an immediate one); a target's sources are added in recording order: first writer + second writer
-// of a concat slice, exactly as "overwrite, then add" does.  adam != null: Keras Adam on the bias right here (the per-layer
-// optimizer launches of the fused step then cover the kernels only).
-struct RowsumAdam { float* p; float* m; float* v; void* shadow; const float* g_base; int shadow_dtype; float alpha, b1, b2, eps, gmul; };
-__global__ __launch_bounds__(1024) void rowsum_flush_kernel(RowsumTable tab, RowsumAdam ad) {
-  int ti = 0;
-  for (int k = 1; k < tab.ntargets; k++) if ((int)blockIdx.x >= tab.t[k].blk0) ti = k;     // block-uniform
-  const RowsumTarget& T = tab.t[ti];
-  const int tid = threadIdx.x, cq = tid & 7, rl = tid >> 3;
-  const int n = ((int)blockIdx.x - T.blk0) * 32 + cq * 4;
-  __shared__ f32x4_t red[16][8];
-  f32x4_t total = {0.f, 0.f, 0.f, 0.f};
-  for (int si = 0; si < T.nsrc; si++) {
-    const RowsumSrc S = T.src[si];
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    if (n < T.ncols)
-      for (int r = rl; r < S.rows; r += 128) acc += *reinterpret_cast<const f32x4_t*>(S.part + (size_t)r * S.ld + S.col0 + n);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      float t = acc[k];
-      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-      acc[k] = t;
-    }
-    __syncthreads();                                        // red is reused per source
-    if ((tid & 63) < 8) red[tid >> 6][cq] = acc;
-    __syncthreads();
-    if (tid < 8) {
-      f32x4_t t = red[0][tid];
-#pragma unroll
-      for (int k = 1; k < 16; k++) t += red[k][tid];
-      total = si == 0 ? t : total + t;
-    }
-  }
-  if (tid < 8 && n < T.ncols) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if (n + r >= T.ncols) break;
-      float* q = T.dst + n + r;
-      // no recorded source: the launches reduced their rows themselves (no workspace rows, a full buffer, the direct kernels) and
-      // the gradient is in place already
-      const float gval = T.nsrc == 0 ? *q : (T.add ? *q + total[r] : total[r]);
-      if (T.nsrc) *q = gval;
-      if (ad.p && T.adam) {
-        const size_t e = (size_t)(q - ad.g_base);
-        float pp = ad.p[e], mm = ad.m[e], vv = ad.v[e];
-        adam_keras_update(pp, mm, vv, gval * ad.gmul, ad.alpha, ad.b1, 1.f - ad.b1, ad.b2, 1.f - ad.b2, ad.eps);
-        ad.p[e] = pp; ad.m[e] = mm; ad.v[e] = vv;
-        if (ad.shadow) {
-          if (ad.shadow_dtype == GCT2_BF16) reinterpret_cast<__bf16*>(ad.shadow)[e] = from_f32<__bf16>(pp);
-          else if (ad.shadow_dtype == GCT2_F16) reinterpret_cast<_Float16*>(ad.shadow)[e] = from_f32<_Float16>(pp);
-          else reinterpret_cast<float*>(ad.shadow)[e] = pp;
-        }
-      }
-    }
-  }
-}
-
 // sums the split-K slabs and applies the epilogue the GEMM kernel skipped.  Work-group = 8 pixels x 128 channels,
 // thread = 4 channels of one pixel (split-K layers have few pixels: keep the grid wide), and the bias-gradient
 // column sums of the 8 pixels are reduced in LDS into one partial row for dbpart_reduce_kernel.
@@ -878,13 +644,13 @@ __global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, 
   }
 }
 
-template <typename T, int FORM, int BM, int BN, int EPI, int NBUF, int WM = 64>
-int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
+template <typename T, int FORM, int BM, int BN, int EPI, int NBUF>
+int launch(gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   const int M = p.B * p.Hs * p.Ws;
   constexpr int PH = FORM == FORM_CONVT ? 4 : 1;
   const int tiles = ((M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * PH;
   const int ntaps = FORM == FORM_CONV ? 16 : (FORM == FORM_CONVT ? 4 : p.ks * p.ks);
-  constexpr int BKS = NBUF >= 5 ? 32 : BK;           // the ring pipeline walks half steps
+  constexpr int BKS = BK;
   const int niter = ntaps * ((p.K + BKS - 1) / BKS);
   const size_t npix = (size_t)M * PH;
   // small-M layers (bottleneck of the U-Net) cannot fill 256 CUs with output tiles: split the reduction
@@ -926,20 +692,17 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   p.wstat = (c.xcd_order == 2 || (c.xcd_order == 0 && w_bytes >= 3 * src_bytes)) && slices >= 8 ? 1 : 0;   // measured per layer: profiles/r02_layers.txt
   dim3 grid(p.wstat ? 8 * ((slices + 7) / 8) * p.m_tiles : 8 * p.xcd_chunk * p.n_tiles * PH * p.ksplit);
   p.bits_words = (p.bits && (uintptr_t)p.bits % 4 == 0 && p.ldbits % 4 == 0 && p.N % 32 == 0) ? 1 : 0;
-  auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF, WM>;
+  auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF>;
   p.dbws = db_rows ? ws + (ws_bytes - dbws_bytes) / sizeof(float) / 4 * 4 : nullptr;
-  // an open row-sum deferral (gct2_rowsum_begin): the partial rows go to the caller's row-sum buffer and stay there until the flush
-  const int db_nrows = p.ksplit > 1 ? (int)fin_rows : p.m_tiles * PH;
-  float* deferred = (want_db && p.dbws) ? rowsum_alloc(c, (size_t)db_nrows, p.N) : nullptr;
-  if (deferred) p.dbws = deferred;
   if (want_db && !p.dbws) zero_overwritten_db(p, s);
-  hipLaunchKernelGGL(kern, grid, dim3((BM / WM) * (BN / 64) * 64), 0, s, p);
+  gct2_log(c, "tap:%s:%dx%d:%s:ksplit=%d%s%s", FORM == FORM_CONV ? "conv" : FORM == FORM_CONVT ? "convT" : "s1", BM, BN,
+           EPI == EPI_BIAS_ACT ? "bias_act" : "mask", p.ksplit, p.wstat ? ":wstat" : "", (p.bits && p.wide && p.ksplit == 1) ? ":bits" : "");
+  hipLaunchKernelGGL(kern, grid, dim3((BM / 64) * (BN / 64) * 64), 0, s, p);
   if (p.ksplit > 1) {
     hipLaunchKernelGGL((tapgemm_finalize_kernel<T, EPI>), dim3((unsigned)fin_rows, (p.N + 127) / 128), dim3(256), 0, s, p, npix);
   }
   if (EPI == EPI_BIAS_ACT && p.bits && p.wide && p.ksplit == 1) c.relu_bits_done = 1;   // the 16-byte epilogue wrote the ReLU bit plane
-  if (deferred) rowsum_record(c, p, deferred, db_nrows);
-  else if (p.dbws) {
+  if (p.dbws) {
     const int rows = p.ksplit > 1 ? (int)fin_rows : p.m_tiles * PH;
     hipLaunchKernelGGL(dbpart_reduce_kernel, dim3((p.N + 31) / 32), dim3(1024), 0, s, p.dbws, rows, p);
   }
@@ -947,131 +710,31 @@ int launch(const gct2_ctx& c, TapGemmParams p, hipStream_t s) {
 }
 
 template <typename T>
-int dispatch(const gct2_ctx& c, int form, int epi, const TapGemmParams& p, hipStream_t s) {
-  const int g_tapgemm_variant = c.tap_variant;
+int dispatch(gct2_ctx& c, int form, int epi, const TapGemmParams& p, hipStream_t s) {
   // the stride-1 forms (off-by-default model variants): one tile shape; the epilogue is the forward's / the input gradient's
   // (tapgemm_mfma checks the pairing)
   if (form == FORM_S1) return launch<T, FORM_S1, 128, 128, EPI_BIAS_ACT, 2>(c, p, s);
   if (form == FORM_S1T) return launch<T, FORM_S1T, 128, 128, EPI_MASK, 2>(c, p, s);
-  // big layers: 256 x 128 tile, 8 waves, 3 LDS buffers; layers with few output pixels keep the 128 x 128 tile
-  // (more work-groups + split-K); N <= 64 (UpShuffle_0) uses the 256 x 64 tile
+  // automatic choice (per-layer A/B: profiles/r01_layer_variants_final.txt, r03_layer_variants.txt): the 256 x 128 single-buffer
+  // tile (8 waves, 48 KiB, two work-groups per CU) moves 25 % fewer L2->LDS bytes per FLOP than the 128 x 128 two-buffer tile and
+  // wins 5-14 % where it still yields >= 2 work-groups per CU; N <= 64 (UpShuffle_0 without the halo kernel) takes 256 x 64
   const int M = p.B * p.Hs * p.Ws;
-  const bool big = g_tapgemm_variant == 3;   // measured r01: the 4-wave tile at 2 work-groups per CU is faster (profiles/)
-  // automatic choice (per-layer A/B in scripts/bench_layer.py, profiles/r01_layer_variants.txt): the 256 x 128 single-
-  // buffer tile moves 25 % fewer L2->LDS bytes per FLOP and wins 5-14 % where it still yields >= 2 work-groups per CU.
   const int tiles256 = ((M + 255) / 256) * ((p.N + 127) / 128) * (form == FORM_CONVT ? 4 : 1);
-  const bool auto5 = g_tapgemm_variant == 0 && tiles256 >= 512;
-  if ((g_tapgemm_variant == 5 || auto5) && p.N > 64) {   // 256 x 128 tile, 8 waves, one LDS buffer (48 KiB), 2 work-groups per CU
+  const bool big = c.tap_variant == 5 || (c.tap_variant == 0 && tiles256 >= 512);
+  if (big && p.N > 64) {
     if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 128, EPI_BIAS_ACT, 1>(c, p, s)
                                                       : launch<T, FORM_CONV, 256, 128, EPI_MASK, 1>(c, p, s);
     return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 128, EPI_BIAS_ACT, 1>(c, p, s)
                                : launch<T, FORM_CONVT, 256, 128, EPI_MASK, 1>(c, p, s);
   }
-  // 256 x 256 tile, 8 waves of 128 x 64, two 64-KiB LDS buffers, one work-group per CU
-  const int tiles6 = ((M + 255) / 256) * ((p.N + 255) / 256) * (form == FORM_CONVT ? 4 : 1);
-  const bool auto6 = false && tiles6 >= 192;
-  if ((g_tapgemm_variant == 6 || auto6) && p.N >= 256) {
-    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 256, EPI_BIAS_ACT, 2, 128>(c, p, s)
-                                                      : launch<T, FORM_CONV, 256, 256, EPI_MASK, 2, 128>(c, p, s);
-    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 256, EPI_BIAS_ACT, 2, 128>(c, p, s)
-                               : launch<T, FORM_CONVT, 256, 256, EPI_MASK, 2, 128>(c, p, s);
-  }
-  // 256 x 256 tile with the five-stage ring (four stages in flight, counted vmcnt across raw barriers), one work-group per CU;
-  // variant 8: the same with the DMA pieces of stage s+4 issued between the MFMA groups of stage s
-  if (g_tapgemm_variant == 7 && p.N >= 256) {
-    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 256, EPI_BIAS_ACT, 5, 128>(c, p, s)
-                                                      : launch<T, FORM_CONV, 256, 256, EPI_MASK, 5, 128>(c, p, s);
-    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 256, EPI_BIAS_ACT, 5, 128>(c, p, s)
-                               : launch<T, FORM_CONVT, 256, 256, EPI_MASK, 5, 128>(c, p, s);
-  }
-  if (g_tapgemm_variant == 8 && p.N >= 256) {
-    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 256, EPI_BIAS_ACT, 6, 128>(c, p, s)
-                                                      : launch<T, FORM_CONV, 256, 256, EPI_MASK, 6, 128>(c, p, s);
-    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 256, EPI_BIAS_ACT, 6, 128>(c, p, s)
-                               : launch<T, FORM_CONVT, 256, 256, EPI_MASK, 6, 128>(c, p, s);
-  }
-  if (g_tapgemm_variant == 1) {
-    if (form == FORM_CONV) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 1>(c, p, s)
-                                                      : launch<T, FORM_CONV, 128, 128, EPI_MASK, 1>(c, p, s);
-    if (p.N > 64) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT, 1>(c, p, s)
-                                             : launch<T, FORM_CONVT, 128, 128, EPI_MASK, 1>(c, p, s);
-  }
-  if (form == FORM_CONV) {
-    if (big) return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 256, 128, EPI_BIAS_ACT, 3>(c, p, s)
-                                        : launch<T, FORM_CONV, 256, 128, EPI_MASK, 3>(c, p, s);
-    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 2>(c, p, s)
-                               : launch<T, FORM_CONV, 128, 128, EPI_MASK, 2>(c, p, s);
-  }
-  const bool narrow = p.N <= 64;
-  if (epi == EPI_BIAS_ACT) {
-    if (narrow) return launch<T, FORM_CONVT, 256, 64, EPI_BIAS_ACT, 2>(c, p, s);
-    return big ? launch<T, FORM_CONVT, 256, 128, EPI_BIAS_ACT, 3>(c, p, s) : launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT, 2>(c, p, s);
-  }
-  if (narrow) return launch<T, FORM_CONVT, 256, 64, EPI_MASK, 2>(c, p, s);
-  return big ? launch<T, FORM_CONVT, 256, 128, EPI_MASK, 3>(c, p, s) : launch<T, FORM_CONVT, 128, 128, EPI_MASK, 2>(c, p, s);
+  if (form == FORM_CONV)
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONV, 128, 128, EPI_BIAS_ACT, 2>(c, p, s) : launch<T, FORM_CONV, 128, 128, EPI_MASK, 2>(c, p, s);
+  if (p.N <= 64)
+    return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 256, 64, EPI_BIAS_ACT, 2>(c, p, s) : launch<T, FORM_CONVT, 256, 64, EPI_MASK, 2>(c, p, s);
+  return epi == EPI_BIAS_ACT ? launch<T, FORM_CONVT, 128, 128, EPI_BIAS_ACT, 2>(c, p, s) : launch<T, FORM_CONVT, 128, 128, EPI_MASK, 2>(c, p, s);
 }
 
 }  // namespace
-
-float* rowsum_alloc(const gct2_ctx& c, size_t rows, int N) {
-  RowsumState& rs = c.rowsum;
-  if (!rs.open || !rs.buf) return nullptr;
-  const size_t need = (rows * (size_t)N + 3) / 4 * 4;
-  // two more targets must fit the table, the rows the buffer; otherwise this launch reduces its rows itself (same result)
-  if (rs.used + need > rs.bytes / sizeof(float) || rs.table.ntargets + 2 > ROWSUM_MAX_TARGETS) { rs.overflow = true; return nullptr; }
-  float* q = rs.buf + rs.used;
-  rs.used += need;
-  return q;
-}
-void rowsum_record(const gct2_ctx& c, const TapGemmParams& p, const float* part, int rows) {
-  RowsumTable& tab = c.rowsum.table;
-  auto add = [&](float* dst, int col0, int ncols, bool adds) {
-    if (!dst || ncols <= 0) return;
-    RowsumTarget* t = nullptr;
-    for (int k = 0; k < tab.ntargets; k++) if (tab.t[k].dst == dst) t = &tab.t[k];
-    if (t && (!adds || t->nsrc >= ROWSUM_MAX_SRC || t->ncols != ncols)) {
-      // an overwriting launch supersedes what was recorded for this target (or the record is full: cannot happen for the U-Net,
-      // every bias gradient has at most two writers) - start over
-      if (!adds) { t->nsrc = 0; t->add = 0; }
-      else return;                                           // unreachable by construction; drop rather than corrupt
-    }
-    if (!t) {
-      t = &tab.t[tab.ntargets++];
-      t->dst = dst; t->ncols = ncols; t->nsrc = 0; t->adam = 0;
-      t->add = adds ? 1 : 0;                                 // first record of the pass adds: keep what dst holds
-    }
-    t->src[t->nsrc++] = RowsumSrc{part, rows, p.N, col0};
-  };
-  add(p.db, 0, p.db_split < p.N ? p.db_split : p.N, (p.db_acc & 1) != 0);
-  add(p.db2, p.db_split, p.N - p.db_split, (p.db_acc & 2) != 0);
-}
-int rowsum_flush_launch(const gct2_ctx& c, const gct2_adam_args* adam, const float* g_base, const int64_t* bias_ranges, int nranges,
-                        hipStream_t s) {
-  RowsumState& rs = c.rowsum;
-  RowsumTable& tab = rs.table;
-  // the biases the caller wants the optimizer applied to: recorded targets get the flag, the others (their launches reduced their
-  // rows themselves: the gradient is in the arena already) join the table without sources
-  for (int r = 0; adam && r < nranges; r++) {
-    float* dst = const_cast<float*>(g_base) + bias_ranges[2 * r];
-    const int ncols = (int)bias_ranges[2 * r + 1];
-    RowsumTarget* t = nullptr;
-    for (int k = 0; k < tab.ntargets; k++) if (tab.t[k].dst == dst) t = &tab.t[k];
-    if (!t) {
-      if (tab.ntargets >= ROWSUM_MAX_TARGETS) return gct2_fail(GCT2_EINVAL, "rowsum_flush: more than %d bias targets", ROWSUM_MAX_TARGETS);
-      t = &tab.t[tab.ntargets++];
-      t->dst = dst; t->ncols = ncols; t->nsrc = 0; t->add = 1;
-    } else if (t->ncols != ncols) return gct2_fail(GCT2_EINVAL, "rowsum_flush: bias range %d has %d elements, the recorded gradient %d", r, ncols, t->ncols);
-    t->adam = 1;
-  }
-  int blocks = 0;
-  for (int k = 0; k < tab.ntargets; k++) { tab.t[k].blk0 = blocks; blocks += (tab.t[k].ncols + 31) / 32; }
-  tab.nblocks = blocks;
-  RowsumAdam ad{};
-  if (adam) ad = RowsumAdam{adam->p, adam->m, adam->v, adam->shadow, g_base, adam->shadow_dtype, adam->alpha, adam->beta1, adam->beta2, adam->eps, adam->grad_mul};
-  if (blocks > 0) hipLaunchKernelGGL(rowsum_flush_kernel, dim3(blocks), dim3(1024), 0, s, tab, ad);
-  rs.open = false; rs.used = 0; tab.ntargets = 0; tab.nblocks = 0;
-  return gct2_check_launch("rowsum_flush");
-}
 
 // true when the MFMA path can take this problem (16-byte aligned rows, whole 8-channel chunks, 31-bit byte offsets)
 bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {
@@ -1089,9 +752,7 @@ bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {
 }
 
 bool halo_convT_wanted(const gct2_ctx& c, int epi, const TapGemmParams& p);      // halo_mfma.hip
-int halo_convT(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s);
-bool halo_conv_wanted(const gct2_ctx& c, int epi, const TapGemmParams& p);       // halo_conv_mfma.hip
-int halo_conv(const gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s);
+int halo_convT(gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s);
 
 // the ordered row reduction of the fused bias gradients, for the other translation units that leave partial rows
 int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, hipStream_t s) {
@@ -1099,7 +760,7 @@ int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, h
   return gct2_check_launch("dbpart_reduce");
 }
 
-int tapgemm_mfma(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s) {
+int tapgemm_mfma(gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams& p, hipStream_t s) {
   if (form == FORM_S1 || form == FORM_S1T) {
     if (epi != (form == FORM_S1 ? EPI_BIAS_ACT : EPI_MASK) || p.ks < 1 || p.ks > 5 || !(p.ks & 1))
       return gct2_fail(GCT2_EINVAL, "tapgemm_mfma: stride-1 form with kernel size %d / epilogue %d", p.ks, epi);
@@ -1107,7 +768,6 @@ int tapgemm_mfma(const gct2_ctx& c, int dtype, int form, int epi, const TapGemmP
     return dispatch<_Float16>(c, form, epi, p, s);
   }
   if (form == FORM_CONVT && c.tap_variant == 0 && halo_convT_wanted(c, epi, p)) return halo_convT(c, dtype, epi, p, s);
-  if (form == FORM_CONV && c.tap_variant == 0 && halo_conv_wanted(c, epi, p)) return halo_conv(c, dtype, epi, p, s);
   if (dtype == GCT2_BF16) return dispatch<__bf16>(c, form, epi, p, s);
   return dispatch<_Float16>(c, form, epi, p, s);
 }

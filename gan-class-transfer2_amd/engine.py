@@ -204,16 +204,6 @@ class UNetEngine:
         self.wgrad_workspace = torch.empty(workspace_mb << 18, dtype=torch.float32, device=self.device) if workspace_mb else None
         self.ctx.set_workspace(self.workspace)
         self.ctx.set_wgrad_workspace(self.wgrad_workspace)
-        # deferred bias-gradient row sums (r03): in the fused single-replica step the 11 input-gradient launches can leave their partial
-        # rows here, and ONE launch behind the last of them sums them all and applies Adam to those biases (the per-layer Adam
-        # launches then cover the kernels only) - instead of 11 small reduction launches on the input-gradient chain (74 -> 64
-        # launches per step).  Bit-identical, and measured 15-25 us SLOWER per step in three in-process A/Bs (the small launches
-        # were hidden in the chain's idle time - the side stream is the critical path - while the flush sits on the tail in front of
-        # DownShuffle_0's weight gradient): off by default.
-        self.defer_rowsums = False
-        self.rowsum_buffer = torch.empty(4 << 20, dtype=torch.float32, device=self.device) if workspace_mb else None
-        if self.rowsum_buffer is not None:
-            self.ctx.set_rowsum_buffer(self.rowsum_buffer)
         # the image layer's weight gradient (HBM-bound, no LDS) is enqueued on the dgrad chain's stream, which has nothing left to
         # do by then, so that it runs BESIDE DownShuffle_1's MFMA-bound weight gradient instead of behind it at the very end of the
         # step; its slabs go to the chain's own scratch (free once the last input gradient is done): a second context
@@ -284,7 +274,11 @@ class UNetEngine:
         b.ld = [_round_up(t.fu(i) + t.cx(i), 8) for i in range(n)]
         z = lambda *shape, dtype=dt: torch.zeros(*shape, dtype=dtype, device=self.device)
         b.R = [z(B, b.hw[i][0], b.hw[i][1], b.ld[i]) for i in range(n)]
-        b.dR = [z(B, b.hw[i][0], b.hw[i][1], b.ld[i]) for i in range(n)]
+        # gradient buffers: same shapes, except level 0 - the image gets no gradient (train.py:224-236: x and eps are data), so dR_0
+        # only holds UpShuffle_0's Fu_0 channels: 128-byte pixels at the reference width instead of R_0's 144-byte rows, which
+        # straddle two 128-byte lines per pixel (r04; U0's input / weight gradients read it, the fused head writes it)
+        b.ldd = [_round_up(t.fu(0), 8) if i == 0 else b.ld[i] for i in range(n)]
+        b.dR = [z(B, b.hw[i][0], b.hw[i][1], b.ldd[i]) for i in range(n)]
         # packed copy of the network input (3 channels + a zero slot): DownShuffle_0 and its weight gradient gather 4x4
         # windows from it instead of striding through R_0's 144-byte rows
         b.img = z(B, H, W, 4)
@@ -475,7 +469,7 @@ class UNetEngine:
         t, A = self.topo, self.arena
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
         call("gct2_dense_head_train", self.ctx.handle, self.dtype, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"),
-             target.data_ptr(), b.pred.data_ptr() if self.keep_pred else None, b.dR[0].data_ptr(), b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"),
+             target.data_ptr(), b.pred.data_ptr() if self.keep_pred else None, b.dR[0].data_ptr(), b.ldd[0], A.gptr("dense.w"), A.gptr("dense.b"),
              b.loss.data_ptr(), b.partials.data_ptr(), b.B * b.H * b.W, t.fu(0) + 3, 3, t.fu(0), ls_ptr, A.gptr("U0.b"),
              b.img.data_ptr(), 4, 0, self._stream())
         return b.loss
@@ -497,7 +491,7 @@ class UNetEngine:
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
         call("gct2_convT4s2_fwd_head_train", self.ctx.handle, self.dtype, x, ldx, A.wptr("U0.w"), A.pptr("U0.b"),
              A.pptr("dense.w"), A.pptr("dense.b"), target.data_ptr(), b.pred.data_ptr() if self.keep_pred else None,
-             b.dR[0].data_ptr(), b.ld[0],
+             b.dR[0].data_ptr(), b.ldd[0],
              A.gptr("dense.w"), A.gptr("dense.b"), b.loss.data_ptr(), b.B, Hi, Wi, t.up_in(0), t.fu(0), t.fu(0) + 3, 3, ls_ptr,
              A.gptr("U0.b"), b.img.data_ptr(), 4, 0, self._stream())
         return b.loss
@@ -527,7 +521,7 @@ class UNetEngine:
         M = b.B * b.H * b.W
         if not head_done:
             call("gct2_dense_bwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), b.dpred.data_ptr(), b.dR[0].data_ptr(),
-                 b.ld[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), 0, s)
+                 b.ldd[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), 0, s)
         with torch.cuda.stream(main):                           # hooks record their events on the stream the gradients come from
             self._ready("dense")
 
@@ -541,29 +535,10 @@ class UNetEngine:
         # the kernel is consumed from the launch's partial sums or from the arena without ever being zeroed.  The update writes
         # the layer's operand copy, so it must follow the layer's dgrad (the last reader): in that mode the dgrad is enqueued
         # first and the side stream waits for it - the weight gradient of layer L then runs beside the dgrad of layer L+1.
-        # row sums deferred to ONE launch at the end of the pass (with the bias optimizer in it): only where nobody needs a bias
-        # gradient earlier - the data-parallel hooks reduce buckets while the pass is still running
-        defer = bool(adam_inline and self.defer_rowsums and self.rowsum_buffer is not None and self.workspace is not None
-                     and self.grad_ready_hook is None)
-        if defer:
-            call("gct2_rowsum_begin", cx)
-        def flush_rowsums() -> None:
-            """ONE launch for every deferred bias gradient (+ their optimizer step), on the chain's stream right behind the LAST
-            input-gradient launch - not at the end of the pass, where it would sit on the tail behind DownShuffle_0's weight gradient"""
-            # every bias whose gradient is a dgrad's column sum: all but UpShuffle_0's (the head produces that one) and dense.b
-            names = [f"D{j}.b" for j in range(n)] + [f"U{j}.b" for j in range(1, n)]
-            args = _lib.AdamArgs(A.p.data_ptr(), A.m.data_ptr(), A.v.data_ptr(), A.shadow.data_ptr() if A.shadow is not None else None,
-                                 self.dtype, A.total, self.adam_alpha(), self.beta_1, self.beta_2, self.epsilon, 1.0)
-            keep.append(args)
-            ranges = (ctypes.c_int64 * (2 * len(names)))(*[v for name in names for v in (A.offsets[name], A.numel(name))])
-            call("gct2_rowsum_flush", cx, ctypes.addressof(args), A.g.data_ptr(), ranges, len(names), s)
-
         def fused(layer: str):
             if not adam_inline:
                 return None
             lo, hi = A.layer_ranges[layer]
-            if defer and layer != "U0":          # the bias follows in the flush launch (UpShuffle_0's comes from the head, not a dgrad)
-                hi = lo + A.numel(layer + ".w")
             args = _lib.AdamArgs(A.p.data_ptr() + 4 * lo, A.m.data_ptr() + 4 * lo, A.v.data_ptr() + 4 * lo,
                                  (A.shadow.data_ptr() + 2 * lo) if A.shadow is not None else None, self.dtype, hi - lo,
                                  self.adam_alpha(), self.beta_1, self.beta_2, self.epsilon, 1.0)
@@ -580,7 +555,7 @@ class UNetEngine:
                 x, ldx, dx, lddx = b.R[i + 1].data_ptr(), b.ld[i + 1], b.dR[i + 1].data_ptr(), b.ld[i + 1]
             else:
                 x, ldx, dx, lddx = b.Dlast.data_ptr(), t.fd(i), b.dDlast.data_ptr(), t.fd(i)
-            dz, lddz = b.dR[i].data_ptr(), b.ld[i]
+            dz, lddz = b.dR[i].data_ptr(), b.ldd[i]
             # bias gradients are column sums of pre-activation gradients: each dgrad launch produces the sums of the tensor it
             # writes (fused into its epilogue), so only U_0's bias needs the wgrad entry point's db when the head is unfused.
             # Nothing accumulates across steps: the first writer of a bias gradient overwrites it (db_accumulate bit clear),
@@ -624,8 +599,6 @@ class UNetEngine:
 
             if adam_inline:
                 dgrad_d()
-            if defer and i == 0:
-                flush_rowsums()                  # every input-gradient launch of the pass has been enqueued
             if i == 0 and adam_inline and side is not main and self.tail_on_chain and self.workspace is not None:
                 call("gct2_conv4s2_wgrad", self.ctx_tail.handle, dt, xw, ldxw, dz, lddz, A.gptr("D0.w"), None, b.B, H, W, t.cx(0),
                      t.fd(0), 0, fused("D0"), s)

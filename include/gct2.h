@@ -37,16 +37,17 @@ enum {
 };
 
 /* library / device identification ------------------------------------------------------------ */
-int gct2_abi_version(void);                 /* bumps when a signature below changes (v12: diffusion_update modes, build flags; v13: ReLU bit planes) */
+int gct2_abi_version(void);                 /* bumps when a signature below changes (v13: ReLU bit planes; v14: pruned tuning word, launch log, no deferred row sums) */
 /* how the library was built: 0 for the product build; bit 0 (GCT2_BUILD_STAMP) = diagnostic build with in-kernel phase stamps
  * (make EXTRA=-DGCT2_STAMP).  Product hosts (the Python binding, bench.py, the tests) refuse a library whose flags are not 0. */
 enum { GCT2_BUILD_STAMP = 1 };
 int gct2_build_flags(void);
 const char* gct2_last_error(void);          /* host string describing the last non-OK return */
 int gct2_device_check(void);                /* GCT2_OK iff the current device is gfx950 */
-/* ---- call context: caller-owned scratch + tuning, re-entrant across streams -------------------------------------------
+/* ---- call context: caller-owned scratch + tuning, one per engine / host thread ------------------------------------------
  * The library keeps NO process-wide mutable state (ABI v11).  A gct2_ctx is a small host object created by the caller; it
- * carries (a) the caller's device scratch for split reductions / partial rows and (b) the tile-selection knobs.  Calls that
+ * carries (a) the caller's device scratch for split reductions / partial rows and (b) the tile-selection knobs.  A ctx is used by
+ * ONE host thread at a time (the layer entry points write its one-shot ReLU plane and its launch log).  Calls that
  * share one ctx must be enqueued on ONE stream at a time per scratch area (forward / input-gradient / head calls use the
  * main workspace, *_wgrad calls the weight-gradient workspace when one is set); calls with DIFFERENT ctx objects (two
  * engines, two host threads, two streams) are fully independent.  ctx = NULL is allowed everywhere: no scratch (split-K and
@@ -60,36 +61,15 @@ int gct2_ctx_set_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
 /* optional second scratch used by the weight-gradient entry points only (their partial-tile slabs): with it *_wgrad calls
  * may run on a second stream concurrently with the forward/dgrad calls of the same ctx (the engine's reverse pass does). */
 int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
-/* tuning (same results for every value; tests cover each tile, scripts/bench_layer.py does A/B timing).
- * bits 0-7: dgrad/forward tile, 0 = automatic, 1/2 = 128x128 with 1/2 LDS buffers, 3 = 256x128 8 waves 3 buffers,
- * 5 = 256x128 one buffer, 6 = 256x256 (128x64 wave tiles);
- * bits 16-19: weight-gradient tile, 0 = automatic, 1/3 = 128x128 with 1/2 buffers, 2 (or 5) = 256x256, 4 = 256x128 at two
- * work-groups per CU, 7 = atomics, 6 / 8 = as 0 / 2 with the r02 stage code of the 256x256 pipeline instead of the lean stage,
- * 9 = 256x256 with the fragment reads of the next rows / next stage issued under the MFMAs (wgrad256r_kernel: same speed);
- * bit 20: aim at 512 instead of 256 work-groups on the 256x256 weight-gradient tile; bit 21: at most 24 pixel splits as ordered
- * slabs on the 128x128 weight-gradient tile (r02; more splits then use atomics - arrival-order dependent; default since r03: slabs
- * whenever the workspace holds them);
- * bit 22: 256x256 weight-gradient tile with two 64-row buffers instead of the four-stage pipeline;
- * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D dgrad), 0 = automatic, 1 = never, 2 = wherever the shape allows;
- * bits 26-27: tile -> XCD order of the forward / input-gradient GEMMs, 0 = automatic, 1 = bands of output pixels per XCD,
- * 2 = weight slices per XCD (layers whose weight tensor is the bigger operand);
- * bits 28-30: forced pixel split of the 128x128 weight-gradient tile, 0 = automatic, v = 1..7: 2^(v-1) splits;
- * r03 additions - tile values 7 / 8 (bits 0-7): 256x256 with a five-stage LDS ring (8: DMA interleaved with the MFMA groups);
- * bit 8: apply the fused optimizer step (gct2_adam_args) INSIDE the epilogue of weight-gradient launches whose tiles have one owner
- * (the gradient never leaves the registers: 8 B per parameter less traffic; measured +70 us per step - the epilogue's p/m/v round
- * trips hold the matrix-core work-groups - so off by default: the step runs the streaming Adam launch behind the gradient);
- * bit 9: automatic weight-gradient tile as in r02 (256x256 below 256 small tiles; default since r03 with the lean stage: below 512,
- * which moves UpShuffle_2 and DownShuffle_3 to the big tile: -11..-14 us per step in in-process A/Bs);
- * bits 10-11: the big tile only with at least 8 (0, default) / 4 (1) / 32 (2) 64-row steps per pixel split (4 also moves
- * DownShuffle_4 to the big tile: the step is within 3 us of the default, the launch moves 164 MB instead of 36 MB);
- * bit 12: Conv2D forward / Conv2DTranspose input gradient take the conv-form halo kernel (r03, halo_conv_mfma.hip) where the output
- * grid tiles into 16x16 patches with full 256-channel tiles (off by default: measured 0..12 % slower than the tap GEMM);
- * bits 13-15: start offset between four groups of CUs in the one-work-group-per-CU kernels (halo tile, 256x256 weight gradients), units
- * of 2048 cycles; 0 = off (measured: no gain, profiles/r03_stagger.txt);
- * bit 23: FOUR stage buffers instead of five (all 160 KiB of LDS, the default since r03: +3..7 % on the two largest layers) in the
- * 256x256 weight-gradient pipeline;
- * bit 31: halo-tile kernel with the DMA of the next round issued in FRONT of the current round's MFMAs (r02) instead of between
- * its MFMA groups (default since r03: -3..-6 % on the UpShuffle_1/2 forward launches). */
+/* tuning: forces a tile / order instead of the automatic per-layer choice (same results for every value within the stated
+ * tolerances; the parity tests and scripts/bench_layer.py use it).  Unknown words are rejected.
+ * bits 0-7  : forward / input-gradient tile: 0 = automatic, 2 = 128x128 (two LDS buffers), 5 = 256x128 (one buffer, 8 waves);
+ * bits 16-23: weight-gradient tile: 0 = automatic, 2 = 256x256 five-stage ring, 3 = 128x128, 7 = 128x128 with fp32 atomics
+ *             instead of ordered slabs (arrival-order dependent: comparison tests only);
+ * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D input gradient): 0 = automatic, 1 = never, 2 = wherever allowed;
+ * bits 26-27: tile -> XCD order of the forward / input-gradient GEMMs: 0 = automatic, 1 = bands of output pixels per XCD,
+ *             2 = weight slices per XCD;
+ * bits 28-30: forced pixel split of the 128x128 weight-gradient tile: 0 = automatic, v = 1..7: 2^(v-1) splits. */
 int gct2_ctx_set_tuning(gct2_ctx* ctx, int v);
 /* test hook: non-zero routes every convolution of this ctx through the direct (non-MFMA) kernels */
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on);
@@ -100,30 +80,21 @@ int gct2_ctx_force_direct(gct2_ctx* ctx, int on);
  *  - before gct2_conv4s2_dgrad / gct2_convT4s2_dgrad with act != NULL: the call MAY read its ReLU mask from the plane instead of
  *    act (1 byte instead of 16 per 8 channels: the mask read is a third of the epilogue traffic of these calls).  The plane must
  *    equal (act > 0) over the Cin channels of the call - which of the two a given kernel reads is unspecified.
- * Channels must be a multiple of 8, ld_bytes >= channels / 8.  bits = NULL clears a pending plane. */
+ * Channels must be a multiple of 8, ld_bytes >= channels / 8.  bits = NULL clears a pending plane.  EVERY layer entry point that
+ * takes a ctx removes a pending plane first thing, whether it succeeds or not; the ones that cannot use a plane (weight gradients,
+ * the head calls, the stride-1 convolutions) return GCT2_EINVAL when one was pending. */
 int gct2_ctx_set_relu_bits(gct2_ctx* ctx, void* bits, int ld_bytes);
 /* diagnostic builds only (gct2_build_flags() & GCT2_BUILD_STAMP): device buffer that receives the s_memrealtime phase stamps of
  * one wave per work-group of the next stamped launch of this ctx (layout: scripts/stamp_*.py).  GCT2_EINVAL in a product build. */
 int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes);
 
-/* ---- deferred bias-gradient row sums (r03) --------------------------------------------------------------------------------
- * The fused bias gradients of the *_dgrad entry points (db / db2) are column sums over partial rows, one row per work-group; by
- * default every dgrad call finishes them with a small reduction launch of its own.  Between gct2_rowsum_begin and
- * gct2_rowsum_flush the calls of this ctx leave their partial rows in the caller's row-sum buffer instead and only record which
- * target each belongs to; the flush is ONE launch that sums every target's sources in call order - bit-identical to the
- * immediate form, including "first writer overwrites, second adds" (db_accumulate).  With `adam` the same launch applies Keras
- * Adam to the biases listed in bias_ranges (HOST array of nranges (offset, count) pairs, in elements from g_base; adam->p / m /
- * v / shadow = ARENA BASES matching g_base, the base of the gradient arena the db targets live in; adam->n = arena length): a
- * listed bias whose gradient was not deferred (its launches reduced their rows themselves: no workspace rows, a full buffer, the
- * direct kernels) is updated from the value already in the arena.  The bias gradients are complete only after the flush: a
- * data-parallel run that reduces gradient buckets while the reverse pass is still running must not open a deferral.  A call that
- * no longer fits the buffer (or the 16-target table) simply reduces its rows itself. */
-int gct2_ctx_set_rowsum_buffer(gct2_ctx* ctx, void* buf, size_t bytes);      /* 16-byte aligned device scratch, or NULL */
-int gct2_rowsum_begin(gct2_ctx* ctx);
-/* (gct2_adam_args is declared below) */
-struct gct2_adam_args;
-int gct2_rowsum_flush(gct2_ctx* ctx, const struct gct2_adam_args* adam /* or NULL */, const float* g_base,
-                      const int64_t* bias_ranges /* host */, int nranges, void* stream);
+/* launch log (tests / diagnostics): while switched on, every layer entry point of this ctx appends the kernel it selected as a
+ * text token ("tap:conv:256x128:mask:ksplit=1:bits;", "halo:convT:bias_act;", "wgrad:256q:rsplit=8:slabs;", "rgb:fwd;",
+ * "direct:tap;", "relu_bits:derived;" ...).  gct2_ctx_log_launches(ctx, on) clears the log and switches it; read copies the
+ * NUL-terminated text (truncated to bytes - 1) and clears it.  A parity test at reduced batch uses it to prove that the kernels it
+ * forced are the ones that ran. */
+int gct2_ctx_log_launches(gct2_ctx* ctx, int on);
+int gct2_ctx_read_launch_log(gct2_ctx* ctx, char* buf, size_t bytes);
 
 /* ---- DownShuffle = Conv2D(f, 4, 2, 'same', relu)   train.py:158-169 ------------------------- */
 /* y[b,oh,ow,o] = act(bias[o] + sum_{kh,kw,i} x[b,2oh+kh-1,2ow+kw-1,i] * w[kh,kw,i,o])

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gct2.h but not exported"
     # and the ctypes table binds exactly the declared entry points (minus last_error, bound separately)
     assert sorted(set(g._lib.SIGNATURES) | {"gct2_last_error"}) == names
-    assert g._lib.load().gct2_abi_version() == g._lib.ABI_VERSION == 13
+    assert g._lib.load().gct2_abi_version() == g._lib.ABI_VERSION == 14
     # the shipped library is the PRODUCT build: no in-kernel stamps, and the diagnostic hook refuses
     assert g._lib.build_flags() == 0
     c = g._lib.Context()
@@ -82,6 +82,8 @@ def test_call_context_is_host_only_and_independent():
     assert L.gct2_ctx_set_workspace(a.handle, 24, 1 << 20) == 1 and b"16-byte" in L.gct2_last_error()      # misaligned
     assert L.gct2_ctx_set_workspace(a.handle, 4096, 1 << 20) == 0 and L.gct2_ctx_set_workspace(a.handle, None, 0) == 0
     assert L.gct2_ctx_set_tuning(b.handle, 2 | (3 << 16) | (1 << 24)) == 0 and L.gct2_ctx_force_direct(b.handle, 1) == 0
+    assert L.gct2_ctx_set_tuning(b.handle, 7) == 1 and b"unknown tuning" in L.gct2_last_error()           # a tile that was pruned in r04
+    assert L.gct2_ctx_set_tuning(b.handle, 0x100) == 1                                                     # ... and a removed switch
     assert L.gct2_ctx_set_workspace(None, None, 0) == 1                                                    # null ctx
     for name in ("gct2_set_workspace", "gct2_set_wgrad_workspace", "gct2_debug_tapgemm_variant", "gct2_debug_force_direct"):
         assert not hasattr(L, name), name                           # the process-wide hooks of ABI v10 are gone
@@ -186,9 +188,41 @@ def test_lds_swizzles_are_conflict_free_in_the_bank_model():
     mod.main()
 
 
-def test_buffer_sets_are_bounded():
-    """UNetEngine keeps at most `max_buffer_sets` activation buffer sets, least recently used first (r02 kept one per shape ever seen)."""
-    import inspect
-    from gan_class_transfer2_amd import engine
-    src = inspect.getsource(engine.UNetEngine.buffers)
-    assert "max_buffer_sets" in src and "popitem(last=False)" in src and "move_to_end" in src
+def test_one_shot_relu_plane_never_outlives_its_call():
+    """gct2_ctx_set_relu_bits registers a plane for the NEXT layer call only.  Every layer entry point takes it out of the ctx first
+    thing, so a call rejected by its argument checks cannot leak it to a later layer (r03 consumed it behind the checks), and an
+    entry point that can neither write nor read a plane says so.  Host-side only: nothing is launched (every call is rejected)."""
+    import gan_class_transfer2_amd as g
+    L = g._lib.load()
+    c = g._lib.Context()
+    plane = 4096                                                    # never dereferenced: every call below fails its checks
+    # (1) a rejected forward call consumes the plane: the weight-gradient call behind it fails for ITS reason, not for a pending plane
+    c.set_relu_bits(plane, 16)
+    assert L.gct2_conv4s2_fwd(c.handle, 1, 16, 8, 16, None, 16, 8, 1, 5, 4, 8, 8, 1, None) == 1 and b"even" in L.gct2_last_error()
+    assert L.gct2_conv4s2_wgrad(c.handle, 1, 16, 8, 16, 8, 16, None, 1, 5, 4, 8, 8, 0, None, None) == 1
+    assert b"even" in L.gct2_last_error() and b"plane" not in L.gct2_last_error()
+    # (2) the same through a rejected input-gradient call
+    c.set_relu_bits(plane, 16)
+    assert L.gct2_convT4s2_dgrad(c.handle, 1, 16, 8, 16, 16, 4, 16, 8, 1, 4, 4, 8, 8, 0, None, 0, None, 0, None) == 1      # ldact < Cin
+    assert L.gct2_convT4s2_wgrad(c.handle, 1, 16, 4, 16, 8, 16, None, 1, 4, 4, 8, 8, 0, None, None) == 1
+    assert b"plane" not in L.gct2_last_error()
+    # (3) entry points that cannot use a plane reject a pending one - and clear it
+    for call in (lambda: L.gct2_conv4s2_wgrad(c.handle, 1, 16, 8, 16, 8, 16, None, 1, 4, 4, 8, 8, 0, None, None),
+                 lambda: L.gct2_convT4s2_wgrad(c.handle, 1, 16, 8, 16, 8, 16, None, 1, 4, 4, 8, 8, 0, None, None),
+                 lambda: L.gct2_conv2d_s1_fwd(c.handle, 1, 16, 8, 16, None, 16, 8, 1, 4, 4, 8, 8, 3, 1, None)):
+        c.set_relu_bits(plane, 16)
+        assert call() == 1 and b"ReLU bit plane was registered" in L.gct2_last_error()
+    assert L.gct2_conv4s2_wgrad(c.handle, 1, 16, 8, 16, 8, 16, None, 1, 5, 4, 8, 8, 0, None, None) == 1 and b"even" in L.gct2_last_error()
+    # (4) a plane that does not fit the call's channels is an error of that call, and gone afterwards
+    c.set_relu_bits(plane, 1)
+    assert L.gct2_conv4s2_fwd(c.handle, 1, 16, 8, 16, None, 16, 16, 1, 4, 4, 8, 16, 1, None) == 1 and b"ld_bytes" in L.gct2_last_error()
+    assert L.gct2_conv4s2_wgrad(c.handle, 1, 16, 8, 16, 8, 16, None, 1, 5, 4, 8, 8, 0, None, None) == 1 and b"even" in L.gct2_last_error()
+
+
+def test_launch_log_is_per_context_and_host_only():
+    import gan_class_transfer2_amd as g
+    c = g._lib.Context()
+    assert c.read_launch_log() == []
+    c.log_launches(True)
+    assert c.read_launch_log() == []                                 # nothing launched yet; reading clears
+    c.log_launches(False)

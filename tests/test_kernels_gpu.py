@@ -222,14 +222,12 @@ def test_wgrad_reduction_modes_agree(gpu, shape):
 
 
 @pytest.mark.parametrize("use_ws", [False, True])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 9, 0x42, 0x82])
+@pytest.mark.parametrize("variant", [2, 3, 7])
 @pytest.mark.parametrize("shape", [(4, 32, 32, 64, 128), (1, 12, 20, 72, 136), (2, 8, 8, 256, 512)])
 def test_wgrad_tile_variants(gpu, variant, shape, use_ws):
-    """weight-gradient tile variants: 1 = 128x128 single buffer, 2 = 256x256 (8 waves of 128x64) with the spanning pipeline (counted
-    vmcnt across raw barriers; five stage buffers and the lean stage of r03 - incremental gather addresses, fragment addresses
-    computed once), 8 = the same pipeline with the r02 stage code, 0x82 = four stage buffers, 0x42 = 256x256 with two 64-row buffers,
-    3 = 128x128 double buffer, 4 = 256x128 single buffer at two work-groups per CU (r03); without a workspace (atomics) and with one
-    (ordered slabs)."""
+    """weight-gradient tiles: 2 = 256x256 (8 waves of 128x64), five-stage ring with counted vmcnt across raw barriers and the lean
+    stage (incremental gather addresses, fragment addresses computed once); 3 = 128x128 with two buffers (lean stage since r04);
+    7 = 128x128 keeping fp32 atomics although a workspace is registered; without a workspace (atomics) and with one (ordered slabs)."""
     B, H, W, Cin, Cout = shape
     dt = BF16
     L = lib()
@@ -254,11 +252,12 @@ def test_wgrad_tile_variants(gpu, variant, shape, use_ws):
         set_ws(None)
 
 
+@pytest.mark.parametrize("variant", [2, 3])
 @pytest.mark.parametrize("shape", [(3, 40, 24, 64, 128), (5, 8, 8, 128, 64), (2, 64, 64, 64, 256), (7, 4, 12, 256, 72)])
-def test_wgrad_lean_stage_equals_pipeline_bit_for_bit(gpu, shape):
-    """wgrad256q_kernel (variant 2, the default big tile) advances its gather addresses incrementally (32 rows per stage, carries into
-    the next image row and the next image) where wgrad256p_kernel (variant 8) recomputes them: same multiplies in the same order, so the fp32 results
-    must be identical - on grids narrower and wider than a stage, ragged row counts, several images per stage."""
+def test_wgrad_incremental_gather_addresses(gpu, shape, variant):
+    """both weight-gradient kernels advance their gather addresses incrementally (32 / 64 rows per stage, carries into the next image
+    row and the next image) instead of decoding every row: checked against the oracle on grids narrower and wider than a stage,
+    ragged row counts and several images per stage, in overwrite mode, twice (bitwise reproducible through the ordered slabs)."""
     B, H, W, Cin, Cout = shape
     dt, L = BF16, lib()
     rng = np.random.default_rng(61)
@@ -268,20 +267,19 @@ def test_wgrad_lean_stage_equals_pipeline_bit_for_bit(gpu, shape):
     xd, dzd, dztd = dev(x, dt, gpu), dev(dz, dt, gpu), dev(dzt, dt, gpu)
     ws = torch.empty(32 << 18, dtype=torch.float32, device=gpu)
     set_ws(ws)
-    res = {}
+    res = []
     try:
-        for variant in (2, 8, 9):
-            set_tuning(variant << 16)
-            dw = torch.zeros(4, 4, Cin, Cout, dtype=torch.float32, device=gpu)
-            dwt = torch.zeros(4, 4, Cout, Cin, dtype=torch.float32, device=gpu)
+        set_tuning(variant << 16)
+        for rep in range(2):
+            dw = torch.full((4, 4, Cin, Cout), float("nan"), dtype=torch.float32, device=gpu)
+            dwt = torch.full((4, 4, Cout, Cin), float("nan"), dtype=torch.float32, device=gpu)
             L.call("gct2_conv4s2_wgrad", ctx(), dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
             L.call("gct2_convT4s2_wgrad", ctx(), dt, xd.data_ptr(), Cin, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
             torch.cuda.synchronize()
-            res[variant] = (dw, dwt)
-        assert torch.equal(res[2][0], res[8][0]) and torch.equal(res[2][1], res[8][1])
-        assert torch.equal(res[2][0], res[9][0]) and torch.equal(res[2][1], res[9][1])      # 9: rolling fragment window (wgrad256r_kernel)
-        assert rel_l2(res[2][0].cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
-        assert rel_l2(res[2][1].cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
+            res.append((dw, dwt))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert rel_l2(res[0][0].cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
+        assert rel_l2(res[0][1].cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
     finally:
         set_tuning(0)
         set_ws(None)
@@ -355,16 +353,12 @@ def test_splitk_bottleneck_layers(gpu, dt, order):
         set_ws(None)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [2, 5])
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 12, 20, 72, 136), (3, 2, 2, 256, 64), (1, 32, 32, 128, 256), (1, 8, 12, 264, 328),
                                    (2, 16, 16, 512, 256)])
 def test_tapgemm_tile_variants(gpu, variant, shape):
-    """every tile variant on every use: 1/2 = 128x128 (1/2 LDS buffers), 3 = 256x128 8-wave 3-buffer (counted vmcnt),
-    5 = 256x128 single buffer, 6 = 256x256 with 128x64 wave tiles, 7 = 256x256 with the five-stage ring (four 32-channel stages in
-    flight, counted vmcnt across raw barriers; r03), 8 = 7 with the DMA pieces issued between the MFMA groups - 6, 7 and 8 are taken
-    where N >= 256, else the call falls through to the default.
-    The last shape gives the ring 16 (Conv2DTranspose forward: 4 taps x 512 / 32) to 256 stages per work-group: several trips of
-    its five-buffer loop, every tail length of the ragged shapes before it."""
+    """both tiles on every use: 2 = 128x128 with two LDS buffers, 5 = 256x128 with one buffer and 8 waves (N <= 64 falls through to
+    the 256x64 tile); ragged M / K / N, one to 128 reduction steps per work-group."""
     B, H, W, Cin, Cout = shape
     dt = BF16
     L = lib()
@@ -446,15 +440,15 @@ def test_dgrad_fused_bias_gradients(gpu, dt, shape, use_ws):
 
 @pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("shape", [(2, 8, 8, 256, 64), (1, 16, 16, 328, 72), (8, 4, 4, 512, 256)])
-def test_ring_tile_dgrad_epilogues(gpu, shape, use_ws):
-    """the 256 x 256 ring tile (variant 7) through the input-gradient epilogues: ReLU mask, accumulation into a running buffer, the
-    fused bias gradients (partial rows in the workspace / atomics without one), split-K slabs + finalize where the workspace allows
-    it (third shape: 2 x 2 = 4 tiles per form) - against the oracle."""
+def test_big_tile_dgrad_epilogues(gpu, shape, use_ws):
+    """the 256 x 128 tile (variant 5: the automatic choice of the big levels at batch 64) through the input-gradient epilogues: ReLU
+    mask, accumulation into a running buffer, the fused bias gradients (partial rows in the workspace / atomics without one), split-K
+    slabs + finalize where the workspace allows it (third shape) - against the oracle."""
     B, H, W, Cin, Cout = shape
     dt, L = BF16, lib()
     ws = torch.empty(32 << 18, dtype=torch.float32, device=gpu)
     set_ws(ws if use_ws else None)
-    set_tuning(7)
+    set_tuning(5)
     try:
         rng = np.random.default_rng(23)
         x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
@@ -485,7 +479,7 @@ def test_ring_tile_dgrad_epilogues(gpu, shape, use_ws):
         assert np.abs(db.cpu().numpy() - cst[:split]).max() <= 2e-3 * scale_t
         assert np.abs(db2.cpu().numpy() - cst[split:]).max() <= 2e-3 * scale_t
         assert rel_l2(dxt.double().cpu().numpy(), contrib_t) <= TOL_OUT[dt]
-        # bit-reproducible (ordered partial rows / slabs) when a workspace is there: the race screen of the ring's hand-placed waits
+        # bit-reproducible (ordered partial rows / slabs) when a workspace is there
         if use_ws:
             dxt2 = torch.zeros_like(dxt); db_a, db2_a = db.clone(), db2.clone()
             for _ in range(3):
@@ -784,8 +778,7 @@ def test_convT_fwd_halo_kernel(gpu, dt, shape):
     xd, wtd, bd = dev(x, dt, gpu), dev(wt, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
     ref = np.maximum(O.convT4s2_fwd(x, wt, b), 0)
     outs = []
-    IL = -(1 << 31)              # bit 31 of the tuning word: the r02 order (DMA pieces in front of the round's MFMAs) instead of interleaved
-    for mode in ((2 << 24), (2 << 24) + IL, (1 << 24)):          # halo forced / forced + interleaved / off: each against the oracle
+    for mode in ((2 << 24), (1 << 24)):                          # halo forced / off: each against the oracle
         set_tuning(mode)
         try:
             ld = Cout + 16                # view = channels [8, 8 + Cout): 16-byte aligned rows (the halo kernel's epilogue needs that)
@@ -798,14 +791,12 @@ def test_convT_fwd_halo_kernel(gpu, dt, shape):
         assert rel_l2(yt[..., 8:8 + Cout].double().cpu().numpy(), ref) <= TOL_OUT[dt], mode
         assert float((yt[..., :8].float() - 7).abs().max()) == 0 and float((yt[..., 8 + Cout:].float() - 7).abs().max()) == 0
         outs.append(yt)
-    assert torch.equal(outs[0], outs[1])                         # the interleaved form runs the same multiplies in the same order
-    assert rel_l2(outs[0].double().cpu().numpy(), outs[2].double().cpu().numpy()) <= TOL_OUT[dt]
+    assert rel_l2(outs[0].double().cpu().numpy(), outs[1].double().cpu().numpy()) <= TOL_OUT[dt]
 
 
-@pytest.mark.parametrize("il", [0, 1])
 @pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64, 24), (1, 32, 64, 136, 64)])
-def test_conv_dgrad_halo_kernel(gpu, shape, use_ws, il):
+def test_conv_dgrad_halo_kernel(gpu, shape, use_ws):
     """the halo-tile kernel as the Conv2D input gradient (mask, accumulation into a running buffer, fused bias gradients with the
     split at db_split, partial rows with a workspace / atomics without): forced on and compared with the oracle."""
     B, H, W, Cin, Cout = shape                     # dgrad output [B,H,W,Cin]; small grid H/2 x W/2 must tile into 16 x 16
@@ -813,7 +804,7 @@ def test_conv_dgrad_halo_kernel(gpu, shape, use_ws, il):
     L = lib()
     ws = torch.empty(8 << 18, dtype=torch.float32, device=gpu)
     set_ws(ws if use_ws else None)
-    set_tuning((2 << 24) - (il << 31))
+    set_tuning(2 << 24)
     try:
         rng = np.random.default_rng(41)
         x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
@@ -961,72 +952,6 @@ def test_relu_bit_plane_read_by_input_gradient_calls(gpu, case):
         set_ws(None)
 
 
-@pytest.mark.parametrize("dt", [BF16, F16])
-@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 256), (1, 64, 32, 48, 72), (3, 32, 64, 16, 264), (1, 32, 32, 128, 8)])
-def test_conv_fwd_halo_kernel(gpu, dt, shape):
-    """conv-form halo kernel (r03) as the Conv2D forward: the 4x4 / stride-2 window through the space-to-depth view of its source
-    (18 x 18 block halo per 16-channel chunk, weights as T images); forced on (tuning bits 24-25 = 2) and the default path, each
-    compared with the oracle on a strided output view; shapes cover one and several patches per image in both directions, several
-    images, K = 16 .. 128 (one chunk, odd numbers of chunks), ragged and tiny N (idle channel quarters), more than one channel tile."""
-    B, H, W, Cin, Cout = shape
-    L = lib()
-    rng = np.random.default_rng(71)
-    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
-    w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
-    b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
-    xd, wd, bd = dev(x, dt, gpu), dev(w, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
-    ref = np.maximum(O.conv4s2_fwd(x, w, b), 0)
-    outs = []
-    for mode in ((2 << 24), 0):                                  # conv-form halo forced / the tap GEMM (automatic choice)
-        set_tuning(mode)
-        try:
-            ld = Cout + 16
-            yt = torch.full((B, H // 2, W // 2, ld), 7.0, dtype=TDT[dt], device=gpu)
-            L.call("gct2_conv4s2_fwd", ctx(), dt, xd.data_ptr(), Cin, wd.data_ptr(), bd.data_ptr(), yt.data_ptr() + 8 * yt.element_size(), ld,
-                   B, H, W, Cin, Cout, 1, stream())
-            torch.cuda.synchronize()
-        finally:
-            set_tuning(0)
-        assert rel_l2(yt[..., 8:8 + Cout].double().cpu().numpy(), ref) <= TOL_OUT[dt], mode
-        assert float((yt[..., :8].float() - 7).abs().max()) == 0 and float((yt[..., 8 + Cout:].float() - 7).abs().max()) == 0
-        outs.append(yt)
-    assert rel_l2(outs[0].double().cpu().numpy(), outs[1].double().cpu().numpy()) <= TOL_OUT[dt]
-
-
-@pytest.mark.parametrize("use_ws", [False, True])
-@pytest.mark.parametrize("shape", [(2, 16, 16, 256, 32), (1, 16, 32, 72, 48), (2, 32, 16, 520, 16)])
-def test_convT_dgrad_halo_kernel(gpu, shape, use_ws):
-    """the conv-form halo kernel as the Conv2DTranspose input gradient (mask, accumulation into a running buffer, fused bias
-    gradients with the split at db_split, partial rows with a workspace / atomics without): forced on and compared with the oracle."""
-    B, H, W, Cin, Cout = shape                     # dgrad output [B,H,W,Cin] (the SMALL grid, 16 x 16 patches); dz on [B,2H,2W,Cout]
-    dt = BF16
-    L = lib()
-    ws = torch.empty(8 << 18, dtype=torch.float32, device=gpu)
-    set_ws(ws if use_ws else None)
-    set_tuning(2 << 24)
-    try:
-        rng = np.random.default_rng(73)
-        x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
-        wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
-        dz = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
-        prev = rnd(rng.standard_normal((B, H, W, Cin)), dt)
-        contrib = O.convT4s2_bwd(x, wt, dz)[0] * (x > 0)
-        split = (Cin // 2) // 8 * 8
-        dxd, dzd, wd, xd = dev(prev, dt, gpu), dev(dz, dt, gpu), dev(wt, dt, gpu), dev(x, dt, gpu)
-        db = torch.full((split,), 3.0, device=gpu); db2 = torch.full((Cin - split,), -1.0, device=gpu)
-        L.call("gct2_convT4s2_dgrad", ctx(), dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin,
-               dxd.data_ptr(), Cin, B, H, W, Cin, Cout, 1, db.data_ptr(), split, db2.data_ptr(), 3, stream())
-        torch.cuda.synchronize()
-        cs = contrib.reshape(-1, Cin).sum(0)
-        scale = np.abs(contrib).reshape(-1, Cin).sum(0).max()
-        assert np.abs(db.cpu().numpy() - 3.0 - cs[:split]).max() <= 2e-3 * scale
-        assert np.abs(db2.cpu().numpy() + 1.0 - cs[split:]).max() <= 2e-3 * scale
-        assert rel_l2(dxd.double().cpu().numpy(), contrib + prev) <= TOL_OUT[dt]
-    finally:
-        set_tuning(0)
-        set_ws(None)
-
-
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64, 128), (2, 8, 8, 256, 512), (1, 16, 16, 3, 128)])
@@ -1065,81 +990,3 @@ def test_wgrad_overwrite_mode(gpu, dt, shape, use_ws):
         set_ws(None)
 
 
-def test_deferred_rowsum_flush_equals_immediate_reduction(gpu):
-    """gct2_rowsum_begin / gct2_rowsum_flush (r03): two input-gradient launches that feed the same bias-gradient target (first
-    overwrites, second adds - the skip slice of a concat buffer) and a third target, deferred into ONE flush launch, against the
-    same calls with their own reduction launches: bit-identical; then the flush with the bias optimizer against Adam on the
-    immediate gradients."""
-    L = lib()
-    dt, B, H, W, Cin, Cout = BF16, 2, 32, 32, 64, 128
-    rng = np.random.default_rng(77)
-    x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
-    w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
-    wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
-    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
-    dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
-    xd, wd, wtd, dzd, dztd = dev(x, dt, gpu), dev(w, dt, gpu), dev(wt, dt, gpu), dev(dz, dt, gpu), dev(dzt, dt, gpu)
-    ws = torch.empty(8 << 18, dtype=torch.float32, device=gpu)
-    rows = torch.empty(1 << 20, dtype=torch.float32, device=gpu)
-    set_ws(ws)
-    _CTX[0].set_rowsum_buffer(rows)
-    split = 24
-    n = 256                                       # a small "arena": g | p | m | v of 256 floats, targets at offsets 0 / 64 / 128
-
-    def run(deferred, with_adam):
-        g = torch.full((n,), 5.0, device=gpu)
-        p_ = torch.linspace(-1, 1, n, device=gpu); m_ = torch.zeros(n, device=gpu); v_ = torch.zeros(n, device=gpu)
-        dx1 = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu); dx2 = torch.zeros_like(dx1)
-        if deferred:
-            L.call("gct2_rowsum_begin", ctx())
-        # launch 1 (Conv2D dgrad, halo or tap GEMM): overwrites target A = g[0:24] and target B = g[64:104]
-        L.call("gct2_conv4s2_dgrad", ctx(), dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dx1.data_ptr(), Cin, B, H, W, Cin, Cout, 0,
-               g.data_ptr(), split, g.data_ptr() + 4 * 64, 0, stream())
-        # launch 2 (Conv2DTranspose dgrad): ADDS to target B through its db2 and overwrites target C = g[128:152]
-        L.call("gct2_convT4s2_dgrad", ctx(), dt, dztd.data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dx2.data_ptr(), Cin, B, H, W, Cin, Cout, 0,
-               g.data_ptr() + 4 * 128, split, g.data_ptr() + 4 * 64, 2, stream())
-        args = None
-        if deferred:
-            if with_adam:
-                args = L.AdamArgs(p_.data_ptr(), m_.data_ptr(), v_.data_ptr(), None, 0, n, 1e-3, 0.9, 0.999, 1e-7, 1.0)
-                import ctypes
-                # target C is NOT listed: flushed to g, no optimizer step; a fourth range (200..208) was never a dgrad target:
-                # the optimizer takes the gradient the arena already holds there
-                ranges = (ctypes.c_int64 * 6)(0, split, 64, Cin - split, 200, 8)
-                L.call("gct2_rowsum_flush", ctx(), ctypes.addressof(args), g.data_ptr(), ranges, 3, stream())
-            else:
-                L.call("gct2_rowsum_flush", ctx(), None, None, None, 0, stream())
-        torch.cuda.synchronize()
-        return g, p_, m_, v_, dx1, dx2
-
-    try:
-        g_imm, *_ = run(False, False)
-        g_def, _, _, _, dx1, dx2 = run(True, False)
-        assert torch.equal(g_imm, g_def)
-        assert float(g_def[split:64].min()) == 5.0 and float(g_def[152:].min()) == 5.0           # nothing else is touched
-        ref1 = O.conv4s2_bwd(x, w, dz)[0] * (x > 0)
-        ref2 = O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)
-        cs1, cs2 = ref1.reshape(-1, Cin).sum(0), ref2.reshape(-1, Cin).sum(0)
-        scale = np.abs(ref1).reshape(-1, Cin).sum(0).max() + np.abs(ref2).reshape(-1, Cin).sum(0).max()
-        got = g_def.cpu().numpy()
-        assert np.abs(got[0:split] - cs1[:split]).max() <= 2e-3 * scale
-        assert np.abs(got[64:64 + Cin - split] - (cs1[split:] + cs2[split:])).max() <= 2e-3 * scale
-        assert np.abs(got[128:128 + split] - cs2[:split]).max() <= 2e-3 * scale
-        # the bias optimizer inside the flush == gct2_adam_keras_multi on the flushed gradients (masked to the targets)
-        g2, p2, m2, v2, *_ = run(True, True)
-        assert torch.equal(g2, g_def)
-        pr = torch.linspace(-1, 1, n, device=gpu); mr = torch.zeros(n, device=gpu); vr = torch.zeros(n, device=gpu)
-        gm = torch.zeros(n, device=gpu)
-        mask = torch.zeros(n, dtype=torch.bool, device=gpu)
-        for lo, cnt in ((0, split), (64, Cin - split), (200, 8)):
-            mask[lo:lo + cnt] = True
-        gm[mask] = g_def[mask]
-        L.call("gct2_adam_keras_multi", pr.data_ptr(), mr.data_ptr(), vr.data_ptr(), gm.data_ptr(), None, 0, n, 1e-3, 0.9, 0.999, 1e-7, 1.0, None, 0, stream())
-        torch.cuda.synchronize()
-        assert torch.equal(p2[mask], pr[mask]) and torch.equal(m2[mask], mr[mask]) and torch.equal(v2[mask], vr[mask])
-        assert torch.equal(p2[~mask], torch.linspace(-1, 1, n, device=gpu)[~mask])               # other parameters untouched
-        with pytest.raises(L.Gct2Error):
-            L.call("gct2_rowsum_flush", ctx(), None, None, None, 0, stream())                      # no deferral open any more
-    finally:
-        _CTX[0].set_rowsum_buffer(None)
-        set_ws(None)

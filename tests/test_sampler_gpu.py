@@ -193,7 +193,7 @@ def test_log_sample_graph_replay_equals_plain_launches(gpu):
     second = both()                                              # replays the graphs captured before the step
     assert not torch.equal(first["fake"], second["fake"])
     version = eng.ctx.version
-    eng.ctx.set_tuning(1)                                        # 128 x 128 single-buffer tiles for every layer
+    eng.ctx.set_tuning(2 | (1 << 24))                            # 128 x 128 tiles for every layer, no halo kernel
     assert eng.ctx.version != version
     third = both()
     assert all(k[1] == eng.ctx.version for k in eng._forward_graphs)
