@@ -28,6 +28,7 @@ struct gct2_ctx {
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
   int xcd_order = 0;                               // tile -> XCD order: 0 = automatic, 1 = m-tile bands, 2 = weight slices
   int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile: 0 = automatic, v: 2^(v-1)
+  int no_splitk = 0;                               // 1: forward / input-gradient GEMMs never split their reduction (tuning bit 8)
   int force_direct = 0;
   unsigned long long* stamps = nullptr; size_t stamps_bytes = 0;   // diagnostic builds only (gct2_ctx_set_stamp_buffer)
   // ReLU bit plane for the NEXT layer call (gct2_ctx_set_relu_bits): every layer entry point takes it out of the ctx first thing
@@ -43,6 +44,35 @@ struct gct2_ctx {
 };
 // appends "token;" to the launch log of the ctx when it is enabled (capi.hip)
 void gct2_log(gct2_ctx& c, const char* fmt, ...);
+
+#ifdef GCT2_STAMP
+// Diagnostic build only (make stamp / EXTRA=-DGCT2_STAMP; gct2_build_flags() says so and product hosts refuse the library).
+// In-kernel clock of a K loop (MI355X_MICROARCH.md, "DVFS give-back" item 6): s_memtime (shader cycles) and s_memrealtime (100 MHz)
+// stamped once in front of and once behind the loop; clock = d(memtime) / d(memrealtime) x 100 MHz.  Every wave writes its four
+// values to the CLOCK REGION of the stamp buffer: entry (work-group * waves + wave) at u64 offset GCT2_CLOCK_OFF, if the buffer is
+// at least GCT2_CLOCK_BYTES (8 MiB) long.  Nothing else reads that memory; no output depends on a stamp.
+constexpr size_t GCT2_CLOCK_OFF = (size_t)1 << 19, GCT2_CLOCK_ENTRIES = (size_t)1 << 17, GCT2_CLOCK_BYTES = (GCT2_CLOCK_OFF + 4 * GCT2_CLOCK_ENTRIES) * 8;
+struct ClockStamp { unsigned long long t0 = 0, r0 = 0, t1 = 0, r1 = 0; };
+__device__ __forceinline__ void clock_now(unsigned long long& t, unsigned long long& r) {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void clock_store(unsigned long long* stamps, const ClockStamp& c, int waves_per_group, int wave, int lane) {
+  const size_t e = (size_t)blockIdx.x * waves_per_group + wave;
+  if (stamps && lane == 0 && e < GCT2_CLOCK_ENTRIES) {
+    unsigned long long* o = stamps + GCT2_CLOCK_OFF + e * 4;
+    o[0] = c.t0; o[1] = c.r0; o[2] = c.t1; o[3] = c.r1;
+  }
+}
+#define GCT2_CLOCK_DECL ClockStamp clk_
+#define GCT2_CLOCK_BEGIN clock_now(clk_.t0, clk_.r0)
+#define GCT2_CLOCK_END(stamps, nwaves, wave, lane) do { clock_now(clk_.t1, clk_.r1); clock_store(stamps, clk_, nwaves, wave, lane); } while (0)
+#else
+#define GCT2_CLOCK_DECL
+#define GCT2_CLOCK_BEGIN
+#define GCT2_CLOCK_END(stamps, nwaves, wave, lane)
+#endif
 
 template <typename T> struct is16 { static constexpr bool value = sizeof(T) == 2; };
 
@@ -232,6 +262,7 @@ struct TapGemmParams {
                                          // pixel decode then uses shifts instead of four integer divisions per row
 #ifdef GCT2_STAMP
   unsigned long long* stamps = nullptr;  // diagnostic build: phase stamps of one wave per work-group (gct2_ctx_set_stamp_buffer)
+  int clock = 0;                         // ... and the buffer is long enough for the clock region (GCT2_CLOCK_OFF)
 #endif
 };
 inline int pow2_shift(int v) { return (v > 0 && !(v & (v - 1))) ? __builtin_ctz((unsigned)v) : -1; }
@@ -294,6 +325,7 @@ struct WgradParams {
   int ks = 0;                     // 0: the 4x4 / stride-2 layers; odd ks: 'same' stride-1 convolution (both tensors on one grid, ks*ks taps)
 #ifdef GCT2_STAMP
   unsigned long long* stamps = nullptr;   // diagnostic build: phase stamps of one wave per work-group (gct2_ctx_set_stamp_buffer)
+  int clock = 0;                          // ... and the buffer is long enough for the clock region (GCT2_CLOCK_OFF)
 #endif
 };
 // wgrad_mfma(): when `defer` is non-null and the launch left its result as workspace slabs, the slab reduction is NOT launched and

@@ -197,6 +197,8 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
     }
   };
   // ---- main loop: 8 rounds (two k-chunks) per trip so that every buffer role is a compile-time constant --------------
+  GCT2_CLOCK_DECL;
+  GCT2_CLOCK_BEGIN;
   issue_halo(0, halo0);
   issue_w(0, wb0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -224,6 +226,9 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   }
 #undef GCT2_LEAN_TRIP
 #undef GCT2_LEAN_ROUND
+#ifdef GCT2_STAMP
+  GCT2_CLOCK_END(p.clock ? p.stamps : nullptr, 8, wave, lane);
+#endif
 
   // ---- epilogue: lane holds out[pixel (row mhalf*8 + j, col q)][n = n0 + 32 (i>>1) + 8 g + 4 (i&1) + r], phase (ph, pw) ----
   // EPI_BIAS_ACT: bias + ReLU (Conv2DTranspose forward).  EPI_MASK: ReLU mask of the tensor the gradient belongs to, optional
@@ -562,6 +567,7 @@ int halo_head(gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, flo
   p.head.part = c.ws;
 #ifdef GCT2_STAMP
   p.stamps = c.stamps;
+  p.clock = c.stamps_bytes >= GCT2_CLOCK_BYTES ? 1 : 0;
 #endif
   dim3 grid(8 * p.xcd_chunk);
   gct2_log(c, "halo:convT:head");
@@ -583,6 +589,10 @@ int halo_convT(gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) 
     if (c.ws && c.ws_bytes >= need + 16) p.dbws = c.ws + (c.ws_bytes - need) / sizeof(float) / 4 * 4;
     if (!p.dbws) zero_overwritten_db(p, s);
   }
+#ifdef GCT2_STAMP
+  p.stamps = c.stamps;
+  p.clock = c.stamps_bytes >= GCT2_CLOCK_BYTES ? 1 : 0;
+#endif
   dim3 grid(8 * p.xcd_chunk * p.n_tiles);
   gct2_log(c, "halo:convT:%s%s", epi == EPI_BIAS_ACT ? "bias_act" : "mask", p.bits ? ":bits" : "");
   if (epi == EPI_BIAS_ACT) {

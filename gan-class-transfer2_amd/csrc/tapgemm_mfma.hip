@@ -298,6 +298,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
   // spilled registers, 10x slower; here: the 256 x 256 and three-buffer variants); behind the guard each step stays its own region.
   const bool live = p.ksplit > 0;
   TG_STAMP(1);
+  GCT2_CLOCK_DECL;
+  GCT2_CLOCK_BEGIN;
   if constexpr (NBUF == 1) {
     // one LDS buffer (32 KiB): no overlap inside a work-group; 4 work-groups per CU cover each other instead
     for (int it = it_lo; it < it_hi; it++) {
@@ -324,6 +326,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
     }
   }
 
+#ifdef GCT2_STAMP
+  GCT2_CLOCK_END(p.clock ? p.stamps : nullptr, NWV, wave, lane);
+#endif
   TG_STAMP(2);
   // ---- epilogue: lane holds out[m = .. + (lane&15)][n = .. + 4*(lane>>4) + r], r = 0..3 ----
   T* __restrict__ yout = reinterpret_cast<T*>(p.y);
@@ -666,6 +671,7 @@ int launch(gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   const bool want_db = EPI == EPI_MASK && (p.db || p.db2);
 #ifdef GCT2_STAMP
   p.stamps = c.stamps;
+  p.clock = c.stamps_bytes >= GCT2_CLOCK_BYTES ? 1 : 0;
 #endif
   // fused bias gradient: partial rows at the tail of the workspace (one per (m-tile, phase), or per finalize work-group)
   const size_t fin_rows = (npix + 7) / 8;
@@ -673,7 +679,7 @@ int launch(gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   const bool db_rows = want_db && ws && ws_bytes >= dbws_bytes + 16;
   const size_t slab_room = db_rows ? ws_bytes - dbws_bytes - 16 : ws_bytes;
   // (below ~1.2 work-groups per CU a second k-slice per tile beats the idle half of the chip: U_3 dgrad 102 -> 77 us)
-  if (ws && tiles < 300 && niter >= 4 * BK / BKS) {
+  if (ws && !c.no_splitk && tiles < 300 && niter >= 4 * BK / BKS) {
     int want = (512 + tiles - 1) / tiles;
     const size_t slab = npix * p.N * sizeof(float);
     want = (int)std::min<size_t>((size_t)want, slab_room / slab);
@@ -767,7 +773,8 @@ int tapgemm_mfma(gct2_ctx& c, int dtype, int form, int epi, const TapGemmParams&
     if (dtype == GCT2_BF16) return dispatch<__bf16>(c, form, epi, p, s);
     return dispatch<_Float16>(c, form, epi, p, s);
   }
-  if (form == FORM_CONVT && c.tap_variant == 0 && halo_convT_wanted(c, epi, p)) return halo_convT(c, dtype, epi, p, s);
+  // (a forced tile keeps the halo kernel out, unless the halo kernel is forced too: halo mode 2)
+  if (form == FORM_CONVT && (c.tap_variant == 0 || c.halo_mode == 2) && halo_convT_wanted(c, epi, p)) return halo_convT(c, dtype, epi, p, s);
   if (dtype == GCT2_BF16) return dispatch<__bf16>(c, form, epi, p, s);
   return dispatch<_Float16>(c, form, epi, p, s);
 }

@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     }
   };
 
+  GCT2_CLOCK_DECL;
+  GCT2_CLOCK_BEGIN;
   {
     issue(step_lo, lds0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -147,6 +149,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     }
   }
 
+#ifdef GCT2_STAMP
+  GCT2_CLOCK_END(p.clock ? p.stamps : nullptr, 4, wave, lane);
+#endif
   // MFMA operand order A = small (cs), B = big (gc): lane holds dW[gc = .. + (lane&15)][cs = .. + 4*(lane>>4) + r], i.e. four
   // consecutive columns of one row -> 16-byte stores (the other order costs four times the store instructions: -7..-24 %)
   //   rsplit == 1        : the tile has one owner -> plain read-add-write (no atomic unit, reproducible)
@@ -331,6 +336,8 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
     else wait_tail(st_hi - 1 - (st + 1));
     __builtin_amdgcn_s_barrier();
   };
+  GCT2_CLOCK_DECL;
+  GCT2_CLOCK_BEGIN;
   issue(lds);
   if (st_lo + 1 < st_hi) issue(lds + STAGE);
   if (st_lo + 2 < st_hi) issue(lds + 2 * STAGE);
@@ -363,6 +370,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
     if (st + 4 >= st_hi) break;
     stage(st + 4, lds + 4 * STAGE, lds + 3 * STAGE);
   }
+#ifdef GCT2_STAMP
+  GCT2_CLOCK_END(p.clock ? p.stamps : nullptr, 8, wave, lane);
+#endif
   float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
   int elane = lane;
@@ -483,6 +493,7 @@ int wgrad_mfma(gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs*
   p.ws = nullptr;
 #ifdef GCT2_STAMP
   p.stamps = c.stamps;
+  p.clock = c.stamps_bytes >= GCT2_CLOCK_BYTES ? 1 : 0;
 #endif
   const size_t n = (size_t)taps * p.Cb * p.Cs;
   size_t ws_bytes = 0;

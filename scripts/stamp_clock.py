@@ -1,0 +1,123 @@
+"""in-kernel clock of the K loops of the kernels that ship (diagnostic build only: `make -C gan-class-transfer2_amd/csrc stamp`).
+
+MI355X_MICROARCH.md, "DVFS give-back" item 6: clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, stamped once in front of and once
+behind the loop after >= 2 s of back-to-back launches on random data, median over the waves.  The launches are the ENGINE'S OWN
+(config 3: its strides, planes, fused bias sums, automatic dispatch), recorded from one train step and replayed - as in
+scripts/engine_layers.py.
+
+    python scripts/stamp_clock.py [--seconds 2.0] [--layers U0.wgrad,U1.fwd,...]
+prints per layer: kernel (launch log), in-kernel clock (median, p10, p90 over waves), K-loop time per work-group, MFMA rate inside
+the loop, and the whole launch for comparison.
+"""
+import argparse, os, sys
+os.environ["GCT2_ALLOW_DIAGNOSTIC_BUILD"] = "1"
+os.environ["GCT2_USE_STAMP_LIB"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import gan_class_transfer2_amd as g
+from gan_class_transfer2_amd import _lib, engine as engine_mod
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=2.0)
+ap.add_argument("--layers", default="U0.wgrad,U1.wgrad,D1.wgrad,U1.fwd,U2.fwd,D1.dgrad,D2.dgrad,U0.dgrad,U1.dgrad,U2.dgrad,D1.fwd,D2.fwd,U3.fwd,U3.dgrad,D3.dgrad,U3.wgrad")
+args = ap.parse_args()
+assert _lib.build_flags() & _lib.BUILD_STAMP, "needs the diagnostic build: make -C gan-class-transfer2_amd/csrc stamp"
+
+dev = torch.device("cuda", 0)
+B, S = 64, 128
+eng = g.UNetEngine(g.Topology(128, 512, 6), g.BF16, dev)
+eng.overlap = False
+x = (torch.randint(0, 256, (B, S, S, 3)).float() / 128 - 1).to(dev)
+for _ in range(2):
+    eng.train_step(x, apply=False)                 # random data everywhere: activations and gradients of a real step
+torch.cuda.synchronize()
+rec, orig = [], _lib.call
+
+
+def recorder(name, *a):
+    rec.append((name, a))
+    return orig(name, *a)
+
+
+_lib.call = engine_mod.call = recorder
+eng.train_step(x, apply=False)
+_lib.call = engine_mod.call = orig
+torch.cuda.synchronize()
+
+LAYER = {"gct2_conv4s2_fwd": ("D", "fwd", 9, 0), "gct2_convT4s2_fwd": ("U", "fwd", 9, 1), "gct2_conv4s2_dgrad": ("D", "dgrad", 10, 0),
+         "gct2_convT4s2_dgrad": ("U", "dgrad", 10, 1), "gct2_conv4s2_wgrad": ("D", "wgrad", 9, 0), "gct2_convT4s2_wgrad": ("U", "wgrad", 9, 1),
+         "gct2_convT4s2_fwd_head_train": ("U", "fwd", 16, 1)}
+
+
+def label(name, a):
+    kind, what, hpos, small = LAYER[name]
+    H = a[hpos] * (2 if small else 1)              # the layer's big-grid height
+    return f"{kind}{(S // H).bit_length() - 1}.{what}"
+
+
+def flops(name, a):
+    if name == "gct2_convT4s2_fwd_head_train":
+        Bn, H, W, Cin, Cout = a[15:20]
+        return 2.0 * Bn * 4 * H * W * Cout * 4 * Cin
+    off = 9 if "dgrad" in name else 8
+    Bn, H, W, Cin, Cout = a[off:off + 5]
+    return 2.0 * Bn * H * W * Cout * (16 * Cin if name.startswith("gct2_convT") else 4 * Cin)   # conv: (H/2)(W/2) * 16 Cin = H W 4 Cin; convT: H, W = the small grid
+
+
+calls, pending = {}, None
+for name, a in rec:
+    if name == "gct2_ctx_set_relu_bits":
+        pending = a
+    elif name in LAYER:
+        calls[label(name, a)] = (name, a, pending)
+        pending = None
+
+stamps = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+OFF = 1 << 19
+print(f"# in-kernel clock of the K loops, config 3 (3x128x128, batch 64, bf16), >= {args.seconds} s of back-to-back launches before the stamped one")
+print("# layer       kernel                                      clock GHz (median p10 p90)   K loop us/work-group   PFLOP/s in loop   launch us")
+for lab in [s for s in args.layers.split(",") if s]:
+    if lab not in calls:
+        print(f"{lab:12s} (no such call)")
+        continue
+    name, a, plane = calls[lab]
+
+    def launch():
+        if plane is not None:
+            orig("gct2_ctx_set_relu_bits", *plane)
+        orig(name, *a)
+
+    eng.ctx.set_stamp_buffer(None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n, t = 0, 0.0
+    while t < args.seconds:                        # back-to-back: the chip settles at the clock this kernel sustains
+        e0.record()
+        for _ in range(200):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        t += e0.elapsed_time(e1) * 1e-3
+        n += 200
+    us_launch = t / n * 1e6
+    stamps.zero_()
+    eng.ctx.set_stamp_buffer(stamps)
+    eng.ctx.log_launches(True)
+    for _ in range(8):                             # no gap in front of the stamped launch either: the last of these is read
+        launch()
+    torch.cuda.synchronize()
+    kern = [k for k in eng.ctx.read_launch_log() if not k.startswith("relu_bits")][-1]
+    eng.ctx.log_launches(False)
+    eng.ctx.set_stamp_buffer(None)
+    c = stamps[OFF:].cpu().numpy().reshape(-1, 4)
+    c = c[(c[:, 1] != 0) & (c[:, 3] > c[:, 1])]
+    clk = (c[:, 2] - c[:, 0]) / (c[:, 3] - c[:, 1]) * 0.1          # cycles per 10 ns -> GHz
+    loop_us = (c[:, 3] - c[:, 1]) / 100.0
+    nwaves = len(c)
+    # MFMA rate inside the loop: the launch's FLOPs, spread over the waves that ran, per median loop time, times the waves resident at once
+    fl = flops(name, a)
+    per_wave = fl / nwaves
+    resident = min(nwaves, 256 * 16 if "256x128" in kern else 256 * 8)     # waves resident at once: two 8-wave groups per CU, else 8 waves per CU
+    rate = per_wave / (np.median(loop_us) * 1e-6) * resident / 1e15
+    print(f"{lab:12s} {kern:42s}  {np.median(clk):5.3f} {np.percentile(clk, 10):5.3f} {np.percentile(clk, 90):5.3f}      "
+          f"{np.median(loop_us):8.2f} ({nwaves} waves)   {rate:6.3f}           {us_launch:7.1f}")
