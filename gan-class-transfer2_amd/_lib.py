@@ -33,7 +33,7 @@ class AdamArgs(C.Structure):
     """gct2_adam_args (include/gct2.h): the optimizer step fused behind a weight-gradient call."""
     _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("shadow", C.c_void_p), ("shadow_dtype", C.c_int),
                 ("n", C.c_size_t), ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("grad_mul", C.c_float)]
+                ("grad_mul", C.c_float), ("defer", C.c_int), ("slab_base", C.c_void_p), ("nslab", C.c_int), ("slab_stride", C.c_size_t)]
 
 
 _vp, _i, _f, _d, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_uint64, C.c_size_t
@@ -60,6 +60,7 @@ SIGNATURES = {
     "gct2_conv4s2_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_conv4s2_dgrad": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp],
     "gct2_conv4s2_wgrad": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "gct2_adam_apply": [_vp, _vp, _sz, _vp],
     "gct2_convT4s2_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gct2_convT4s2_fwd_head_train": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
                                      _vp, _vp, _vp, _i, _i, _vp],
@@ -148,6 +149,7 @@ class Context:
         # bumped by every setter: whoever caches something that bakes in this context's pointers or tile choices (the sampler's
         # HIP graphs of the forward pass) keys its cache on it
         self.version = 0
+        self.tuning = 0
 
     def set_relu_bits(self, ptr, ld_bytes: int) -> None:
         """ReLU bit plane for the NEXT forward (written) / input-gradient (read instead of act) call of this context; one-shot.
@@ -185,6 +187,7 @@ class Context:
 
     def set_tuning(self, v: int) -> None:
         self.version += 1
+        self.tuning = int(v)
         call("gct2_ctx_set_tuning", self.handle, int(v))
 
     def force_direct(self, on: bool) -> None:

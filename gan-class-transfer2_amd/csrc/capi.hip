@@ -162,7 +162,11 @@ int check_adam_args(const gct2_adam_args* a, const float* dw, size_t nw) {
     return gct2_fail(GCT2_EINVAL, "wgrad + adam: range shorter than the weight tensor or misaligned");
   return GCT2_OK;
 }
-int adam_after_wgrad(const gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& sl, void* stream) {
+int adam_after_wgrad(gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& sl, void* stream) {
+  if (a->defer) {      // the caller runs the step later (gct2_adam_apply): tell it where the kernel gradient is
+    a->slab_base = sl.base; a->nslab = sl.nslab; a->slab_stride = sl.stride;
+    return GCT2_OK;
+  }
   return pw_adam(a->p, a->m, a->v, dw, a->shadow, a->shadow_dtype, a->n, a->alpha, a->beta1, a->beta2, a->eps, a->grad_mul, nullptr, 0,
                  S(stream), sl.base, sl.nslab, sl.stride, sl.nslab ? nw : 0);
 }
@@ -298,7 +302,7 @@ int gct2_conv4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const
 }
 
 int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
-                       int Cin, int Cout, int accumulate, const gct2_adam_args* adam, void* stream) {
+                       int Cin, int Cout, int accumulate, gct2_adam_args* adam, void* stream) {
   gct2_ctx& c = C(ctx);
   if (int e = PlaneTaken(c).none("conv4s2_wgrad")) return e;
   if (int e = check_conv_args("conv4s2_wgrad", dtype, x, dz, dw, B, H, W, Cin, Cout)) return e;
@@ -365,7 +369,7 @@ int gct2_convT4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, cons
 }
 
 int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw, float* db, int B, int H, int W,
-                        int Cin, int Cout, int accumulate, const gct2_adam_args* adam, void* stream) {
+                        int Cin, int Cout, int accumulate, gct2_adam_args* adam, void* stream) {
   gct2_ctx& c = C(ctx);
   if (int e = PlaneTaken(c).none("convT4s2_wgrad")) return e;
   if (int e = check_conv_args("convT4s2_wgrad", dtype, x, dz, dw, B, 2 * H, 2 * W, Cin, Cout)) return e;
@@ -552,6 +556,14 @@ int gct2_adam_keras_multi(float* p, float* m, float* v, float* g, void* shadow, 
   if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) % 16 || (shadow && (uintptr_t)shadow % 8))
     return gct2_fail(GCT2_EINVAL, "adam_keras_multi: arenas must be 16-byte aligned");
   return pw_adam(p, m, v, g, shadow, shadow_dtype, n, alpha, beta1, beta2, eps, grad_mul, ls, zero_grad, S(stream));
+}
+
+int gct2_adam_apply(const gct2_adam_args* a, float* dw, size_t nw, void* stream) {
+  if (!a || !dw) return gct2_fail(GCT2_EINVAL, "adam_apply: null pointer");
+  if (int e = check_adam_args(a, dw, nw)) return e;
+  if (a->nslab < 0 || (a->nslab > 0 && (!a->slab_base || a->slab_stride < nw))) return gct2_fail(GCT2_EINVAL, "adam_apply: bad slab description");
+  return pw_adam(a->p, a->m, a->v, dw, a->shadow, a->shadow_dtype, a->n, a->alpha, a->beta1, a->beta2, a->eps, a->grad_mul, nullptr, 0,
+                 S(stream), a->slab_base, a->nslab, a->slab_stride, a->nslab ? nw : 0);
 }
 
 int gct2_cast_from_f32(int dtype, const float* src, void* dst, size_t n, void* stream) {

@@ -94,8 +94,31 @@ class ParamArena:
         self.layer_ranges[layer] = (self.layer_ranges[layer][0], off)
         self.total = off
         z = lambda dt: torch.zeros(self.total, dtype=dt, device=device)
-        self.p, self.m, self.v, self.g = z(torch.float32), z(torch.float32), z(torch.float32), z(torch.float32)
-        self.shadow = z(TORCH_DTYPE[dtype]) if dtype != F32 else None
+        self._p, self._m, self._v, self.g = z(torch.float32), z(torch.float32), z(torch.float32), z(torch.float32)
+        self._shadow = z(TORCH_DTYPE[dtype]) if dtype != F32 else None
+        # the engine may hold optimizer launches back (UNetEngine.defer_adam: the Adam step of the layers the forward pass needs last
+        # runs inside the NEXT forward pass): whoever looks at p / m / v / shadow through these properties gets them flushed first
+        self.before_read: Optional[Callable[[], None]] = None
+
+    def _sync(self) -> None:
+        if self.before_read is not None:
+            self.before_read()
+
+    @property
+    def p(self) -> torch.Tensor:
+        self._sync(); return self._p
+
+    @property
+    def m(self) -> torch.Tensor:
+        self._sync(); return self._m
+
+    @property
+    def v(self) -> torch.Tensor:
+        self._sync(); return self._v
+
+    @property
+    def shadow(self) -> Optional[torch.Tensor]:
+        self._sync(); return self._shadow
 
     def numel(self, name: str) -> int:
         return int(np.prod(self.shapes[name]))
@@ -111,20 +134,20 @@ class ParamArena:
 
     def wptr(self, name: str) -> int:
         """device pointer of the compute-dtype operand copy of a weight."""
-        o = self.offsets[name]
-        if self.shadow is None:
-            return self.p.data_ptr() + 4 * o
-        return self.shadow.data_ptr() + 2 * o
+        o = self.offsets[name]                    # (raw storage: the engine orders its own launches against pending updates)
+        if self._shadow is None:
+            return self._p.data_ptr() + 4 * o
+        return self._shadow.data_ptr() + 2 * o
 
     def pptr(self, name: str) -> int:
-        return self.p.data_ptr() + 4 * self.offsets[name]
+        return self._p.data_ptr() + 4 * self.offsets[name]
 
     def gptr(self, name: str) -> int:
         return self.g.data_ptr() + 4 * self.offsets[name]
 
     def refresh_shadow(self, stream: int) -> None:
         if self.shadow is not None:
-            call("gct2_cast_from_f32", self.dtype, self.p.data_ptr(), self.shadow.data_ptr(), self.total, stream)
+            call("gct2_cast_from_f32", self.dtype, self._p.data_ptr(), self._shadow.data_ptr(), self.total, stream)
 
     def glorot_init(self, seed: int = 1234) -> None:
         """Keras glorot_uniform kernels, zero biases (train.py:134,149,162)."""
@@ -210,6 +233,21 @@ class UNetEngine:
         self.tail_on_chain = True
         self.ctx_tail = _lib.Context()
         self.ctx_tail.set_workspace(self.workspace)
+        # deferred optimizer steps (r04): in the fused single-replica step the Adam launches of the layers the forward pass needs LAST
+        # (the head and the outer UpShuffle levels: 5.5 M of the 41.7 M parameters, but three of the six 64-MiB slab sets) are not run
+        # behind their weight gradients - beside other full-chip GEMMs, where HBM-bound work costs its full duration - but inside the
+        # NEXT forward pass's bottleneck window (DownShuffle_3 .. UpShuffle_3: latency-bound launches that leave the memory system
+        # idle), on the side stream, finished before UpShuffle_2 reads its weights.  Same launches, same bits; everything that looks at
+        # the parameters (arena properties, state_dict, predict, the sampler) flushes them first.  The slabs of a deferred layer must
+        # outlive the step: such layers get a call context of their own (_defer_ctx) whose weight-gradient scratch nobody else uses.
+        self.defer_adam = True
+        self.defer_layers = ("dense", "U0", "U1", "U2")
+        self._pending: list = []
+        self._pending_event = None
+        self._pending_names: set = set()
+        self._defer_ctxs: Dict[str, "_lib.Context"] = {}
+        self._defer_ws: Dict[str, torch.Tensor] = {}
+        self.arena.before_read = self.flush_deferred
         self.ls_state = None
         if loss_scaling:
             self.enable_loss_scaling()
@@ -247,6 +285,40 @@ class UNetEngine:
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---- deferred optimizer steps ------------------------------------------------------------------------------------------
+    def _defer_ctx(self, layer: str) -> "_lib.Context":
+        c = self._defer_ctxs.get(layer)
+        if c is None:
+            c = self._defer_ctxs[layer] = _lib.Context()
+            self._defer_ws[layer] = torch.empty_like(self.wgrad_workspace)
+            c.set_wgrad_workspace(self._defer_ws[layer])
+        return c
+
+    def _launch_pending(self, stream: int) -> None:
+        """the optimizer launches held back by the last step, in the order the fused step would have run them"""
+        A = self.arena
+        for item in self._pending:
+            if item[0] == "range":
+                _, lo, hi, alpha = item
+                shadow = None if A._shadow is None else A._shadow.data_ptr() + 2 * lo
+                call("gct2_adam_keras_multi", A._p.data_ptr() + 4 * lo, A._m.data_ptr() + 4 * lo, A._v.data_ptr() + 4 * lo,
+                     A.g.data_ptr() + 4 * lo, shadow, self.dtype, hi - lo, alpha, self.beta_1, self.beta_2, self.epsilon, 1.0, None, 0, stream)
+            else:
+                _, layer, args = item
+                call("gct2_adam_apply", ctypes.addressof(args), A.gptr(layer + ".w"), A.numel(layer + ".w"), stream)
+        self._pending = []
+
+    def flush_deferred(self) -> None:
+        """run whatever optimizer launches the last train step held back, on the current stream (no-op when nothing is pending).
+        Called by everything that reads or overwrites parameters outside the train step itself."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._pending:
+            self._launch_pending(cur.cuda_stream)
+        if self._pending_event is not None:
+            cur.wait_event(self._pending_event)
+            self._pending_event = None
+        self._pending_names = set()
 
     def check_input_shape(self, H: int, W: int) -> None:
         n = self.topo.octaves
@@ -368,7 +440,7 @@ class UNetEngine:
         b.R[0][..., t.fu(0):t.fu(0) + 3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
         b.img[..., :3].copy_(noised.to(TORCH_DTYPE[self.dtype]))
 
-    def forward(self, b: _Buffers, head: bool = True, stop_before_u0: bool = False, planes: bool = False) -> torch.Tensor:
+    def forward(self, b: _Buffers, head: bool = True, stop_before_u0: bool = False, planes: bool = False, in_step: bool = False) -> torch.Tensor:
         """Denoiser.call (train.py:206-215): R_0's image slice must already hold the network input.
         head=False stops before Dense(3) (the train step runs the fused head kernel instead); stop_before_u0 also leaves
         UpShuffle_0 to the caller (u0_head_train: its forward carries the head in its epilogue); planes: also write the ReLU bit
@@ -376,6 +448,16 @@ class UNetEngine:
         t, n, s, dt, A, cx = self.topo, self.topo.octaves, self._stream(), self.dtype, self.arena, self.ctx.handle
         planes = planes and self.relu_bits
         b.bits_valid = planes
+        if not in_step:
+            self.flush_deferred()                              # (a captured graph, the sampler, predict: no side-stream work in here)
+        cur = torch.cuda.current_stream(self.device)
+        window_at = min(3, n - 1)                               # deferred Adam starts once DownShuffle_{window_at} is enqueued
+
+        def join_pending() -> None:                             # the deferred updates are done before their weights are read
+            if self._pending_event is not None:
+                cur.wait_event(self._pending_event)
+                self._pending_event = None
+                self._pending_names = set()
 
         def plane(level: int, ch: int) -> None:                 # one-shot: applies to the layer call that follows
             if planes and b.bits[level] is not None:
@@ -390,18 +472,28 @@ class UNetEngine:
             if i < n - 1:
                 plane(i + 1, t.fu(i + 1))
             call("gct2_conv4s2_fwd", cx, dt, x, ldx, A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"), y, ldy, b.B, H, W, t.cx(i), t.fd(i), 1, s)
+            if i == window_at and self._pending:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                self._side.wait_event(ev)
+                self._launch_pending(self._side.cuda_stream)
+                self._pending_event = torch.cuda.Event()
+                self._pending_event.record(self._side)
         for i in reversed(range(n)):                            # UpShuffle_i    (train.py:188)
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
                 x, ldx = b.R[i + 1].data_ptr(), b.ld[i + 1]
             else:
                 x, ldx = b.Dlast.data_ptr(), t.fd(i)
+            if f"U{i}" in self._pending_names or i == 0:
+                join_pending()
             if i == 0 and stop_before_u0:
                 return b.pred
             if i >= 1:
                 plane(i, 0)
             call("gct2_convT4s2_fwd", cx, dt, x, ldx, A.wptr(f"U{i}.w"), A.pptr(f"U{i}.b"), b.R[i].data_ptr(), b.ld[i],
                  b.B, Hi, Wi, t.up_in(i), t.fu(i), 1, s)
+        join_pending()
         if not head:
             return b.pred
         M = b.B * b.H * b.W                                     # Dense(3)       (train.py:198-202)
@@ -535,20 +627,41 @@ class UNetEngine:
         # the kernel is consumed from the launch's partial sums or from the arena without ever being zeroed.  The update writes
         # the layer's operand copy, so it must follow the layer's dgrad (the last reader): in that mode the dgrad is enqueued
         # first and the side stream waits for it - the weight gradient of layer L then runs beside the dgrad of layer L+1.
+        # the optimizer steps of defer_layers are held back until the next forward pass (see __init__)
+        deferred = set(self.defer_layers) if (adam_inline and self.defer_adam and side is not main and self.wgrad_workspace is not None) else set()
+        if self._pending:                                       # (a reverse pass without a forward pass in front of it: scripts, tests)
+            self.flush_deferred()
+
         def fused(layer: str):
             if not adam_inline:
                 return None
             lo, hi = A.layer_ranges[layer]
-            args = _lib.AdamArgs(A.p.data_ptr() + 4 * lo, A.m.data_ptr() + 4 * lo, A.v.data_ptr() + 4 * lo,
-                                 (A.shadow.data_ptr() + 2 * lo) if A.shadow is not None else None, self.dtype, hi - lo,
+            args = _lib.AdamArgs(A._p.data_ptr() + 4 * lo, A._m.data_ptr() + 4 * lo, A._v.data_ptr() + 4 * lo,
+                                 (A._shadow.data_ptr() + 2 * lo) if A._shadow is not None else None, self.dtype, hi - lo,
                                  self.adam_alpha(), self.beta_1, self.beta_2, self.epsilon, 1.0)
+            if layer in deferred:
+                args.defer = 1
+                self._pending.append(("layer", layer, args))
+                self._pending_names.add(layer)
             keep.append(args)
             return ctypes.addressof(args)
+
+        def wctx(layer: str) -> int:                            # a deferred layer's slabs must outlive the step: its own scratch
+            if layer not in deferred:
+                return cx
+            c = self._defer_ctx(layer)
+            if c.tuning != self.ctx.tuning:
+                c.set_tuning(self.ctx.tuning)
+            return c.handle
 
         keep: list = []
         if adam_inline:
             side_waits_main()                                   # the head (and its gradients) are done
-            self.apply_adam(0, A.layer_ranges["dense"][1], stream=sw)   # the head's parameters: nothing reads them any more
+            if "dense" in deferred:
+                self._pending.append(("range", 0, A.layer_ranges["dense"][1], self.adam_alpha()))
+                self._pending_names.add("dense")
+            else:
+                self._apply_adam(0, A.layer_ranges["dense"][1], stream=sw)   # the head's parameters: nothing reads them any more
         for i in range(n):                                      # UpShuffle_i backward, outermost first
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
@@ -575,7 +688,7 @@ class UNetEngine:
             if adam_inline:
                 dgrad_u()
             side_waits_main()                                   # dz (and this layer's bias gradient) are complete
-            call("gct2_convT4s2_wgrad", cx, dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), 0,
+            call("gct2_convT4s2_wgrad", wctx(f"U{i}"), dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), 0,
                  fused(f"U{i}"), sw)
             with torch.cuda.stream(side):
                 self._ready(f"U{i}")
@@ -636,14 +749,18 @@ class UNetEngine:
     def apply_adam(self, lo: int = 0, hi: Optional[int] = None, grad_div: float = 1.0, stream: Optional[int] = None) -> None:
         """Keras Adam on arena range [lo, hi); does not advance `iterations` (see finish_step).
         grad_div > 1 folds the data-parallel mean (sum over ranks / world size) into the gradient read."""
+        self.flush_deferred()
+        self._apply_adam(lo, hi, grad_div, stream)
+
+    def _apply_adam(self, lo: int = 0, hi: Optional[int] = None, grad_div: float = 1.0, stream: Optional[int] = None) -> None:
         A, s = self.arena, (self._stream() if stream is None else stream)
         hi = A.total if hi is None else hi
         # with loss scaling the kernel takes inv_scale / found_inf / alpha from the device-resident state (the step counter that
         # alpha depends on only advances on applied steps); otherwise alpha comes from the host's counter
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
         alpha = 0.0 if self.ls_state is not None else self.adam_alpha()
-        shadow = None if A.shadow is None else A.shadow.data_ptr() + 2 * lo
-        call("gct2_adam_keras_multi", A.p.data_ptr() + 4 * lo, A.m.data_ptr() + 4 * lo, A.v.data_ptr() + 4 * lo,
+        shadow = None if A._shadow is None else A._shadow.data_ptr() + 2 * lo
+        call("gct2_adam_keras_multi", A._p.data_ptr() + 4 * lo, A._m.data_ptr() + 4 * lo, A._v.data_ptr() + 4 * lo,
              A.g.data_ptr() + 4 * lo, shadow, self.dtype, hi - lo, alpha, self.beta_1, self.beta_2,
              self.epsilon, 1.0 / grad_div, ls_ptr, 0, s)
 
@@ -675,6 +792,9 @@ class UNetEngine:
             x = x.to(self.device, torch.float32).contiguous()
         B, H, W, _ = x.shape
         b = self.buffers(B, H, W)
+        inline = apply and self.fuse_adam and self.ls_state is None
+        if not inline:
+            self.flush_deferred()                              # (a fused step schedules them inside its forward pass instead)
         self.begin_step()
         default_obj = self.default_objective()
         if t_int is None and eps is None:
@@ -692,17 +812,17 @@ class UNetEngine:
         weighted = self.objective_weighted()
         fused = self.fused_head_ok()
         if fused and self.fused_u0_head_ok(b):
-            self.forward(b, head=False, stop_before_u0=True, planes=True)
+            self.forward(b, head=False, stop_before_u0=True, planes=True, in_step=True)
             loss = self.u0_head_train(b, target)
         else:
-            self.forward(b, head=not fused, planes=True)
+            self.forward(b, head=not fused, planes=True, in_step=True)
             if weighted:
                 loss = self.weighted_loss_and_dpred(b, target, w)
             else:
                 loss = self.head_train(b, target) if fused else self.loss_and_dpred(b, target)
         # single GPU without loss scaling: Adam rides the side stream inside backward(); the loss-scaled step has to see
         # every gradient (finite check) before any update
-        inline = apply and self.fuse_adam and self.ls_state is None
+        self.flush_deferred()                                  # (no-op after a forward pass that scheduled them; covers octaves < 4 corner cases)
         self.backward(b, head_done=fused, adam_inline=inline)
         self._grads_in_arena = not inline
         if apply:

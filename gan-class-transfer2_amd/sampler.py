@@ -85,6 +85,7 @@ class _Sampler:
         if not self.planned:
             return eng.predict(self._inputs[B])
         b = eng.buffers(B, self.H, self.W)
+        eng.flush_deferred()                     # optimizer launches the last train step held back: never inside a captured graph
         if not self.use_graph:
             eng.forward(b)
             return b.pred

@@ -134,6 +134,14 @@ typedef struct gct2_adam_args {
   void* shadow; int shadow_dtype;      /* compute-dtype copy of p over the same range, or NULL */
   size_t n;
   float alpha, beta1, beta2, eps, grad_mul;
+  /* defer != 0 (r04): the weight-gradient call launches NO optimizer step; it records where it left the kernel gradient - slab_base
+   * / nslab / slab_stride: `nslab` partial tensors in the ctx's weight-gradient scratch (nslab = 0: the gradient is in dw) - and the
+   * caller runs the step later with gct2_adam_apply(this struct, dw, 16*Cin*Cout, stream): the same launch, the same bits.  Until
+   * then the scratch of that ctx must not be handed to another weight-gradient call (the engine gives such layers a ctx of their
+   * own) and dw / the bias gradients behind it must stay untouched.  The engine uses it to run the optimizer step of the layers the
+   * forward pass needs LAST inside the bottleneck window of the next forward pass. */
+  int defer;
+  const float* slab_base; int nslab; size_t slab_stride;     /* out (defer != 0) */
 } gct2_adam_args;
 
 /* weight + bias gradient: dw[kh,kw,i,o] += sum_{b,oh,ow} x[b,2oh+kh-1,2ow+kw-1,i]*dz[b,oh,ow,o],
@@ -141,7 +149,9 @@ typedef struct gct2_adam_args {
  * zeroed) buffer and is added to; accumulate == 0: dw is overwritten (saves reading it).  db follows the same flag. */
 int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
                        float* db, int B, int H, int W, int Cin, int Cout, int accumulate,
-                       const gct2_adam_args* adam /* or NULL */, void* stream);
+                       gct2_adam_args* adam /* or NULL */, void* stream);
+/* the optimizer step a weight-gradient call with adam->defer != 0 left to the caller (see gct2_adam_args) */
+int gct2_adam_apply(const gct2_adam_args* adam, float* dw, size_t nw, void* stream);
 
 /* ---- UpShuffle = Conv2DTranspose(f, 4, 2, 'same', relu)   train.py:145-156 ------------------ */
 /* y[b,2ih+kh-1,2iw+kw-1,o] += x[b,ih,iw,i] * w[kh,kw,o,i]; then bias, relu.
@@ -160,7 +170,7 @@ int gct2_convT4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, cons
  * conv4s2_wgrad. */
 int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* dz, int lddz, float* dw,
                         float* db, int B, int H, int W, int Cin, int Cout, int accumulate,
-                        const gct2_adam_args* adam /* or NULL */, void* stream);
+                        gct2_adam_args* adam /* or NULL */, void* stream);
 
 /* ---- the reference's off-by-default model variants ------------------------------------------------------------------------
  * Block = block_depth x Conv2D(filters, 3, 1, 'same', relu) (train.py:20, 123-143) and the bias-free projection

@@ -364,16 +364,31 @@ def test_fused_adam_equals_separate_adam(gpu):
     ts = [torch.randint(1, 201, (16,), generator=gen, dtype=torch.int32) for _ in range(3)]
     es = [torch.randn(16, 64, 64, 3, generator=gen) for _ in range(3)]
     engines = []
-    for fuse in (False, True):
+    # third engine (r04): the fused step with the optimizer launches of dense / UpShuffle_0..2 DEFERRED into the next forward pass's
+    # bottleneck window (engine.defer_adam, the default): the same launches at another time - the same bits, and everything that
+    # looks at the parameters in between (a prediction, the arena properties) sees them applied
+    for fuse, defer in ((False, False), (True, False), (True, True)):
         eng = g.UNetEngine(topo, g.BF16, gpu, seed=77)
-        eng.fuse_adam = fuse
-        losses = [float(eng.train_step(x, t, e)[0]) for x, t, e in zip(xs, ts, es)]
+        eng.fuse_adam, eng.defer_adam = fuse, defer
+        losses, preds = [], []
+        for k, (x, t, e) in enumerate(zip(xs, ts, es)):
+            losses.append(float(eng.train_step(x, t, e)[0]))
+            assert bool(eng._pending) == defer
+            if k == 1:
+                preds.append(eng.predict(x[:2].to(torch.bfloat16).float()).clone())      # flushes what step 1 held back
+                assert not eng._pending
         torch.cuda.synchronize()
-        engines.append((eng, losses))
-    (a, la), (b, lb) = engines
-    assert la == lb and a.iterations == b.iterations == 3
-    for name in ("p", "m", "v", "shadow"):
-        assert torch.equal(getattr(a.arena, name), getattr(b.arena, name)), name
+        engines.append((eng, losses, preds))
+    (a, la, pa), (b, lb, pb), (c, lc, pc) = engines
+    assert la == lb == lc and a.iterations == b.iterations == c.iterations == 3
+    assert torch.equal(pa[0], pb[0]) and torch.equal(pa[0], pc[0])
+    assert c._pending                                            # the last step's launches are still held back ...
+    for name in ("p", "m", "v", "shadow"):                       # ... until somebody looks
+        for other in (b, c):
+            assert torch.equal(getattr(a.arena, name), getattr(other.arena, name)), name
+    assert not c._pending
+    sd = c.state_dict()
+    assert torch.equal(sd["arena.p"], a.arena.p.cpu())
 
 
 def test_relu_bit_planes_do_not_change_the_step(gpu):
@@ -657,7 +672,7 @@ def test_config3_bf16_slice_vs_rounded_oracle(gpu, parity_log):
         assert any(t.startswith(token) for t in ran), (token, sorted(set(ran)))
     assert sum(t.startswith("halo:convT:bias_act:bits") for t in ran) == 2 and sum(t.startswith("halo:convT:mask:bits") for t in ran) == 2   # U1, U2 / D1, D2
     assert not any("ksplit=" in t and "ksplit=1" not in t for t in ran) and "relu_bits:derived" not in ran
-    assert sum(t.startswith("wgrad:256q") for t in ran) == 11 and sum(t.startswith("wgrad:256q") and t.endswith("slabs") for t in ran) >= 6
+    assert sum(t.startswith("wgrad:256q") for t in ran) == 11 and sum(t.startswith("wgrad:256q") and t.endswith("slabs") for t in ran) >= 5   # U0, U1, U2, D1, D2 (the deeper levels have one 64-row step at batch 2)
     assert not any(t.startswith(("halo:convT:bias_act", "halo:convT:mask", "tap:conv:256x128", "wgrad:256q")) for t in logs["default"])
     # the fused optimizer on the same dispatch: Keras Adam fed from the weight-gradient slabs (never materialised) must equal the
     # oracle's Adam applied to the gradients this dispatch produced above (iteration 0, zero slots)
