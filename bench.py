@@ -298,18 +298,36 @@ def main():
             # family, NOT measured in this run: the average over its launches in the committed per-layer PMC passes
             # (profiles/r03_traffic_per_layer.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
             # scripts/traffic_layers.py, gfx950 corrections applied), only for the default config; `traffic_source` says so.
-            traffic, traffic_source = None, None
-            tname = "r03_traffic_per_layer.json"
+            traffic, traffic_source, mfma_util, mfma_source = None, None, None, None
+            fam_of = lambda lay, d: ("wgrad" if d == "wgrad" else "conv_form" if (lay[0] == "D") == (d == "fwd") else "convT_form")
+            tname = "r04_traffic_per_layer.json"
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and (S, B, args.dtype, world) == (128, 64, "bf16", 1):
                 with open(tpath) as f:
-                    rows = [r for r in json.load(f)["layers"] if r["form"] == {"conv_form": "conv", "convT_form": "convT", "wgrad": "wgrad"}[dom]]
+                    rows = [r for r in json.load(f)["layers"] if r["form"] != "rgb" and fam_of(r["layer"], r["dir"].split("+")[0]) == dom]
                 if rows:
                     traffic = sum(r["read_MB"] + r["write_MB"] for r in rows) * 1e6 / len(rows)
-                    traffic_source = f"profiles/{tname}: mean of {len(rows)} standalone launches of this family (rocprofv3 --pmc, committed file - not this run)"
+                    traffic_source = (f"profiles/{tname}: mean of the {len(rows)} launches of this family in the ENGINE'S OWN step (its strides, bit planes, "
+                                      "dispatch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections; committed file - not this run)")
+            uname = "r04_mfma_util.txt"
+            upath = os.path.join(ROOT, "profiles", uname)
+            if os.path.exists(upath) and (S, B, args.dtype, world) == (128, 64, "bf16", 1):
+                busy = cyc = 0.0
+                with open(upath) as f:
+                    for line in f:
+                        c = line.split()
+                        if line.startswith(("#", "lay")) or len(c) < 8 or c[0] == "D0":
+                            continue
+                        if fam_of(c[0], c[1].split("+")[0]) == dom:
+                            busy += float(c[-5]); cyc += float(c[-3])
+                if cyc:
+                    mfma_util = busy / (1024 * cyc)
+                    mfma_source = (f"profiles/{uname}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) summed over this family's launches in the "
+                                   "engine's own step (rocprofv3 --pmc; committed file - not this run); in-kernel clocks: profiles/r04_kernel_clock.txt")
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_PEAK, 5),
                                "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_source,
+                               "mfma_util": None if mfma_util is None else round(mfma_util, 4), "mfma_util_source": mfma_source,
                                "flops_per_launch": fl[dom] / (cnt[dom] // iso_steps), "event_steps": iso_steps,
                                "avg_launch_us": round(tot[dom] / cnt[dom] * 1e6, 2),
                                "mode": "one stream (4 extra steps after the timed region): isolated launch durations"}

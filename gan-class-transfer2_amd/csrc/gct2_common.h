@@ -51,27 +51,46 @@ void gct2_log(gct2_ctx& c, const char* fmt, ...);
 // stamped once in front of and once behind the loop; clock = d(memtime) / d(memrealtime) x 100 MHz.  Every wave writes its four
 // values to the CLOCK REGION of the stamp buffer: entry (work-group * waves + wave) at u64 offset GCT2_CLOCK_OFF, if the buffer is
 // at least GCT2_CLOCK_BYTES (8 MiB) long.  Nothing else reads that memory; no output depends on a stamp.
-constexpr size_t GCT2_CLOCK_OFF = (size_t)1 << 19, GCT2_CLOCK_ENTRIES = (size_t)1 << 17, GCT2_CLOCK_BYTES = (GCT2_CLOCK_OFF + 4 * GCT2_CLOCK_ENTRIES) * 8;
-struct ClockStamp { unsigned long long t0 = 0, r0 = 0, t1 = 0, r1 = 0; };
+constexpr size_t GCT2_CLOCK_OFF = (size_t)1 << 19, GCT2_CLOCK_ENTRIES = (size_t)1 << 16, GCT2_CLOCK_BYTES = (GCT2_CLOCK_OFF + 8 * GCT2_CLOCK_ENTRIES) * 8;
+// entry = 8 u64: [0] memtime, [1] memrealtime in front of the K loop; [2], [3] the same behind it; [4] memrealtime at kernel entry;
+// [5] memrealtime at the end of the epilogue (phases of a work-group's life: setup = [1] - [4], loop = [3] - [1], epilogue = [5] - [3])
+struct ClockStamp { unsigned long long t0 = 0, r0 = 0, t1 = 0, r1 = 0, rin = 0; };
 __device__ __forceinline__ void clock_now(unsigned long long& t, unsigned long long& r) {
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r)::"memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+__device__ __forceinline__ unsigned long long realtime_now() {
+  unsigned long long r;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return r;
+}
+// the loop stamps are stored right behind the loop (as before); the exit stamp when the epilogue's stores have been ISSUED and
+// drained (s_waitcnt vmcnt(0)): what a work-group's slot on the CU really costs
 __device__ __forceinline__ void clock_store(unsigned long long* stamps, const ClockStamp& c, int waves_per_group, int wave, int lane) {
   const size_t e = (size_t)blockIdx.x * waves_per_group + wave;
   if (stamps && lane == 0 && e < GCT2_CLOCK_ENTRIES) {
-    unsigned long long* o = stamps + GCT2_CLOCK_OFF + e * 4;
-    o[0] = c.t0; o[1] = c.r0; o[2] = c.t1; o[3] = c.r1;
+    unsigned long long* o = stamps + GCT2_CLOCK_OFF + e * 8;
+    o[0] = c.t0; o[1] = c.r0; o[2] = c.t1; o[3] = c.r1; o[4] = c.rin;
   }
 }
-#define GCT2_CLOCK_DECL ClockStamp clk_
+__device__ __forceinline__ void clock_exit(unsigned long long* stamps, int waves_per_group, int wave, int lane) {
+  const size_t e = (size_t)blockIdx.x * waves_per_group + wave;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long r = realtime_now();
+  if (stamps && lane == 0 && e < GCT2_CLOCK_ENTRIES) stamps[GCT2_CLOCK_OFF + e * 8 + 5] = r;
+}
+#define GCT2_CLOCK_DECL ClockStamp clk_; clk_.rin = realtime_now()
 #define GCT2_CLOCK_BEGIN clock_now(clk_.t0, clk_.r0)
 #define GCT2_CLOCK_END(stamps, nwaves, wave, lane) do { clock_now(clk_.t1, clk_.r1); clock_store(stamps, clk_, nwaves, wave, lane); } while (0)
+#define GCT2_CLOCK_EXIT(stamps, nwaves, wave, lane) clock_exit(stamps, nwaves, wave, lane)
 #else
 #define GCT2_CLOCK_DECL
 #define GCT2_CLOCK_BEGIN
 #define GCT2_CLOCK_END(stamps, nwaves, wave, lane)
+#define GCT2_CLOCK_EXIT(stamps, nwaves, wave, lane)
 #endif
 
 template <typename T> struct is16 { static constexpr bool value = sizeof(T) == 2; };

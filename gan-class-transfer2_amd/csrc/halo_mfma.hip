@@ -75,6 +75,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   char* const wb0 = lds_all + 2 * HALO_BYTES;
   char* const wb1 = lds_all + 2 * HALO_BYTES + WB_BYTES;
 
+  GCT2_CLOCK_DECL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int phase = wave >> 1, mhalf = wave & 1;
@@ -197,7 +198,6 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
     }
   };
   // ---- main loop: 8 rounds (two k-chunks) per trip so that every buffer role is a compile-time constant --------------
-  GCT2_CLOCK_DECL;
   GCT2_CLOCK_BEGIN;
   issue_halo(0, halo0);
   issue_w(0, wb0);
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       unsigned long long* o = p.stamps + ((size_t)m_tile * 8 + wave) * 8;
       for (int k = 0; k < 6; k++) o[k] = st[k];
     }
+    GCT2_CLOCK_EXIT(p.clock ? p.stamps : nullptr, 8, wave, lane);
 #endif
     return;
   }
@@ -525,6 +526,9 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
       }
     }
   }
+#ifdef GCT2_STAMP
+  GCT2_CLOCK_EXIT(p.clock ? p.stamps : nullptr, 8, wave, lane);
+#endif
 }
 
 }  // namespace

@@ -641,6 +641,9 @@ template <typename T>
 __global__ void diffusion_mix_kernel(const float* __restrict__ x, const float* __restrict__ e, float sa, float sb,
                                      float* __restrict__ fake, T* __restrict__ out, int ldout, T* __restrict__ out2, int ldout2,
                                      size_t n, int C) {
+  // plain IEEE multiplies and adds in the order of the formula, no FMA contraction: what an unfused TensorFlow op chain computes
+  // (train.py:372-375), and independent of the code around it (as for adam_keras_update)
+#pragma clang fp contract(off)
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float f = sa * x[i] + sb * e[i];
@@ -657,6 +660,7 @@ __global__ void diffusion_mix_kernel(const float* __restrict__ x, const float* _
 template <int MODE>
 __global__ void diffusion_update_kernel(const float* __restrict__ pred, const float* __restrict__ fake, float sa, float sb, float sb1, float den,
                                         float* __restrict__ x, float* __restrict__ e, size_t n) {
+#pragma clang fp contract(off)          // (f - sa p) / sb etc. as separate roundings, like the reference's op chain (train.py:382-413)
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float p = pred[i], f = fake[i];

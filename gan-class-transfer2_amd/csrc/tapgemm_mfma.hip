@@ -96,6 +96,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
   unsigned long long* stamp_out = p.stamps;
   TG_STAMP(0);
 #endif
+  GCT2_CLOCK_DECL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WAVES_N, wm = wave / WAVES_N;
@@ -298,7 +299,6 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
   // spilled registers, 10x slower; here: the 256 x 256 and three-buffer variants); behind the guard each step stays its own region.
   const bool live = p.ksplit > 0;
   TG_STAMP(1);
-  GCT2_CLOCK_DECL;
   GCT2_CLOCK_BEGIN;
   if constexpr (NBUF == 1) {
     // one LDS buffer (32 KiB): no overlap inside a work-group; 4 work-groups per CU cover each other instead
@@ -543,6 +543,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
       }
     }
   }
+#ifdef GCT2_STAMP
+  GCT2_CLOCK_EXIT(p.clock ? p.stamps : nullptr, NWV, wave, lane);
+#endif
 }
 
 // db[n] += sum over the partial rows part[rows][N] left by the GEMM epilogue / the split-K finalize (fixed order).
@@ -750,10 +753,13 @@ bool tapgemm_mfma_supported(int dtype, const TapGemmParams& p) {
   if ((uintptr_t)p.x % 16 || (uintptr_t)p.w % 16 || (uintptr_t)p.y % 8) return false;
   if (p.act && (uintptr_t)p.act % 8) return false;
   if (p.bias && (uintptr_t)p.bias % 16) return false;
-  // buffer descriptors address 2 GiB: source tensor (BIG grid for conv-form) and the 16-tap weight tensor
+  // buffer descriptors address 2 GiB: source tensor (BIG grid for conv-form) and the 16-tap weight tensor.  The lean issue bases the
+  // source descriptor one row + one pixel IN FRONT of the tensor and adds that shift to every per-lane offset, whose bit 31 is the
+  // "invalid tap" flag: the largest offset a valid lane can form (tensor + shift + tap / chunk part) must stay below 2^31
   const size_t src_bytes = (size_t)p.B * p.Hs * p.Ws * 4 * p.ldx * 2;
+  const size_t shift = (size_t)(2 * p.Ws + 1) * p.ldx * 2, tap_max = (size_t)(3 * 2 * p.Ws + 3) * p.ldx * 2 + (size_t)p.K * 2;
   const size_t w_bytes = (size_t)16 * p.K * p.N * 2;
-  if (src_bytes >= 0x7ff00000u || w_bytes >= 0x7ff00000u) return false;
+  if (src_bytes + shift + tap_max >= 0x7ff00000u || w_bytes >= 0x7ff00000u) return false;
   return true;
 }
 

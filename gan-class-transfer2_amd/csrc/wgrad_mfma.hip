@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   __shared__ __attribute__((aligned(16))) char lds0[2 * IMG];     // [big image | small image]
   __shared__ __attribute__((aligned(16))) char lds1[2 * IMG];
 
+  GCT2_CLOCK_DECL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wm = wave >> 1;
@@ -130,7 +131,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     }
   };
 
-  GCT2_CLOCK_DECL;
   GCT2_CLOCK_BEGIN;
   {
     issue(step_lo, lds0);
@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       }
     }
   }
+#ifdef GCT2_STAMP
+  GCT2_CLOCK_EXIT(p.clock ? p.stamps : nullptr, 4, wave, lane);
+#endif
 }
 
 #define GCT2_VMCNT_ONLY(n) ((((n) & 0xF) | 0x70 | 0xF00 | ((((n) >> 4) & 3) << 14)))
@@ -207,6 +210,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
   constexpr int NDMA = 4;
   __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
 
+  GCT2_CLOCK_DECL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 3, wm = wave >> 2;
@@ -336,7 +340,6 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
     else wait_tail(st_hi - 1 - (st + 1));
     __builtin_amdgcn_s_barrier();
   };
-  GCT2_CLOCK_DECL;
   GCT2_CLOCK_BEGIN;
   issue(lds);
   if (st_lo + 1 < st_hi) issue(lds + STAGE);
@@ -394,6 +397,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
       }
     }
   }
+#ifdef GCT2_STAMP
+  GCT2_CLOCK_EXIT(p.clock ? p.stamps : nullptr, 8, wave, lane);
+#endif
 }
 
 // dw[e] += sum_s slab[s][e], 4 elements per thread, slabs added in index order

@@ -870,6 +870,7 @@ class UNetEngine:
             self.ls_state.copy_(sd["loss_scale_state"].to(self.device))
         self.iterations = its
         A.refresh_shadow(self._stream())
+        self._masters_sharded = False                          # the arenas are whole again (a sharded wrapper sets it at its next step)
 
     def save_checkpoint(self, path: str) -> None:
         from safetensors.torch import save_file

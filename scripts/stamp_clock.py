@@ -76,7 +76,8 @@ for name, a in rec:
 stamps = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
 OFF = 1 << 19
 print(f"# in-kernel clock of the K loops, config 3 (3x128x128, batch 64, bf16), >= {args.seconds} s of back-to-back launches before the stamped one")
-print("# layer       kernel                                      clock GHz (median p10 p90)   K loop us/work-group   PFLOP/s in loop   launch us")
+print("# phases of a work-group's life from s_memrealtime: setup = entry -> K loop, loop, epilogue = K loop end -> stores drained; span = first entry -> last exit")
+print("# layer       kernel                                      clock GHz (median p10 p90)   setup / K loop / epilogue us (median per wave)   waves   PFLOP/s in loop   span us   launch us")
 for lab in [s for s in args.layers.split(",") if s]:
     if lab not in calls:
         print(f"{lab:12s} (no such call)")
@@ -109,10 +110,11 @@ for lab in [s for s in args.layers.split(",") if s]:
     kern = [k for k in eng.ctx.read_launch_log() if not k.startswith("relu_bits")][-1]
     eng.ctx.log_launches(False)
     eng.ctx.set_stamp_buffer(None)
-    c = stamps[OFF:].cpu().numpy().reshape(-1, 4)
-    c = c[(c[:, 1] != 0) & (c[:, 3] > c[:, 1])]
+    c = stamps[OFF:].cpu().numpy().reshape(-1, 8)
+    c = c[(c[:, 1] != 0) & (c[:, 3] > c[:, 1]) & (c[:, 5] != 0)]
     clk = (c[:, 2] - c[:, 0]) / (c[:, 3] - c[:, 1]) * 0.1          # cycles per 10 ns -> GHz
-    loop_us = (c[:, 3] - c[:, 1]) / 100.0
+    setup_us, loop_us, epi_us = (c[:, 1] - c[:, 4]) / 100.0, (c[:, 3] - c[:, 1]) / 100.0, (c[:, 5] - c[:, 3]) / 100.0
+    span = (c[:, 5].max() - c[:, 4].min()) / 100.0
     nwaves = len(c)
     # MFMA rate inside the loop: the launch's FLOPs, spread over the waves that ran, per median loop time, times the waves resident at once
     fl = flops(name, a)
@@ -120,4 +122,4 @@ for lab in [s for s in args.layers.split(",") if s]:
     resident = min(nwaves, 256 * 16 if "256x128" in kern else 256 * 8)     # waves resident at once: two 8-wave groups per CU, else 8 waves per CU
     rate = per_wave / (np.median(loop_us) * 1e-6) * resident / 1e15
     print(f"{lab:12s} {kern:42s}  {np.median(clk):5.3f} {np.percentile(clk, 10):5.3f} {np.percentile(clk, 90):5.3f}      "
-          f"{np.median(loop_us):8.2f} ({nwaves} waves)   {rate:6.3f}           {us_launch:7.1f}")
+          f"{np.median(setup_us):6.2f} / {np.median(loop_us):7.2f} / {np.median(epi_us):6.2f}   {nwaves:6d}   {rate:6.3f}   {span:7.1f}   {us_launch:7.1f}")
