@@ -69,7 +69,9 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   STAMP(0);
 #endif
   // ONE array, the halo images first: every fragment address of the lean rounds is a per-lane register + a 16-bit immediate
-  __shared__ __attribute__((aligned(16))) char lds_all[2 * HALO_BYTES + 2 * WB_BYTES];
+  // (EPI_HEAD: 14 KiB more - the rest of the CU's 160 KiB - for the operand images of the Dense kernel, built while the first DMA is in flight)
+  constexpr int HEAD_CT_OFF = 2 * HALO_BYTES + 2 * WB_BYTES, HEAD_CT_BYTES = 14 * 1024;
+  __shared__ __attribute__((aligned(16))) char lds_all[2 * HALO_BYTES + 2 * WB_BYTES + (EPI == EPI_HEAD ? HEAD_CT_BYTES : 0)];
   char* const halo0 = lds_all;
   char* const halo1 = lds_all + HALO_BYTES;
   char* const wb0 = lds_all + 2 * HALO_BYTES;
@@ -198,9 +200,44 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
     }
   };
   // ---- main loop: 8 rounds (two k-chunks) per trip so that every buffer role is a compile-time constant --------------
+  // EPI_HEAD: the operand images of the Dense kernel for the epilogue's matrix-core contractions (see there), written behind the K loop's
+  // buffers while the first halo / weight pieces are in flight: their global loads (67 x 3 floats, L2-resident) hide under that DMA
+  auto head_term_bits = [](float v, int t) -> uint32_t {  // t-th term of v = hi + mid + lo in the storage type
+    T a = from_f32<T>(v);
+    if (t == 0) return (uint32_t)__builtin_bit_cast(uint16_t, a);
+    float r = v - to_f32<T>(a);
+    T b2 = from_f32<T>(r);
+    if (t == 1) return (uint32_t)__builtin_bit_cast(uint16_t, b2);
+    r = r - to_f32<T>(b2);
+    return (uint32_t)__builtin_bit_cast(uint16_t, from_f32<T>(r));
+  };
   GCT2_CLOCK_BEGIN;
   issue_halo(0, halo0);
   issue_w(0, wb0);
+  if constexpr (EPI == EPI_HEAD) {
+    const HeadFuse& hd = p.head;
+    const int Cout = hd.Cout;
+    for (int e = tid; e < 14 * 64; e += 512) {
+      const int ent = e >> 6, L = e & 63, r16 = L & 15, kg = L >> 4;
+      uint32_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        float w = 0.f;
+        int t;
+        if (ent < 6) {                                      // (F) entry (t, kk): A[row o = r16][k = channel 32 kk + 8 kg + i]
+          t = ent >> 1;
+          const int c = 32 * (ent & 1) + 8 * kg + i;
+          if (r16 < Cout) w = hd.w[c * Cout + r16];
+        } else {                                            // (G) entry (f, t): A[row r16 -> channel w_row(f, r16)][k = output i], lane group 0 only
+          const int f = (ent - 6) >> 1;
+          t = (ent - 6) & 1;
+          if (kg == 0 && i < Cout) w = hd.w[w_row(f, r16) * Cout + i];
+        }
+        v[i] = head_term_bits(w, t);
+      }
+      *reinterpret_cast<u32x4_t*>(lds_all + HEAD_CT_OFF + e * 16) = u32x4_t{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #define GCT2_LEAN_ROUND(FAST, R, IDX, HCUR, HNEXT, WCUR, WNEXT)                              \
@@ -241,161 +278,209 @@ __global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
   if constexpr (EPI == EPI_HEAD) {
     STAMP(1);
     // ---- UpShuffle_0 forward + Dense(3) head + fp32 MSE + both gradients (train.py:188, 198-202, 262-272) ------------------
-    // A wave holds ALL N = 64 channels of its 128 pixels (the 4 lane groups g of a pixel column q carry 16 channels each), so the
-    // head runs on the accumulators: y = relu(acc + bias) rounded to the storage type (the value the unfused path would have
-    // written to R_0), pred = [y, image] Wd + bd, d = pred - target, the loss, and dR_0 = (y > 0) * dpred Wd^T - the only tensor
-    // this epilogue stores.  Dense kernel / bias gradients, the loss and UpShuffle_0's bias gradient leave as ONE partial row
-    // per work-group (HEAD_ROW floats) for the ordered finish kernel of the head.
+    // A wave holds ALL N = 64 channels of its 128 pixels (the 4 lane groups of a pixel column q carry 16 channels each), so the
+    // head runs where the activations are produced: y = relu(acc + bias) rounded to the storage type (the value the unfused path
+    // would have written to R_0), pred = [y, image] Wd + bd, d = pred - target, the loss, and dR_0 = (y > 0) * dpred Wd^T - the
+    // only tensor this epilogue stores.  Dense kernel / bias gradients, the loss and UpShuffle_0's bias gradient leave as ONE
+    // partial row per work-group (HEAD_ROW floats) for the ordered finish kernel of the head.
+    //
+    // r04: the three small contractions run on the MATRIX CORES (r03: ~290 vector instructions per patch row and wave, 16.3 us of a
+    // 40.6-us work-group life at one work-group per CU - profiles/r04_kernel_clock.txt).  With the fp32 operands split into 2-3
+    // terms of the storage type (hi + mid + lo: 24 bits) the results are fp32-accurate:
+    //  (F) pred^T[o][px]  = Wd^T[o][c] . Y[c][px]     : B operand = the lane's OWN packed activations (k = channel 32 ip + 8 eg + i, column = pixel q)
+    //                                                    -> rows o = 0..2 land in lane group 0 of pixel q, where d and dpred are formed
+    //  (G) dy^T[c][px]    = Wd[c][o] . dpred^T[o][px]  : A rows in the permuted channel order w_row(), so that fragments 2 ip / 2 ip + 1 give every
+    //                                                    lane the 8 channels it stores (the layout of the accumulators)
+    //  (W) dW^T[o][c]    += dpred^T[o][px] . Y[px][c]  : contraction over PIXELS: Y is parked in LDS as a [pixel][64 channels] image (swizzled 32-byte
+    //                                                    chunks) and read back TRANSPOSED (ds_read_b64_tr_b16), dpred^T from a small per-wave table
+    // Everything is wave-private between the two barriers (a wave's DS instructions execute in order), no barrier inside the row loop.
     const HeadFuse& hd = p.head;
     const int Cout = hd.Cout;
-    // Register budget: 128 accumulators + 64 gradient sums of the head do not fit 256 registers.  The head only needs the
-    // ACTIVATIONS (16-bit after rounding): all of them are parked in LDS first - idle after the K loop - as sixteen 8-KiB slots
-    // (slot (j, ip) = 512 lanes x 16 bytes = 8 channels of patch row j, conflict-free), which frees every accumulator; the head
-    // then walks the rows in a real loop, each lane reading back exactly what it wrote.
-    auto park = [&](int slot) -> char* {
-      return slot < 5 ? halo0 + slot * 8192 : slot < 10 ? halo1 + (slot - 5) * 8192 : slot < 14 ? wb0 + (slot - 10) * 8192
-                                                                                               : wb1 + (slot - 14) * 8192;
-    };
-    float* hw = reinterpret_cast<float*>(wb1 + 16384);    // [68][4] Dense kernel (column 3 zero), then [64] layer bias
-    float* hbias = hw + 68 * 4;
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-#pragma unroll
-      for (int ip = 0; ip < 2; ip++) {
-        const f32x4_t b0 = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + 32 * ip + 8 * eg) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const f32x4_t b1 = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + 32 * ip + 8 * eg + 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const f32x4_t v0 = acc[2 * ip][j] + b0, v1 = acc[2 * ip + 1][j] + b1;
-        const u32x4_t o = {pack2<T>(fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f)), pack2<T>(fmaxf(v0[2], 0.f), fmaxf(v0[3], 0.f)),
-                           pack2<T>(fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f)), pack2<T>(fmaxf(v1[2], 0.f), fmaxf(v1[3], 0.f))};
-        *reinterpret_cast<u32x4_t*>(park(2 * j + ip) + tid * 16) = o;           // what R_0 would hold
-      }
-    for (int i = tid; i < 68 * 4; i += 512) {
-      const int c = i >> 2, o = i & 3;
-      hw[i] = (c < hd.Cin && o < Cout) ? hd.w[c * Cout + o] : 0.f;
+    constexpr int YP_WAVE = 64 * 128;                       // park image of HALF a wave's pixels: 64 pixel rows x 128 B
+    constexpr int CT_OFF = HEAD_CT_OFF;                     // operand images of the Dense kernel: 6 (F) + 8 (G) entries x 64 lanes x 16 B (built before the K loop)
+    constexpr int DT_OFF = 8 * YP_WAVE;                     // dpred^T terms: [wave][2 terms][3 outputs][64 pixels] x 2 B
+    constexpr int DT_WAVE = 2 * 3 * 64 * 2;
+    constexpr int PC_OFF = DT_OFF + 8 * DT_WAVE;            // per-pixel constants of lane group 0: [3 image channels][4] Dense rows, then the Dense bias [4]
+    constexpr int LB_OFF = PC_OFF + 64;                     // the layer's own bias [64] (LDS reads per row instead of global loads: those would sit in
+    static_assert(LB_OFF + 256 <= HEAD_CT_OFF, "epilogue LDS map");                      // vmcnt behind the previous row's stores and wait for them)
+    auto fsw = [](int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); };      // chunk swizzle of the park image (conflict-free transposed reads)
+    auto term_bits = head_term_bits;
+    const T* __restrict__ x2 = reinterpret_cast<const T*>(hd.x2);
+    const int nimg = (x2 != nullptr) ? min(hd.Cin - 64, 3) : 0;
+    if (tid < 16) {                                          // lane group 0's per-pixel constants (read back per row: registers are scarce here)
+      const int c = tid >> 2, o = tid & 3;
+      float v = 0.f;
+      if (o < Cout) v = c < 3 ? (c < nimg ? hd.w[(64 + c) * Cout + o] : 0.f) : (hd.b ? hd.b[o] : 0.f);
+      reinterpret_cast<float*>(lds_all + PC_OFF)[tid] = v;
     }
+    if (tid >= 64 && tid < 128) reinterpret_cast<float*>(lds_all + LB_OFF)[tid - 64] = p.bias ? p.bias[tid - 64] : 0.f;
     __syncthreads();
     STAMP(2);
     const float gscale = (hd.loss_scale ? *hd.loss_scale : 1.f) * 2.0f / hd.count;
-    float bd[3];
+    float bacc[16];                                        // column sums of dy (UpShuffle_0's bias gradient), this lane's 16 channels
+    float wimg[3][3], dbd[3] = {0.f, 0.f, 0.f}, lacc = 0.f; // lane group 0: Dense kernel gradient of the image channels, Dense bias gradient, loss
 #pragma unroll
-    for (int o = 0; o < 3; o++) bd[o] = (hd.b && o < Cout) ? hd.b[o] : 0.f;
-    const T* __restrict__ x2 = reinterpret_cast<const T*>(hd.x2);
-    float wacc[16][3];                                     // dW[this lane's channel c][o] over its pixels
-    float bacc[16];                                        // column sums of dR_0 (UpShuffle_0's bias gradient)
-    // wx: lane group 0 sums dpred (the Dense bias gradient), lane groups 1..3 the Dense kernel gradient of image channel g-1
-    float wx[3] = {0.f, 0.f, 0.f}, lacc = 0.f;
+    for (int c = 0; c < 16; c++) bacc[c] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 16; c++) { bacc[c] = 0.f; wacc[c][0] = wacc[c][1] = wacc[c][2] = 0.f; }
-    const int imc = eg - 1;                                // this lane group's image channel (-1: none)
-    const bool im_ok = imc >= 0 && 64 + imc < hd.Cin && x2 != nullptr;
-    // lane-local channel c = 8 ip + k  <->  channel 32 ip + 8 eg + k of the layer
-    // the per-pixel inputs of row j + 1 (target, packed image) are loaded while row j is processed: with two waves per SIMD a
-    // dependent global load in every row would be most of the epilogue
-    auto row_pix = [&](int j) {
-      const int sh = sh0 + mhalf * 8 + j, sw = sw0 + eq;
-      return ((size_t)b * (2 * Hs) + 2 * sh + ph) * (2 * Ws) + 2 * sw + pw;
-    };
+    for (int c = 0; c < 3; c++) wimg[c][0] = wimg[c][1] = wimg[c][2] = 0.f;
+    f32x4_t accW[4];                                       // (W): dW^T[o = 4 g + r][c = 16 f + (lane & 15)] over this wave's 128 pixels
+#pragma unroll
+    for (int f = 0; f < 4; f++) accW[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    char* const ypark = lds_all + wave * YP_WAVE;
+    char* const dtab = lds_all + DT_OFF + wave * DT_WAVE;
+    const size_t pix0 = ((size_t)b * (2 * Hs) + 2 * (sh0 + mhalf * 8) + ph) * (2 * Ws) + 2 * (sw0 + eq) + pw;   // output pixel of patch row 0
+    const size_t pix_step = (size_t)4 * Ws;                                                                   // ... two output rows further per patch row
+    auto row_pix = [&](int j) { return pix0 + (size_t)j * pix_step; };
+    // the per-pixel inputs of row j + 1 (target, packed image; lane group 0 only) are loaded while row j is processed
     float tg_n[3] = {0.f, 0.f, 0.f};
     u32x2_t im_n = {0u, 0u};
-    auto prefetch = [&](int j) {
-      const size_t px = row_pix(j);
+    auto prefetch = [&](int j) {                           // (every lane group loads: lane-divergent loads would hide the issue order from
+      const size_t px = row_pix(j);                          // hipcc's vmcnt bookkeeping and every row would wait for the previous row's stores)
 #pragma unroll
       for (int o = 0; o < 3; o++) tg_n[o] = o < Cout ? hd.target[px * Cout + o] : 0.f;
-      if (im_ok) im_n = *reinterpret_cast<const u32x2_t*>(x2 + px * hd.ldx2);
+      if (nimg > 0) im_n = *reinterpret_cast<const u32x2_t*>(x2 + px * hd.ldx2);
     };
     prefetch(0);
-    // this lane's 16 rows of the Dense kernel stay in registers for the whole row loop (they were re-read from LDS twice per row:
-    // 32 of the ~40 LDS instructions of a row; the kernel has the registers since the lane reductions went to DPP)
-    float hwr[16][3];
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-      const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(hw + 4 * (32 * (c >> 3) + 8 * eg + (c & 7)));
-      hwr[c][0] = w4[0]; hwr[c][1] = w4[1]; hwr[c][2] = w4[2];
-    }
-#pragma unroll 1
     for (int j = 0; j < 8; j++) {
+      int ct = CT_OFF + elane * 16;                        // opaque per row: keeps the 14 operand fragments out of the registers between rows
+      asm volatile("" : "+v"(ct));
       const size_t opix = row_pix(j);
       const float tg[3] = {tg_n[0], tg_n[1], tg_n[2]};
       const u32x2_t v2 = im_n;
       if (j < 7) prefetch(j + 1);
-      float yq[16];
+      const int krow = (j & 3) * 16 + eq;                  // this pixel's row in the park image of the current half
+      // y = relu(acc + bias), rounded to the storage type: what R_0 would hold; parked for (W), used right away for (F)
+      u32x4_t yv[2];
 #pragma unroll
       for (int ip = 0; ip < 2; ip++) {
-        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(park(2 * j + ip) + tid * 16);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { yq[8 * ip + 2 * k] = unpack_lo<T>(v[k]); yq[8 * ip + 2 * k + 1] = unpack_hi<T>(v[k]); }
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lds_all + LB_OFF + (32 * ip + 8 * eg) * 4);
+        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lds_all + LB_OFF + (32 * ip + 8 * eg + 4) * 4);
+        const f32x4_t v0 = acc[2 * ip][j] + b0, v1 = acc[2 * ip + 1][j] + b1;
+        yv[ip] = u32x4_t{pack2<T>(fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f)), pack2<T>(fmaxf(v0[2], 0.f), fmaxf(v0[3], 0.f)),
+                         pack2<T>(fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f)), pack2<T>(fmaxf(v1[2], 0.f), fmaxf(v1[3], 0.f))};
+        *reinterpret_cast<u32x4_t*>(ypark + krow * 128 + (((2 * ip + (eg >> 1)) ^ fsw(krow)) << 5) + (eg & 1) * 16) = yv[ip];
       }
-      float s3[3] = {0.f, 0.f, 0.f};
+      // (F) pred^T = Wd^T . Y: three terms of the Dense kernel x two 32-channel blocks
+      f32x4_t accP = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 16; c++) {
-        s3[0] = fmaf(yq[c], hwr[c][0], s3[0]); s3[1] = fmaf(yq[c], hwr[c][1], s3[1]); s3[2] = fmaf(yq[c], hwr[c][2], s3[2]);
-      }
-      float mult = eg == 0 ? 1.f : 0.f;                    // multiplier of dsc in wx
-      if (im_ok) {                                         // image channel N + imc from the packed copy
-        mult = imc == 0 ? unpack_lo<T>(v2[0]) : (imc == 1 ? unpack_hi<T>(v2[0]) : unpack_lo<T>(v2[1]));
-        const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(hw + 4 * (64 + imc));
-        s3[0] = fmaf(mult, w4[0], s3[0]); s3[1] = fmaf(mult, w4[1], s3[1]); s3[2] = fmaf(mult, w4[2], s3[2]);
-      }
-      float dsc[3];
+      for (int t = 0; t < 3; t++)
 #pragma unroll
-      for (int o = 0; o < 3; o++) {
-        const float t = rows4_sum(s3[o]);                            // the pixel's four lane groups
-        const float pr = keras_f16_point<T>(t + bd[o]);
-        const float d = o < Cout ? pr - tg[o] : 0.f;
-        if (eg == 0 && o < Cout) {
-          if (hd.pred) hd.pred[opix * Cout + o] = pr;
-          lacc = fmaf(d, d, lacc);
+        for (int kk = 0; kk < 2; kk++) accP = mfma16<T>(lds_read128(lds_all, ct + (t * 2 + kk) * 1024), yv[kk], accP);
+      // lane group 0: prediction, loss, dpred of pixel q (rows o = 0..2 of the result)
+      float dsc[3] = {0.f, 0.f, 0.f};
+      if (eg == 0) {
+        const float im[3] = {unpack_lo<T>(v2[0]), unpack_hi<T>(v2[0]), unpack_lo<T>(v2[1])};
+        f32x4_t pc[4];                                       // rows 0..2: Dense rows of the image channels, row 3: Dense bias
+#pragma unroll
+        for (int c = 0; c < 4; c++) pc[c] = *reinterpret_cast<const f32x4_t*>(lds_all + PC_OFF + 16 * c);
+#pragma unroll
+        for (int o = 0; o < 3; o++) {
+          float s = accP[o];
+#pragma unroll
+          for (int c = 0; c < 3; c++) s = fmaf(im[c], pc[c][o], s);
+          const float pr = keras_f16_point<T>(s + pc[3][o]);
+          const float d = o < Cout ? pr - tg[o] : 0.f;
+          if (o < Cout) {
+            if (hd.pred) hd.pred[opix * Cout + o] = pr;
+            lacc = fmaf(d, d, lacc);
+          }
+          dsc[o] = keras_f16_point<T>(d * gscale);
+          dbd[o] += dsc[o];
+#pragma unroll
+          for (int c = 0; c < 3; c++) wimg[c][o] = fmaf(im[c], dsc[o], wimg[c][o]);
         }
-        dsc[o] = keras_f16_point<T>(d * gscale);
-        wx[o] = fmaf(mult, dsc[o], wx[o]);
       }
+      // dpred^T as two terms: the B operand of (G) (k = output, lane group 0) and the per-wave table for (W)
+      u32x4_t dB[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const uint32_t d0 = term_bits(dsc[0], t), d1 = term_bits(dsc[1], t), d2 = term_bits(dsc[2], t);
+        dB[t] = u32x4_t{d0 | (d1 << 16), d2, 0u, 0u};       // (lane groups 1..3: dsc = 0 -> zero operand)
+        if (eg == 0) {
+          uint16_t* dt = reinterpret_cast<uint16_t*>(dtab) + (t * 3) * 64 + krow;
+          dt[0] = (uint16_t)d0; dt[64] = (uint16_t)d1; dt[128] = (uint16_t)d2;
+        }
+      }
+      // (G) dy^T = Wd . dpred^T (hi.hi + hi.lo + lo.hi), masked by y > 0, summed into the bias gradient, stored as dR_0
 #pragma unroll
       for (int ip = 0; ip < 2; ip++) {
-        float gv[8];
+        f32x4_t gq[2];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int c = 8 * ip + k;
-          float gch = dsc[0] * hwr[c][0] + dsc[1] * hwr[c][1] + dsc[2] * hwr[c][2];
-          if (!(yq[c] > 0.f)) gch = 0.f;
-          gv[k] = gch;
-          bacc[c] += gch;
-          wacc[c][0] = fmaf(yq[c], dsc[0], wacc[c][0]);
-          wacc[c][1] = fmaf(yq[c], dsc[1], wacc[c][1]);
-          wacc[c][2] = fmaf(yq[c], dsc[2], wacc[c][2]);
+        for (int h = 0; h < 2; h++) {
+          const int f = 2 * ip + h;
+          const u32x4_t wh = lds_read128(lds_all, ct + (6 + f * 2) * 1024), wl = lds_read128(lds_all, ct + (7 + f * 2) * 1024);
+          f32x4_t a = mfma16<T>(wh, dB[0], f32x4_t{0.f, 0.f, 0.f, 0.f});
+          a = mfma16<T>(wh, dB[1], a);
+          gq[h] = mfma16<T>(wl, dB[0], a);
         }
-        const u32x4_t o = {pack2<T>(gv[0], gv[1]), pack2<T>(gv[2], gv[3]), pack2<T>(gv[4], gv[5]), pack2<T>(gv[6], gv[7])};
+        apply_relu_bits8(relu_bits8<T>(yv[ip]), gq[0], gq[1]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { bacc[8 * ip + k] += gq[0][k]; bacc[8 * ip + 4 + k] += gq[1][k]; }
+        const u32x4_t o = {pack2<T>(gq[0][0], gq[0][1]), pack2<T>(gq[0][2], gq[0][3]), pack2<T>(gq[1][0], gq[1][1]), pack2<T>(gq[1][2], gq[1][3])};
         *reinterpret_cast<u32x4_t*>(yout + opix * p.ldy + 32 * ip + 8 * eg) = o;
+      }
+      if ((j & 3) == 3) {
+        // (W) for the four rows just parked: 64 pixels = two 32-pixel steps x two terms of dpred x four 16-channel fragments.
+        // (compiler fences: the park image and the table are written and read through differently typed pointers; the hardware
+        // executes a wave's DS instructions in order, so no wait is needed between the writes above and the reads below)
+        asm volatile("" ::: "memory");
+        const int wo = elane & 15, kg = elane >> 4;
+        const int g4 = elane >> 4, q4 = (elane >> 2) & 3, pq = elane & 3;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          u32x4_t da[2];
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            da[t] = lds_read128(dtab, ((t * 3 + (wo < 3 ? wo : 0)) * 64 + 32 * ks + 8 * kg) * 2);
+            if (wo >= 3) da[t] = u32x4_t{0u, 0u, 0u, 0u};
+          }
+          const int k0 = 32 * ks + 8 * g4 + q4;
+#pragma unroll
+          for (int f = 0; f < 4; f++) {
+            const int o0 = k0 * 128 + ((f ^ fsw(k0)) << 5) + pq * 8;
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ypark + o0));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ypark + o0 + 4 * 128));
+            const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+            const u32x4_t yb = {l2[0], l2[1], h2[0], h2[1]};
+            accW[f] = mfma16<T>(da[0], yb, accW[f]);
+            accW[f] = mfma16<T>(da[1], yb, accW[f]);
+          }
+        }
+        asm volatile("" ::: "memory");
       }
     }
     STAMP(3);
-    __syncthreads();                                       // every wave is done with its parked rows
+    __syncthreads();                                       // every wave is done with its park image and tables
     STAMP(4);
-    float* red = reinterpret_cast<float*>(halo0);          // [8][HEAD_ROW]
+    float* red = reinterpret_cast<float*>(lds_all);        // [8][HEAD_ROW]
     for (int i = tid; i < 8 * HEAD_ROW; i += 512) red[i] = 0.f;
     __syncthreads();
-    auto bfly = [](float t) { return row16_sum(t); };
     float* rw = red + wave * HEAD_ROW;
+    if (eg == 0) {                                         // (W): rows o = r of lane group 0, column = channel 16 f + (lane & 15)
+#pragma unroll
+      for (int f = 0; f < 4; f++)
+#pragma unroll
+        for (int o = 0; o < 3; o++)
+          if (o < Cout) rw[(16 * f + eq) * Cout + o] = accW[f][o];
+    }
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-      const int ch = 32 * (c >> 3) + 8 * eg + (c & 7);
-#pragma unroll
-      for (int o = 0; o < 3; o++) {
-        const float t = bfly(wacc[c][o]);
-        if (eq == 0 && o < Cout) rw[ch * Cout + o] = t;
-      }
-      const float tb = bfly(bacc[c]);
-      if (eq == 0) rw[224 + ch] = tb;
+      const float tb = row16_sum(bacc[c]);
+      if (eq == 0) rw[224 + 32 * (c >> 3) + 8 * eg + (c & 7)] = tb;
     }
 #pragma unroll
     for (int o = 0; o < 3; o++) {
-      const float t = bfly(wx[o]);
-      if (eq == 0 && o < Cout) {
-        if (eg == 0) rw[216 + o] = t;
-        else if (im_ok) rw[(64 + imc) * Cout + o] = t;
+      const float td = row16_sum(dbd[o]);
+      if (elane == 0 && o < Cout) rw[216 + o] = td;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float tw = row16_sum(wimg[c][o]);
+        if (elane == 0 && o < Cout && c < nimg) rw[(64 + c) * Cout + o] = tw;
       }
     }
     {
-      const float t = bfly(lacc);
+      const float t = row16_sum(lacc);
       if (elane == 0) rw[219] = t;
     }
     __syncthreads();

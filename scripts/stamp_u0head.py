@@ -3,6 +3,7 @@
 The stamps go to the buffer handed over with gct2_ctx_set_stamp_buffer; the product build has no stamps (gct2_build_flags() == 0)."""
 import sys, os
 os.environ["GCT2_ALLOW_DIAGNOSTIC_BUILD"] = "1"       # the binding refuses a stamped library otherwise
+os.environ["GCT2_USE_STAMP_LIB"] = "1"               # libgct2_stamp.so (make -C gan-class-transfer2_amd/csrc stamp)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, numpy as np
 import gan_class_transfer2_amd as g
@@ -21,7 +22,7 @@ for _ in range(5):
 torch.cuda.synchronize()
 st = stamps.reshape(1024, 8, 8).cpu().numpy()[:, :, :6].astype(np.int64)
 d = np.diff(st, axis=2) / 100.0          # s_memrealtime: 100 MHz -> us
-names = ["K loop", "park acts + head weights", "row loop (8 rows)", "barrier", "reductions + partial row"]
+names = ["K loop", "operand images of the Dense kernel + barrier", "row loop (8 rows)", "barrier", "reductions + partial row"]
 for k, n in enumerate(names):
     print("%-28s median %6.2f us   p10 %6.2f   p90 %6.2f" % (n, np.median(d[:, :, k]), np.percentile(d[:, :, k], 10), np.percentile(d[:, :, k], 90)))
 tot = (st[:, :, 5] - st[:, :, 0]) / 100.0
