@@ -294,10 +294,9 @@ def main():
             dom = max(tot, key=tot.get)
             achieved = fl[dom] * iso_steps / tot[dom] / 1e12
             # achieved = algorithmic FLOPs of ALL launches of the dominant family in the serial-stream steps / their summed
-            # HIP-event time (= average FLOPs per launch / average launch duration).  traffic = HBM bytes per launch of that
-            # family, NOT measured in this run: the average over its launches in the committed per-layer PMC passes
-            # (profiles/r03_traffic_per_layer.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-            # scripts/traffic_layers.py, gfx950 corrections applied), only for the default config; `traffic_source` says so.
+            # HIP-event time (= average FLOPs per launch / average launch duration).  traffic / mfma_util are NOT measured in this
+            # run: they come from the committed rocprofv3 --pmc passes over the ENGINE'S OWN launches (scripts/engine_layers.py --pmc,
+            # scripts/collect_engine_pmc.py, scripts/profile_round.sh), only for the default config; the *_source fields say so.
             traffic, traffic_source, mfma_util, mfma_source = None, None, None, None
             fam_of = lambda lay, d: ("wgrad" if d == "wgrad" else "conv_form" if (lay[0] == "D") == (d == "fwd") else "convT_form")
             tname = "r04_traffic_per_layer.json"

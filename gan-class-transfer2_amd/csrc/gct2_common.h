@@ -193,9 +193,14 @@ __device__ __forceinline__ u32x4_t gload128(const void* p) {
   return *reinterpret_cast<const u32x4_t*>(p);
 }
 
+// two floats -> one packed pair of the 16-bit storage type: ONE v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (round to nearest even, the same
+// bits as two scalar conversions; hipcc turns the scalar form into two conversions + shift + or: 4 instructions per pair in every epilogue)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b) {
-  T x = from_f32<T>(a), y = from_f32<T>(b);
-  return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+  typedef __attribute__((ext_vector_type(2))) T t2_t;
+  static_assert(sizeof(T) == 2, "pack2 packs 16-bit storage types");
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, t2_t));
 }
 template <typename T> __device__ __forceinline__ float unpack_lo(uint32_t u) {
   return to_f32<T>(__builtin_bit_cast(T, (uint16_t)(u & 0xffffu)));

@@ -55,7 +55,7 @@ __device__ __forceinline__ bool db_adds(const TapGemmParams& p, int n) { return 
 // best on this chip (the three-buffer, 256 x 256 and five-stage-ring tiles of r01-r03 were 12-35 % slower and are gone).
 // Every wave owns a 64 (m) x 64 (n) sub-tile.
 #ifdef GCT2_STAMP
-// diagnostic build (make EXTRA=-DGCT2_STAMP, scripts/stamp_layer.py): s_memrealtime at the phase boundaries of one wave per work-group,
+// diagnostic build (make stamp, scripts/stamp_clock.py): s_memrealtime at the phase boundaries of one wave per work-group,
 // written to the buffer handed over with gct2_ctx_set_stamp_buffer (never part of the product build: gct2_build_flags())
 __device__ __forceinline__ unsigned long long tg_stamp() {
   unsigned long long t;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NBUF == 1 ? 4 : 2) void
     const int eg = elane >> 4;
     const int nlane = wn * 64 + 16 * (eg & 1) + 4 * (eg & ~1);
     // the ReLU-mask words of pixel column j + 1 are loaded while column j is processed: one exposed load latency per tile instead
-    // of one per column (in-kernel stamps, scripts/stamp_layer.py: the epilogue of UpShuffle_0's input gradient took 8.2 us of a
+    // of one per column (in-kernel stamps, r02: the epilogue of UpShuffle_0's input gradient took 8.2 us of a
     // 41-us work-group life, most of it four serialized 16-byte-load round trips)
     auto out_pixel = [&](int j, size_t& opix) -> bool {
       const int m = m0 + wm * WM + j * 16 + (elane & 15);
