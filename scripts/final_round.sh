@@ -1,0 +1,12 @@
+set -e
+cd $GRAFT_REPO_ROOT
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+tail -c 600 gpurun_out/bench_default.json
+bash scripts/profile_round.sh > gpurun_out/profile_round.log 2>&1 || true
+python scripts/stamp_clock.py --seconds 2.0 --layers U0.wgrad,U1.wgrad,U2.wgrad,D1.wgrad,D2.wgrad,D3.wgrad,U0.fwd,U1.fwd,U2.fwd,D1.dgrad,D2.dgrad,U0.dgrad,U1.dgrad,U2.dgrad,D1.fwd,D2.fwd,D3.fwd,U3.fwd,U3.dgrad,D3.dgrad,U3.wgrad,U4.wgrad > gpurun_out/kernel_clock.txt 2>&1
+python scripts/engine_layers.py > gpurun_out/layers.txt 2>&1
+python bench.py --size 256 --batch 16 --dtype f16 --no-cpu-baseline > gpurun_out/bench_config5.json 2>/dev/null
+python bench.py --size 64 --batch 32 --no-cpu-baseline > gpurun_out/bench_config2.json 2>/dev/null
+python scripts/bench_dp_overhead.py 30 > gpurun_out/dp_overhead.txt 2>&1 || true
+python scripts/bench_sampler.py > gpurun_out/sampler.txt 2>&1 || true
+echo done
