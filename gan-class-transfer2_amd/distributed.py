@@ -105,7 +105,7 @@ class DataParallelStep:
     def __init__(self, engine, bucket_elems: int = 4 << 20, group=None, force_exchange: bool = False):
         self.engine = engine
         A = engine.arena
-        self.reducer = BucketedAllReducer(A.g, engine.topo.layer_order(), A.layer_ranges, bucket_elems, group, force_exchange)
+        self.reducer = BucketedAllReducer(A.g, A.ready_order(), A.layer_ranges, bucket_elems, group, force_exchange)
         engine.grad_ready_hook = self._grad_ready
         self.world = self.reducer.world
         self._adam_next = 0            # first bucket whose update has not been enqueued in this step
@@ -170,9 +170,15 @@ class ShardedDataParallelStep:
 
     The fp32 master parameters and Adam slots are only maintained for the rank's own shards (`gather_master()` assembles the full
     arenas on every rank: checkpoints, tests).  With loss scaling every rank checks its shards and the found_inf flags are
-    combined with one 4-byte MAX all-reduce."""
+    combined with one 4-byte MAX all-reduce.
 
-    def __init__(self, engine, bucket_elems: int = 4 << 20, group=None, force_exchange: bool = False, tail_layers: int = 2):
+    The LAST bucket is REPLICATED (r04): it holds the last convolution layers of the reverse pass and the arena's fp32 zone - the
+    Dense(3) layer and every bias, which the kernels read in fp32 from the master arena - and is all-reduced and updated on every
+    rank.  It closes only when the reverse pass is over, so it is kept small (0.54 M of the 41.7 M parameters at the reference
+    topology) and its exchange is ONE collective; r03 exchanged the fp32-read parameters with a second collective and three indexing
+    kernels behind the last bucket's reduce-scatter / all-gather."""
+
+    def __init__(self, engine, bucket_elems: int = 4 << 20, group=None, force_exchange: bool = False, tail_layers: int = 3):
         self.engine, self.group = engine, group
         A = engine.arena
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -182,11 +188,11 @@ class ShardedDataParallelStep:
         if A.total % unit:
             raise ValueError(f"arena of {A.total} elements is not a multiple of world x 64 = {unit}")
         bsz = max(unit, (bucket_elems + unit - 1) // unit * unit)
-        order = engine.topo.layer_order()
-        # The LAST bucket closes only when the last layer of the reverse pass (DownShuffle_0) is ready, so its reduce-scatter, Adam
-        # and all-gather are always exposed: keep it small.  It starts at the first of the `tail_layers` last layers
-        # (DownShuffle_1 and _0 of the reference topology: 0.53 M of the 41.7 M parameters), rounded down to a
-        # shard unit; every bucket before it is a fixed-size piece that closes with an earlier layer.
+        order = A.ready_order()                 # convolution layers in backward completion order, then the fp32 zone
+        # The LAST bucket closes only when the reverse pass is over (DownShuffle_0's weight gradient, the fp32 zone), so its exchange
+        # is always exposed: keep it small.  It starts at the first of the `tail_layers` last ranges (DownShuffle_1, DownShuffle_0 and
+        # the fp32 zone of the reference topology: 0.54 M of the 41.7 M parameters), rounded down to a shard unit;
+        # every bucket before it is a fixed-size piece that closes with an earlier layer.
         tail = A.total
         if 0 < tail_layers < len(order):
             tail = A.layer_ranges[order[-tail_layers]][0] // unit * unit
@@ -205,22 +211,11 @@ class ShardedDataParallelStep:
         _one_stream_less(engine, self.exchange)
         self.events: List[Tuple[int, object, object]] = []      # (bucket, start, end) of the collectives when timing is on
         self.time_collectives = False
-        # Parameters the kernels read in FP32 straight from the master arena (every bias, the Dense(3) kernel and bias:
-        # engine.forward / backward pass A.pptr(...), include/gct2.h declares `const float* bias`).  In the 16-bit modes the
-        # all-gather above only carries the compute-dtype shadow, so a rank never saw the updates of such parameters outside its
-        # own shards and kept computing with their initial values (r02).  They are few (a few thousand floats):
-        # after the last bucket's update every rank contributes the ones it owns to ONE small all-reduce (everybody else adds
-        # zeros, so the sum is the owner's value bit for bit) and writes the result back into its master arena.
-        self._small_idx = self._small_own = None
-        if A.shadow is not None:
-            names = [n for n in A.shapes if n.endswith(".b") or n.startswith("dense.")]
-            idx = torch.cat([torch.arange(A.offsets[n], A.offsets[n] + A.numel(n)) for n in names])
-            own = torch.zeros(A.total, dtype=torch.bool)
-            for k in range(len(self.buckets)):
-                slo, shi = self.shard(k)
-                own[slo:shi] = True
-            self._small_idx = idx.to(A.p.device)
-            self._small_own = own[idx].to(A.p.device)
+        # Parameters the kernels read in FP32 straight from the master arena (every bias, the Dense(3) kernel and bias): the sharded
+        # buckets only all-gather the compute-dtype shadow, so these must live in the replicated last bucket (ParamArena puts them
+        # in one zone at the end of the arena for exactly this)
+        if self.buckets[-1][0] > A.layer_ranges["fp32"][0]:
+            raise ValueError("the last bucket must contain the arena's fp32 zone (raise tail_layers)")
         engine._masters_sharded = False     # True after a sharded step, until gather_master(): UNetEngine.state_dict refuses
         self._begin()
 
@@ -230,8 +225,13 @@ class ShardedDataParallelStep:
         self.next_opt = 0           # first bucket whose Adam + all-gather has not been enqueued
         self.launched = 0
 
+    def replicated(self, k: int) -> bool:
+        return k == len(self.buckets) - 1
+
     def shard(self, k: int) -> Tuple[int, int]:
         lo, hi = self.buckets[k]
+        if self.replicated(k):                  # every rank owns (and updates) the whole last bucket
+            return lo, hi
         n = (hi - lo) // self.world
         return lo + self.rank * n, lo + (self.rank + 1) * n
 
@@ -259,7 +259,10 @@ class ShardedDataParallelStep:
         lo, hi = self.buckets[k]
         slo, shi = self.shard(k)
         with self._on_comm():
-            self._timed(k, lambda: dist.reduce_scatter_tensor(g[slo:shi], g[lo:hi], op=dist.ReduceOp.SUM, group=self.group))
+            if self.replicated(k):
+                self._timed(k, lambda: dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group))
+            else:
+                self._timed(k, lambda: dist.reduce_scatter_tensor(g[slo:shi], g[lo:hi], op=dist.ReduceOp.SUM, group=self.group))
         self.launched += 1
 
     def _optimize_and_gather(self, k: int) -> None:
@@ -269,11 +272,15 @@ class ShardedDataParallelStep:
         with self._on_comm():
             stream = self.comm_stream.cuda_stream if self.on_cuda else None
             eng.apply_adam(slo, shi, grad_div=float(self.world), stream=stream)
+            if self.replicated(k):              # updated identically everywhere: nothing to gather
+                return
             w = A.shadow if A.shadow is not None else A.p
             self._timed(k, lambda: dist.all_gather_into_tensor(w[lo:hi], w[slo:shi], group=self.group))
 
     def _grad_ready(self, layer: str) -> None:
         if not self.exchange:
+            return
+        if layer not in self.layer_index:       # ("dense": its gradients live in the fp32 zone, which has its own hook)
             return
         q = self.layer_index[layer]
         rs_due = self.next_rs < len(self.buckets) and self.last_layer[self.next_rs] <= q
@@ -316,23 +323,11 @@ class ShardedDataParallelStep:
         while self.next_opt < len(self.buckets):
             self._optimize_and_gather(self.next_opt)
             self.next_opt += 1
-        self._exchange_fp32_read_parameters()
         if self.on_cuda:
             torch.cuda.current_stream(eng.device).wait_stream(self.comm_stream)
         eng._masters_sharded = True
         eng.finish_step()
         return loss
-
-    def _exchange_fp32_read_parameters(self) -> None:
-        """biases + Dense(3): owner's fp32 values to every rank (see __init__); on the communication stream behind the updates."""
-        if self._small_idx is None:
-            return
-        A = self.engine.arena
-        with self._on_comm():
-            buf = A.p.index_select(0, self._small_idx)
-            buf = torch.where(self._small_own, buf, torch.zeros_like(buf))
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            A.p.index_copy_(0, self._small_idx, buf)
 
     def gather_master(self) -> None:
         """assemble the full fp32 parameter and Adam-slot arenas on every rank from the per-rank shards (a collective: every rank
@@ -342,6 +337,8 @@ class ShardedDataParallelStep:
         A = self.engine.arena
         for t in (A.p, A.m, A.v):
             for k, (lo, hi) in enumerate(self.buckets):
+                if self.replicated(k):
+                    continue
                 slo, shi = self.shard(k)
                 dist.all_gather_into_tensor(t[lo:hi], t[slo:shi].clone(), group=self.group)
         self.engine._masters_sharded = False

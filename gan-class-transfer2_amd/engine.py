@@ -82,16 +82,27 @@ class ParamArena:
         self.shapes = topo.param_shapes()
         self.offsets: Dict[str, int] = {}
         off = 0
+        # Layout (r04): the convolution kernels first, in backward completion order (U_0 .. U_{n-1}, D_{n-1} .. D_0: a gradient bucket
+        # is a contiguous range), then ONE zone with every parameter the kernels read in FP32 straight from the master arena - the
+        # Dense(3) kernel and bias and all convolution biases (a few thousand floats).  A layer's fused optimizer launch covers its
+        # kernel; the zone gets one small launch once the last input gradient (the last writer of a bias gradient) is enqueued.  For
+        # the sharded data-parallel step this puts the fp32-read parameters into the LAST bucket, which is all-reduced and updated on
+        # every rank (replicated): no exchange of fp32 values, no second collective behind the last bucket (r03 needed both).
         self.layer_ranges: Dict[str, Tuple[int, int]] = {}
-        for layer in topo.layer_order():
+        convs = [l for l in topo.layer_order() if l != "dense"]
+        for layer in convs:
             lo = off
-            for suffix in (".w", ".b"):
-                name = layer + suffix
-                self.offsets[name] = off
-                off = _round_up(off + int(np.prod(self.shapes[name])), self.ALIGN)
+            self.offsets[layer + ".w"] = off
+            off = _round_up(off + int(np.prod(self.shapes[layer + ".w"])), self.ALIGN)
             self.layer_ranges[layer] = (lo, off)
+        zone_lo = off
+        for name in ["dense.w", "dense.b"] + [l + ".b" for l in convs]:
+            self.offsets[name] = off
+            off = _round_up(off + int(np.prod(self.shapes[name])), self.ALIGN)
+            if name == "dense.b":
+                self.layer_ranges["dense"] = (zone_lo, off)
         off = _round_up(off, 64 * self.ALIGN)       # the arena splits into equal 16-byte aligned shards for up to 64 ranks
-        self.layer_ranges[layer] = (self.layer_ranges[layer][0], off)
+        self.layer_ranges["fp32"] = (zone_lo, off)  # (contains the "dense" range)
         self.total = off
         z = lambda dt: torch.zeros(self.total, dtype=dt, device=device)
         self._p, self._m, self._v, self.g = z(torch.float32), z(torch.float32), z(torch.float32), z(torch.float32)
@@ -119,6 +130,13 @@ class ParamArena:
     @property
     def shadow(self) -> Optional[torch.Tensor]:
         self._sync(); return self._shadow
+
+    LAYOUT = 2        # bumped when the order of tensors inside the arenas changes (state_dict carries it)
+
+    def ready_order(self) -> List[str]:
+        """arena ranges in the order their gradients complete during the reverse pass: the convolution layers (each ready hook
+        fires when the layer's weight gradient is enqueued), then the fp32 zone (complete with the last input gradient)."""
+        return [l for l in self.topo.layer_order() if l != "dense"] + ["fp32"]
 
     def numel(self, name: str) -> int:
         return int(np.prod(self.shapes[name]))
@@ -241,7 +259,7 @@ class UNetEngine:
         # the parameters (arena properties, state_dict, predict, the sampler) flushes them first.  The slabs of a deferred layer must
         # outlive the step: such layers get a call context of their own (_defer_ctx) whose weight-gradient scratch nobody else uses.
         self.defer_adam = True
-        self.defer_layers = ("dense", "U0", "U1", "U2")
+        self.defer_layers = ("U0", "U1", "U2")
         self._pending: list = []
         self._pending_event = None
         self._pending_names: set = set()
@@ -298,15 +316,8 @@ class UNetEngine:
     def _launch_pending(self, stream: int) -> None:
         """the optimizer launches held back by the last step, in the order the fused step would have run them"""
         A = self.arena
-        for item in self._pending:
-            if item[0] == "range":
-                _, lo, hi, alpha = item
-                shadow = None if A._shadow is None else A._shadow.data_ptr() + 2 * lo
-                call("gct2_adam_keras_multi", A._p.data_ptr() + 4 * lo, A._m.data_ptr() + 4 * lo, A._v.data_ptr() + 4 * lo,
-                     A.g.data_ptr() + 4 * lo, shadow, self.dtype, hi - lo, alpha, self.beta_1, self.beta_2, self.epsilon, 1.0, None, 0, stream)
-            else:
-                _, layer, args = item
-                call("gct2_adam_apply", ctypes.addressof(args), A.gptr(layer + ".w"), A.numel(layer + ".w"), stream)
+        for _, layer, args in self._pending:
+            call("gct2_adam_apply", ctypes.addressof(args), A.gptr(layer + ".w"), A.numel(layer + ".w"), stream)
         self._pending = []
 
     def flush_deferred(self) -> None:
@@ -655,13 +666,6 @@ class UNetEngine:
             return c.handle
 
         keep: list = []
-        if adam_inline:
-            side_waits_main()                                   # the head (and its gradients) are done
-            if "dense" in deferred:
-                self._pending.append(("range", 0, A.layer_ranges["dense"][1], self.adam_alpha()))
-                self._pending_names.add("dense")
-            else:
-                self._apply_adam(0, A.layer_ranges["dense"][1], stream=sw)   # the head's parameters: nothing reads them any more
         for i in range(n):                                      # UpShuffle_i backward, outermost first
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
@@ -712,6 +716,14 @@ class UNetEngine:
 
             if adam_inline:
                 dgrad_d()
+            if i == 0:
+                # every input-gradient launch (the writers of the bias gradients) and the head are enqueued on the chain's stream: the
+                # fp32 zone - Dense(3) and all biases - is complete.  Its optimizer step is one small launch right here (nothing reads
+                # these parameters before the next forward pass); the data-parallel wrappers get their hook at the end instead.
+                if adam_inline:
+                    if not head_done and side is not main:      # UpShuffle_0's bias gradient came from its weight-gradient call (side stream)
+                        main.wait_stream(side)
+                    self._apply_adam(*A.layer_ranges["fp32"], stream=s)
             if i == 0 and adam_inline and side is not main and self.tail_on_chain and self.workspace is not None:
                 call("gct2_conv4s2_wgrad", self.ctx_tail.handle, dt, xw, ldxw, dz, lddz, A.gptr("D0.w"), None, b.B, H, W, t.cx(0),
                      t.fd(0), 0, fused("D0"), s)
@@ -727,6 +739,8 @@ class UNetEngine:
                 dgrad_d()
         if side is not main:
             main.wait_stream(side)
+        with torch.cuda.stream(main):                           # last hook: both streams' gradient writers are in front of it
+            self._ready("fp32")
         if main is not caller:
             caller.wait_stream(main)
 
@@ -850,16 +864,20 @@ class UNetEngine:
         A = self.arena
         sd = {"arena.p": A.p.cpu(), "arena.m": A.m.cpu(), "arena.v": A.v.cpu(),
               "counters": torch.tensor([self.iterations, self.rng_seed, self.rng_offset_t, self.rng_offset_eps], dtype=torch.int64),
-              "topology": torch.tensor([self.topo.pixel_size, self.topo.max_size, self.topo.octaves, A.total], dtype=torch.int64)}
+              "topology": torch.tensor([self.topo.pixel_size, self.topo.max_size, self.topo.octaves, A.total, A.LAYOUT], dtype=torch.int64)}
         if self.ls_state is not None:
             sd["loss_scale_state"] = self.ls_state.cpu()
         return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         A = self.arena
-        want = [self.topo.pixel_size, self.topo.max_size, self.topo.octaves, A.total]
-        if [int(v) for v in sd["topology"]] != want:
-            raise ValueError(f"checkpoint topology {[int(v) for v in sd['topology']]} != engine topology {want}")
+        want = [self.topo.pixel_size, self.topo.max_size, self.topo.octaves, A.total, A.LAYOUT]
+        have = [int(v) for v in sd["topology"]]
+        if len(have) == 4:
+            raise ValueError("checkpoint written with the r01-r03 arena layout ([kernel | bias] per layer); this engine keeps the biases and "
+                             "Dense(3) in one fp32 zone behind the kernels (ParamArena.LAYOUT = 2): re-export it by parameter name")
+        if have != want:
+            raise ValueError(f"checkpoint topology / layout {have} != engine {want}")
         if ("loss_scale_state" in sd) != (self.ls_state is not None):
             raise ValueError("checkpoint and engine disagree on dynamic loss scaling (mixed_precision, train.py:34)")
         for name in ("p", "m", "v"):

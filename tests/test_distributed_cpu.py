@@ -41,12 +41,12 @@ def _worker(rank, world, port, out_dir):
         A = ParamArena(topo, g.F32, torch.device("cpu"))
         for k, v in g_local.items():
             A.grad(k).copy_(torch.tensor(v, dtype=torch.float32))
-        red = BucketedAllReducer(A.g, topo.layer_order(), A.layer_ranges, bucket_elems=1500)
+        red = BucketedAllReducer(A.g, A.ready_order(), A.layer_ranges, bucket_elems=1500)
         assert red.world == world and len(red.buckets) >= 2
         assert red.buckets[0][0] == 0 and red.buckets[-1][1] == A.total
         assert all(red.buckets[i][1] == red.buckets[i + 1][0] for i in range(len(red.buckets) - 1))
         red.begin()
-        for layer in topo.layer_order():           # the order UNetEngine.backward fires its hook in
+        for layer in ["dense"] + A.ready_order():  # the order UNetEngine.backward fires its hook in
             red.grad_ready(layer)
         assert red.launched == len(red.buckets)
         for i in range(len(red.buckets)):
@@ -77,9 +77,9 @@ def test_single_process_reducer_is_a_noop():
     topo = g.Topology(8, 16, 2)
     A = ParamArena(topo, g.F32, torch.device("cpu"))
     A.g.fill_(3.0)
-    red = BucketedAllReducer(A.g, topo.layer_order(), A.layer_ranges)
+    red = BucketedAllReducer(A.g, A.ready_order(), A.layer_ranges)
     red.begin()
-    for layer in topo.layer_order():
+    for layer in ["dense"] + A.ready_order():
         red.grad_ready(layer)
     assert red.world == 1 and red.launched == 0 and red.wait_bucket(0) == red.buckets[0] and float(A.g.min()) == 3.0
 
@@ -129,7 +129,7 @@ class _CpuEngine:
             self.arena.grad(k).copy_(torch.tensor(v, dtype=torch.float32))
         if self.inject is not None:
             self.arena.g[self.inject[0]] = self.inject[1]
-        for layer in self.topo.layer_order():
+        for layer in ["dense"] + self.arena.ready_order():   # UNetEngine.backward: head, the layers, the fp32 zone last
             self.grad_ready_hook(layer)
         return loss
 
@@ -231,14 +231,17 @@ def _w4_worker(rank, world, port, out_dir):
         cfg = O.OracleConfig(**W4_CFG)
         topo = g.Topology(cfg.pixel_size, cfg.max_size, cfg.octaves)
         eng = _CpuEngine(cfg, topo, O.init_params(cfg, seed=21), dtype=g.BF16, loss_scaling=True)
-        dp = ShardedDataParallelStep(eng, bucket_elems=1000)
+        dp = ShardedDataParallelStep(eng, bucket_elems=1000, tail_layers=2)      # (tiny topology: DownShuffle_0 + the fp32 zone)
         A = eng.arena
         assert dp.world == 4 and dp.exchange and len(dp.buckets) >= 5
         layer_ends = {hi for _, hi in A.layer_ranges.values()}
         assert any(hi not in layer_ends for _, hi in dp.buckets[:-1])                  # buckets cut through layers
-        # the last bucket holds (about) the last two layers only: its exchange is the exposed tail of the step
-        tail_lo = A.layer_ranges[topo.layer_order()[-2]][0]
+        # the last bucket holds (about) the last layer and the fp32 zone only: its exchange is the exposed tail of the step.
+        # It is REPLICATED: all-reduced and updated on every rank, so the fp32-read parameters never need an exchange of their own
+        tail_lo = A.layer_ranges[A.ready_order()[-2]][0]
         assert dp.buckets[-1][1] == A.total and tail_lo - 4 * 64 < dp.buckets[-1][0] <= tail_lo
+        assert dp.replicated(len(dp.buckets) - 1) and dp.shard(len(dp.buckets) - 1) == dp.buckets[-1]
+        assert dp.buckets[-1][0] <= A.layer_ranges["fp32"][0] and not hasattr(dp, "_exchange_fp32_read_parameters")
         # an inf lands, at one step, in rank 2's LOCAL gradient at a position whose reduced value belongs to rank 1 (an interior
         # shard of a middle bucket): the owner's finite check + the 4-byte MAX all-reduce must make every rank skip
         k_mid = len(dp.buckets) // 2

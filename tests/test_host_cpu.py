@@ -126,11 +126,21 @@ def test_arena_layout_is_aligned_and_bucketable():
     import gan_class_transfer2_amd as g
     A = ParamArena(g.Topology(128, 512, 6), g.BF16, torch.device("cpu"))
     prev_hi = 0
-    for layer in A.topo.layer_order():
+    assert A.ready_order() == ["U0", "U1", "U2", "U3", "U4", "U5", "D5", "D4", "D3", "D2", "D1", "D0", "fp32"]
+    for layer in A.ready_order():
         lo, hi = A.layer_ranges[layer]
         assert lo == prev_hi and lo % 64 == 0          # contiguous, in backward order, 16-byte aligned in bf16
+        if layer != "fp32":                            # a layer's range is its kernel: what its fused optimizer launch covers
+            assert lo == A.offsets[layer + ".w"] and hi - lo >= A.numel(layer + ".w") > hi - lo - 64
         prev_hi = hi
     assert prev_hi == A.total and A.total >= 41_691_660
+    # every parameter the kernels read in fp32 from the master arena sits in ONE zone behind the kernels (r04): the replicated last
+    # bucket of the sharded data-parallel step, one small optimizer launch on a single GPU
+    zlo, zhi = A.layer_ranges["fp32"]
+    fp32_read = [k for k in A.shapes if k.endswith(".b") or k.startswith("dense.")]
+    assert len(fp32_read) == 14 and all(zlo <= A.offsets[k] and A.offsets[k] + A.numel(k) <= zhi for k in fp32_read)
+    assert all(A.offsets[k] + A.numel(k) <= zlo for k in A.shapes if k not in fp32_read)
+    assert A.layer_ranges["dense"][0] == zlo and zhi - zlo <= 64 * 64 + 8192
     A.glorot_init(1)
     w = A.param("U3.w")
     lim = np.sqrt(6.0 / (16 * 512 + 16 * 1024))
