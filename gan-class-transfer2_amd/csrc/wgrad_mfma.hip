@@ -202,7 +202,23 @@ __device__ __forceinline__ void dma16_hidden(__amdgpu_buffer_rsrc_t rsrc, char* 
 // carries into the next image row / image), tap validity from four precomputed per-lane flags; (b) the fragment addresses are
 // lane offsets computed ONCE, plus the stage's compile-time base; (c) ONE LDS array (the DMA is hidden inline asm, so hipcc has
 // nothing to drain); (d) a constant vmcnt in the steady state.  Same arithmetic in the same order: bit-identical results.
-template <typename T>
+//
+// r04, from the per-stage stamps of the diagnostic build (make stamp EXTRA=-DGCT2_PHASES, profiles/r04_wgrad_stage_phases.txt): a
+// stage of the r03 order took ~1750 cycles for 1024 cycles of multiplies per SIMD - ~450 cycles of address code + DMA issue at the
+// start in which NO wave of the CU multiplies (all 8 waves are in that phase together), then the older wave of every SIMD (waves
+// 0-3: they win the arbitration for the matrix core) is through its multiplies 300 cycles before its SIMD-mate and idles ~600
+// cycles at the barrier.  The memory system is not the limit (vmcnt wait: 8 cycles; every source byte from a 1-MiB window: -4 %),
+// nor is where the DMA pieces sit between the multiplies (three placements: +-1 %).  Two changes:
+//   TURNS    the two waves of a SIMD take turns.  Waves 0-3 read their 12 fragments, multiply, and issue their DMA pieces BEHIND their
+//            multiplies; waves 4-7 issue first and multiply second - one wave's address code + DMA issue runs under its SIMD-mate's
+//            multiplies.  All 24 fragment reads of a stage are issued up front (48 registers) and the 32 multiplies follow back to
+//            back, so the wave that has the matrix core to itself never waits for LDS between rows.
+//   ALIGNED  a 32-row stage that never leaves one image and starts at a multiple of its width or spans whole rows (Ws % 32 == 0, or
+//            32 % Ws == 0 and Hs % (32 / Ws) == 0: every layer of the reference topology that takes this kernel) sits at the same
+//            place for every lane: the position counters, the stage's byte offsets and its border bits are scalar, a lane adds a
+//            constant offset and tests constant flags - 8 vector instructions per stage instead of ~45.
+// Same sources, same zero fill, same multiplies in the same order: bit-identical to the r03 order (which other shapes keep).
+template <typename T, bool TURNS, bool ALIGNED>
 __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
   constexpr int NST = 5;
   constexpr int IMG = 32 * 256;                                   // one T image of a stage: 32 r-rows x 128 columns
@@ -289,6 +305,48 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
     rh -= ch ? Hs : 0; rb += ch ? 1 : 0;
   };
 
+  // ---- ALIGNED: lane constants, scalar stage position
+  const int span_w = min(32, Ws), span_h = max(1, 32 / Ws);
+  const int l_rw = row0 % span_w, l_dh = row0 / span_w;
+  unsigned cbig[2], csml[2], eflag[2];
+  unsigned long long ms_never[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    cbig[g] = (unsigned)((2 * l_dh * Wb + 2 * l_rw) * ldb2 + dg[g]);
+    csml[g] = (unsigned)(row0 * lds2b + (cs0 + lc * 8) * 2 + g * 256);
+    // bit 0: top tap on the stage's first image row, 1: bottom tap on its last, 2: left tap in its first column, 3: right tap in its
+    // last, 4: tap / channel block out of range (always masked), 5: set in every lane (a stage beyond the last row masks all)
+    eflag[g] = ((edge[g] & 1u) && l_dh == 0 ? 1u : 0u) | ((edge[g] & 2u) && l_dh == span_h - 1 ? 2u : 0u) | ((edge[g] & 4u) && l_rw == 0 ? 4u : 0u) |
+               ((edge[g] & 8u) && l_rw == span_w - 1 ? 8u : 0u) | (edge[g] & 16u) | 32u;
+    ms_never[g] = __builtin_amdgcn_ballot_w64(s_bad[g] != 0);
+  }
+  int u_rs = st_lo * 32;                                           // first row of the stage to issue next and where it sits: all uniform
+  int u_w = u_rs % Ws, u_h, u_b;
+  { const int t = u_rs / Ws; u_h = t % Hs; u_b = t / Hs; }
+  unsigned u_pix = (unsigned)(((u_b * Hb + 2 * u_h) * Wb + 2 * u_w) * ldb2), u_soff = (unsigned)(u_rs * lds2b);
+  auto issue_aligned = [&](char* base) {
+    const bool beyond = u_rs >= R;
+    const unsigned s_pos = (u_h == 0 ? 1u : 0u) | (u_h + span_h == Hs ? 2u : 0u) | (u_w == 0 ? 4u : 0u) | (u_w + span_w == Ws ? 8u : 0u) | 16u | (beyond ? 32u : 0u);
+    const unsigned long long all = beyond ? ~0ull : 0ull;
+    char* piece = base + wave * 1024;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const bool badb = (eflag[g] & s_pos) != 0u;
+      const bool bads = __builtin_amdgcn_inverse_ballot_w64(all | ms_never[g]);
+      dma16_hidden(rs_b, piece + g * IMG, badb ? OOB : u_pix + cbig[g]);
+      dma16_hidden(rs_s, piece + (2 + g) * IMG, bads ? OOB : u_soff + csml[g]);
+    }
+    u_rs += 32; u_soff += (unsigned)(32 * lds2b);
+    u_w += adv_w; u_pix += (unsigned)pixA;
+    if (u_w >= Ws) { u_w -= Ws; u_h++; u_pix += (unsigned)pixB; }
+    u_h += adv_h; u_b += adv_b; u_pix += (unsigned)pixCD;
+    if (u_h >= Hs) { u_h -= Hs; u_b++; }
+  };
+  auto issue_x = [&](char* base) {
+    if constexpr (ALIGNED) issue_aligned(base);
+    else issue(base);
+  };
+
   f32x4_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; i++)
@@ -334,25 +392,70 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
   };
   auto stage = [&](int st, const char* cur, char* tgt) {
     const bool more = st + NST - 1 < st_hi;                        // block-uniform
-    if (more) issue(tgt);
+    if (more) issue_x(tgt);
     if (live) compute(cur);
     if (more) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(3 * NDMA));   // steady state: stages st+2 .. st+4 stay in flight
     else wait_tail(st_hi - 1 - (st + 1));
     __builtin_amdgcn_s_barrier();
   };
   GCT2_CLOCK_BEGIN;
-  issue(lds);
-  if (st_lo + 1 < st_hi) issue(lds + STAGE);
-  if (st_lo + 2 < st_hi) issue(lds + 2 * STAGE);
-  if (st_lo + 3 < st_hi) issue(lds + 3 * STAGE);
+  issue_x(lds);
+  if (st_lo + 1 < st_hi) issue_x(lds + STAGE);
+  if (st_lo + 2 < st_hi) issue_x(lds + 2 * STAGE);
+  if (st_lo + 3 < st_hi) issue_x(lds + 3 * STAGE);
   wait_tail(min(st_lo + 3, st_hi - 1) - st_lo);
   __builtin_amdgcn_s_barrier();
   // steady state: every stage of the trip still has a stage to issue (st + 4 + 4 < st_hi): no tail logic, one constant wait
+#if defined(GCT2_STAMP) && defined(GCT2_PHASES)
+  // cycles per steady-state stage by phase (every stamp waits for its own value - the compiler may copy an asm output at once; in
+  // the TURNS order no LDS read is outstanding at any stamp but [1]'s end, which waits for the reads anyway):
+  // [0] issue block in front of the multiplies, [1] fragment reads until their data is there, [2] the 32 multiplies issued,
+  // [3] issue block behind the multiplies, [4] vmcnt wait, [5] barrier, [7] stages
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, nstages = 0;
+  auto now = [&]() -> unsigned long long {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  };
+#define GCT2_PH(x) x
+#else
+#define GCT2_PH(x)
+#endif
   auto stage_fast = [&](const char* cur, char* tgt) {
-    issue(tgt);
-    if (live) compute(cur);
+    const bool front = TURNS ? wm != 0 : true;                     // issue block in front of the multiplies (else behind them)
+    GCT2_PH(const unsigned long long t0 = now(); unsigned long long t2 = 0;)
+    if (front) issue_x(tgt);
+    GCT2_PH(const unsigned long long t1 = now();)
+    __builtin_amdgcn_sched_barrier(0);
+    if (live) {
+      if constexpr (TURNS) {
+        u32x4_t sf[4], bf[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) sf[j] = frag(cur, sf_off[j]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) bf[i] = frag(cur, bf_off[i]);
+        __builtin_amdgcn_sched_barrier(0);                         // all 24 reads in flight before the first multiply
+        GCT2_PH(t2 = now();)
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(sf[j], bf[i], acc[i][j]);
+      } else {
+        GCT2_PH(t2 = t1;)
+        compute(cur);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    GCT2_PH(const unsigned long long t3 = now();)
+    if (!front) issue_x(tgt);
+    GCT2_PH(const unsigned long long t4 = now();)
     __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(3 * NDMA));
+    GCT2_PH(const unsigned long long t5 = now();)
     __builtin_amdgcn_s_barrier();
+    GCT2_PH(const unsigned long long t6 = now();
+            ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; ph[5] += t6 - t5; nstages++;)
   };
   int st = st_lo;
   for (; st + 8 < st_hi; st += 5) {
@@ -375,6 +478,13 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
   }
 #ifdef GCT2_STAMP
   GCT2_CLOCK_END(p.clock ? p.stamps : nullptr, 8, wave, lane);
+#ifdef GCT2_PHASES
+  if (p.clock && lane == 0 && (size_t)blockIdx.x * 8 + wave < ((size_t)1 << 15)) {       // phase region of the stamp buffer (scripts/stamp_clock.py)
+    unsigned long long* o = p.stamps + ((size_t)1 << 18) + ((size_t)blockIdx.x * 8 + wave) * 8;
+    for (int k = 0; k < 6; k++) o[k] = ph[k];
+    o[6] = 0; o[7] = nstages;
+  }
+#endif
 #endif
   float* __restrict__ out = p.ws ? p.ws + (size_t)split * GC * Cs : p.dw;
   const int mode = p.ws ? 2 : (p.rsplit == 1 ? 1 : 0);
@@ -485,7 +595,7 @@ int wgrad_mfma(gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs*
   const int tiles256 = ((taps * p.Cb + 255) / 256) * ((p.Cs + 255) / 256);
   const int minsteps = tiles128 < 256 ? 4 : 8;
   const int blocks256 = tiles256 * std::max(1, std::min((256 + tiles256 - 1) / tiles256, steps_total / minsteps));
-  const bool big_tile = !p.ks && (variant == 2 || (variant == 0 && tiles128 < 512 && blocks256 >= 192));
+  const bool big_tile = !p.ks && (variant == 2 || variant == 4 || (variant == 0 && tiles128 < 512 && blocks256 >= 192));
   const int tiles = big_tile ? tiles256 : tiles128;
   // pixel splits: ~256 work-groups for the big tile; ~768 (3 per CU) for the small one, one owner per tile once the tiles alone
   // give every CU two work-groups, two splits in between; always >= 4 steps of 64 rows per split
@@ -512,13 +622,20 @@ int wgrad_mfma(gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs*
   if (!p.ws && rsplit > 1 && !p.accumulate) {     // atomics add into the target: start it from zero
     (void)hipMemsetAsync(p.dw, 0, n * sizeof(float), s);
   }
-  gct2_log(c, "wgrad:%s:rsplit=%d:%s", p.ks ? "s1" : (big_tile ? "256q" : "128"), rsplit, p.ws ? "slabs" : (rsplit == 1 ? "owner" : "atomics"));
+  gct2_log(c, "wgrad:%s:rsplit=%d:%s", p.ks ? "s1" : (big_tile ? (variant == 4 ? "256q-r03" : "256q") : "128"), rsplit, p.ws ? "slabs" : (rsplit == 1 ? "owner" : "atomics"));
   if (p.ks) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad_kernel<__bf16, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<_Float16, true>), grid, dim3(256), 0, s, p);
   } else if (big_tile) {
-    if (dtype == GCT2_BF16) hipLaunchKernelGGL(wgrad256q_kernel<__bf16>, grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL(wgrad256q_kernel<_Float16>, grid, dim3(512), 0, s, p);
+    // stage-aligned geometry -> scalar address code and waves taking turns (see the kernel); other shapes keep the r03 stage order
+    const bool aligned = (p.Ws % 32 == 0 || (32 % p.Ws == 0 && p.Hs % (32 / p.Ws) == 0)) && variant != 4;
+    if (dtype == GCT2_BF16) {
+      if (aligned) hipLaunchKernelGGL((wgrad256q_kernel<__bf16, true, true>), grid, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((wgrad256q_kernel<__bf16, false, false>), grid, dim3(512), 0, s, p);
+    } else {
+      if (aligned) hipLaunchKernelGGL((wgrad256q_kernel<_Float16, true, true>), grid, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((wgrad256q_kernel<_Float16, false, false>), grid, dim3(512), 0, s, p);
+    }
   } else {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad_kernel<__bf16>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<_Float16>), grid, dim3(256), 0, s, p);

@@ -24,6 +24,7 @@ ap.add_argument("--pmc", type=int, default=0)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--no-planes", action="store_true")
+ap.add_argument("--zeros", action="store_true", help="replay on all-zero activations, gradients and weights (the DVFS test of MI355X_MICROARCH.md: same instruction stream, no operand toggling)")
 args = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -109,6 +110,13 @@ for name, a in rec:
         calls.append((name, a, pending))
         pending = None
 only = [s for s in args.only.split(",") if s]
+if args.zeros:
+    for v in vars(b).values():
+        for t in (v if isinstance(v, (list, tuple)) else [v]):
+            if torch.is_tensor(t) and t.is_floating_point():
+                t.zero_()
+    eng.arena._shadow.zero_()
+    torch.cuda.synchronize()
 
 
 def replay(name, a, plane):

@@ -20,6 +20,7 @@ from gan_class_transfer2_amd import _lib, engine as engine_mod
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=2.0)
+ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0)
 ap.add_argument("--layers", default="U0.wgrad,U1.wgrad,D1.wgrad,U1.fwd,U2.fwd,D1.dgrad,D2.dgrad,U0.dgrad,U1.dgrad,U2.dgrad,D1.fwd,D2.fwd,U3.fwd,U3.dgrad,D3.dgrad,U3.wgrad")
 args = ap.parse_args()
 assert _lib.build_flags() & _lib.BUILD_STAMP, "needs the diagnostic build: make -C gan-class-transfer2_amd/csrc stamp"
@@ -28,6 +29,8 @@ dev = torch.device("cuda", 0)
 B, S = 64, 128
 eng = g.UNetEngine(g.Topology(128, 512, 6), g.BF16, dev)
 eng.overlap = False
+if args.tuning:
+    eng.ctx.set_tuning(args.tuning)
 x = (torch.randint(0, 256, (B, S, S, 3)).float() / 128 - 1).to(dev)
 for _ in range(2):
     eng.train_step(x, apply=False)                 # random data everywhere: activations and gradients of a real step
@@ -121,5 +124,14 @@ for lab in [s for s in args.layers.split(",") if s]:
     per_wave = fl / nwaves
     resident = min(nwaves, 256 * 16 if "256x128" in kern else 256 * 8)     # waves resident at once: two 8-wave groups per CU, else 8 waves per CU
     rate = per_wave / (np.median(loop_us) * 1e-6) * resident / 1e15
+    ph = stamps[1 << 18:(1 << 18) + 8 * (1 << 15)].cpu().numpy().reshape(-1, 8)
+    grp = (np.arange(len(ph)) % 8) // 4            # wave group of the entry (8 waves per work-group: waves 0-3 / 4-7 share SIMDs pairwise)
+    for gsel in (0, 1):                            # make stamp EXTRA=-DGCT2_PHASES: cycles per steady-state stage, by phase (mean over waves)
+        q = ph[(ph[:, 7] > 0) & (grp == gsel)]
+        if len(q):
+            per = q[:, :6] / q[:, 7:8]
+            m = per.mean(axis=0)
+            print(f"{lab:12s} waves {4 * gsel}-{4 * gsel + 3}: issue (front) {m[0]:5.0f} | reads {m[1]:5.0f} | 32 MFMA {m[2]:5.0f} | issue (behind) {m[3]:5.0f} | "
+                  f"vmcnt wait {m[4]:4.0f} | barrier {m[5]:5.0f} | sum {m.sum():6.0f} cycles per stage ({int(q[:, 7].mean())} stages per wave)")
     print(f"{lab:12s} {kern:42s}  {np.median(clk):5.3f} {np.percentile(clk, 10):5.3f} {np.percentile(clk, 90):5.3f}      "
           f"{np.median(setup_us):6.2f} / {np.median(loop_us):7.2f} / {np.median(epi_us):6.2f}   {nwaves:6d}   {rate:6.3f}   {span:7.1f}   {us_launch:7.1f}")

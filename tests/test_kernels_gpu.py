@@ -252,6 +252,40 @@ def test_wgrad_tile_variants(gpu, variant, shape, use_ws):
         set_ws(None)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 256), (3, 32, 32, 72, 136), (5, 16, 16, 128, 64), (2, 128, 64, 64, 64), (3, 40, 24, 64, 128)])
+def test_wgrad_turns_and_scalar_addresses_equal_r03_order_bit_for_bit(gpu, shape):
+    """r04 stage order of the 256x256 weight-gradient tile (the two waves of a SIMD take turns between DMA issue and multiplies; stage
+    position, offsets and border bits in SGPRs where a 32-row stage is aligned with the image rows) against the r03 order (tuning
+    16-23 = 4): same sources, same zero fill, same multiplies in the same order, hence the same bits - grids of 64 / 32 / 16 / 8
+    columns (stage = part of a row, one row, 2 and 4 rows), ragged channel counts, several images per split, and one shape that is
+    not aligned (both tunings then run the r03 order)."""
+    B, H, W, Cin, Cout = shape
+    dt, L = BF16, lib()
+    rng = np.random.default_rng(71)
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+    dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+    xd, dzd, dztd = dev(x, dt, gpu), dev(dz, dt, gpu), dev(dzt, dt, gpu)
+    ws = torch.empty(64 << 18, dtype=torch.float32, device=gpu)
+    set_ws(ws)
+    res = {}
+    try:
+        for variant in (2, 4):
+            set_tuning(variant << 16)
+            dw = torch.full((4, 4, Cin, Cout), float("nan"), dtype=torch.float32, device=gpu)
+            dwt = torch.full((4, 4, Cout, Cin), float("nan"), dtype=torch.float32, device=gpu)
+            L.call("gct2_conv4s2_wgrad", ctx(), dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
+            L.call("gct2_convT4s2_wgrad", ctx(), dt, xd.data_ptr(), Cin, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
+            torch.cuda.synchronize()
+            res[variant] = (dw, dwt)
+        assert torch.equal(res[2][0], res[4][0]) and torch.equal(res[2][1], res[4][1])
+        assert rel_l2(res[2][0].cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
+        assert rel_l2(res[2][1].cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
+    finally:
+        set_tuning(0)
+        set_ws(None)
+
+
 @pytest.mark.parametrize("variant", [2, 3])
 @pytest.mark.parametrize("shape", [(3, 40, 24, 64, 128), (5, 8, 8, 128, 64), (2, 64, 64, 64, 256), (7, 4, 12, 256, 72)])
 def test_wgrad_incremental_gather_addresses(gpu, shape, variant):
