@@ -97,8 +97,10 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = LIB_PATH
-    if os.environ.get("GCT2_ALLOW_DIAGNOSTIC_BUILD") == "1" and os.environ.get("GCT2_USE_STAMP_LIB") == "1":
-        path = os.path.join(_HERE, "csrc", "libgct2_stamp.so")        # `make -C csrc stamp`: the diagnostic build beside the product one
+    if os.environ.get("GCT2_ALLOW_DIAGNOSTIC_BUILD") == "1" and os.environ.get("GCT2_USE_STAMP_LIB") in ("1", "phases"):
+        # `make -C csrc stamp` / `make -C csrc phases`: the diagnostic builds beside the product one (clock + work-group phases / the
+        # same plus per-stage phase stamps inside wgrad256q_kernel's K loop, which slow that loop by a few percent)
+        path = os.path.join(_HERE, "csrc", "libgct2_phases.so" if os.environ["GCT2_USE_STAMP_LIB"] == "phases" else "libgct2_stamp.so")
     if not os.path.exists(path):
         raise Gct2Error(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

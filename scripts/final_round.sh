@@ -5,6 +5,13 @@ tail -c 600 gpurun_out/bench_default.json
 bash scripts/profile_round.sh > gpurun_out/profile_round.log 2>&1 || true
 python scripts/stamp_clock.py --seconds 2.0 --layers U0.wgrad,U1.wgrad,U2.wgrad,D1.wgrad,D2.wgrad,D3.wgrad,U0.fwd,U1.fwd,U2.fwd,D1.dgrad,D2.dgrad,U0.dgrad,U1.dgrad,U2.dgrad,D1.fwd,D2.fwd,D3.fwd,U3.fwd,U3.dgrad,D3.dgrad,U3.wgrad,U4.wgrad > gpurun_out/kernel_clock.txt 2>&1
 python scripts/engine_layers.py > gpurun_out/layers.txt 2>&1
+python scripts/engine_layers.py --zeros > gpurun_out/layers_zero_data.txt 2>&1
+( echo "# per-stage phases of wgrad256q_kernel's steady-state K loop (diagnostic build: make phases; cycles per 32-row stage, mean over the waves of a group)"
+  echo "## r04 order: waves take turns, reads up front, scalar stage position (tuning 0)"
+  python scripts/stamp_clock.py --phases --seconds 0.5 --layers U0.wgrad,U1.wgrad,U2.wgrad,D1.wgrad,D2.wgrad,D3.wgrad | grep -v amdgpu.ids
+  echo "## r03 order (tuning bits 16-23 = 4)"
+  python scripts/stamp_clock.py --phases --tuning 0x40000 --seconds 0.5 --layers U0.wgrad,U1.wgrad,U2.wgrad,D1.wgrad,D2.wgrad,D3.wgrad | grep -v "amdgpu.ids\|^#" ) > gpurun_out/wgrad_stage_phases.txt 2>&1 || true
+tests/hw_probe/probe_power > gpurun_out/probe_power.txt 2>&1 || true
 python bench.py --size 256 --batch 16 --dtype f16 --no-cpu-baseline > gpurun_out/bench_config5.json 2>/dev/null
 python bench.py --size 64 --batch 32 --no-cpu-baseline > gpurun_out/bench_config2.json 2>/dev/null
 python scripts/bench_dp_overhead.py 30 > gpurun_out/dp_overhead.txt 2>&1 || true

@@ -11,7 +11,7 @@ the loop, and the whole launch for comparison.
 """
 import argparse, os, sys
 os.environ["GCT2_ALLOW_DIAGNOSTIC_BUILD"] = "1"
-os.environ["GCT2_USE_STAMP_LIB"] = "1"
+os.environ["GCT2_USE_STAMP_LIB"] = "phases" if "--phases" in sys.argv else "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -21,6 +21,7 @@ from gan_class_transfer2_amd import _lib, engine as engine_mod
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=2.0)
 ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0)
+ap.add_argument("--phases", action="store_true", help="load libgct2_phases.so (make phases): per-stage phase stamps of wgrad256q_kernel")
 ap.add_argument("--layers", default="U0.wgrad,U1.wgrad,D1.wgrad,U1.fwd,U2.fwd,D1.dgrad,D2.dgrad,U0.dgrad,U1.dgrad,U2.dgrad,D1.fwd,D2.fwd,U3.fwd,U3.dgrad,D3.dgrad,U3.wgrad")
 args = ap.parse_args()
 assert _lib.build_flags() & _lib.BUILD_STAMP, "needs the diagnostic build: make -C gan-class-transfer2_amd/csrc stamp"
@@ -126,7 +127,8 @@ for lab in [s for s in args.layers.split(",") if s]:
     rate = per_wave / (np.median(loop_us) * 1e-6) * resident / 1e15
     ph = stamps[1 << 18:(1 << 18) + 8 * (1 << 15)].cpu().numpy().reshape(-1, 8)
     grp = (np.arange(len(ph)) % 8) // 4            # wave group of the entry (8 waves per work-group: waves 0-3 / 4-7 share SIMDs pairwise)
-    for gsel in (0, 1):                            # make stamp EXTRA=-DGCT2_PHASES: cycles per steady-state stage, by phase (mean over waves)
+    for gsel in (0, 1):                            # --phases (make phases): cycles per steady-state stage of wgrad256q_kernel, by phase (mean over the waves of a group;
+                                                   # r03 order: reads and multiplies interleave, both are in the '32 MFMA' column)
         q = ph[(ph[:, 7] > 0) & (grp == gsel)]
         if len(q):
             per = q[:, :6] / q[:, 7:8]
