@@ -260,6 +260,7 @@ class UNetEngine:
         # outlive the step: such layers get a call context of their own (_defer_ctx) whose weight-gradient scratch nobody else uses.
         self.defer_adam = True
         self.defer_layers = ("U0", "U1", "U2")
+        self.defer_window_at = 3          # the held-back launches start once DownShuffle_<this> of the next forward pass is enqueued
         self._pending: list = []
         self._pending_event = None
         self._pending_names: set = set()
@@ -462,7 +463,7 @@ class UNetEngine:
         if not in_step:
             self.flush_deferred()                              # (a captured graph, the sampler, predict: no side-stream work in here)
         cur = torch.cuda.current_stream(self.device)
-        window_at = min(3, n - 1)                               # deferred Adam starts once DownShuffle_{window_at} is enqueued
+        window_at = min(self.defer_window_at, n - 1)            # deferred Adam starts once DownShuffle_{window_at} is enqueued
 
         def join_pending() -> None:                             # the deferred updates are done before their weights are read
             if self._pending_event is not None:
