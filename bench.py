@@ -4,12 +4,15 @@ backward -> [RCCL all-reduce] -> Keras Adam) on synthetic 3x128x128 batches, bs 
 fp32 accumulation (BASELINE.json config 3; config 4 when launched on N > 1 GPUs).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...          # starts its N ranks itself (one process per GPU, before this process touches a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel family (HIP events around every launch of
-the three MFMA kernel families inside the timed region); `step_roofline_frac` is the whole step against the
-2.5 PFLOP/s dense bf16 MFMA peak (F_train = 32.1314 GFLOP/image at 128^2).
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant KERNEL SYMBOL by summed time (HIP events on the launching stream
+around every layer call of 4 extra single-stream steps, the kernel each call selected taken from the library's launch log; its own
+algorithmic FLOPs / its own average duration); `kernels` keeps the per-family table, `kernel_symbols` the per-symbol one;
+`roofline.step_frac` (= `step_roofline_frac`) is the whole step against the 2.5 PFLOP/s dense bf16 MFMA peak (SURVEY.md §8d:
+F_train = 32.1314 GFLOP/image at 128^2).
 `cpu_baseline` times oracle/torch_cross.py (a CPU restatement of train.py - TensorFlow is not installable here) on
 the host cores, rank 0, N = 1 only.
 """
@@ -55,32 +58,73 @@ def f_train_per_image(topo, H, W):
     return sum(f.values())
 
 
+def call_flops(name, a):
+    """algorithmic FLOPs (2*M*N*K, padding taps counted) of one layer call; argument positions as in include/gct2.h"""
+    if name == "gct2_convT4s2_fwd_head_train":
+        Bn, H, W, Cin, Cout = a[15:20]
+        return 2.0 * Bn * 4 * H * W * Cout * 4 * Cin
+    off = 9 if name.endswith("dgrad") else 8
+    Bn, H, W, Cin, Cout = a[off:off + 5]
+    # conv4s2_*: H, W = the big grid, (H/2)(W/2) * 16 Cin = H W 4 Cin; convT4s2_*: H, W = the small grid, 4 H W * 4 Cin
+    return 2.0 * Bn * H * W * Cout * (16 * Cin if name.startswith("gct2_convT") else 4 * Cin)
+
+
+def call_label(name, a):
+    """("U2", "dgrad") ... of a layer call: level from the channel counts of the reference topology is ambiguous, so from the grid: the
+    level of a layer is log2(image height / its big-grid height), the image height is the largest big grid seen (set by bench main)"""
+    kind = "U" if name.startswith("gct2_convT") else "D"
+    what = "fwd" if "fwd" in name else ("dgrad" if name.endswith("dgrad") else "wgrad")
+    h = a[16] if name == "gct2_convT4s2_fwd_head_train" else a[10 if what == "dgrad" else 9]
+    big = 2 * h if kind == "U" else h
+    return (f"{kind}{(call_label.size // big).bit_length() - 1}", what)
+
+
+call_label.size = 128
+
+
+def kernel_symbol(token):
+    """launch-log token (include/gct2.h gct2_ctx_log_launches) -> the kernel symbol rocprofv3 lists for it"""
+    t = token.split(":")
+    if t[0] == "wgrad":
+        return "wgrad256q_kernel" if t[1].startswith("256") else "wgrad_kernel"
+    if t[0] == "tap":
+        return f"tapgemm_kernel<{t[1]},{t[2]}>"
+    if t[0] == "deep":
+        return f"deepgemm_kernel<{t[1]}>"
+    if t[0] == "halo":
+        return "halo_convT_kernel<head>" if "head" in t else "halo_convT_kernel"
+    if t[0] == "rgb":
+        return f"rgb_{t[1]}_kernel"
+    return token
+
+
 class KernelTimer:
-    """HIP events on the stream each kernel is launched on, per kernel family."""
+    """HIP events on the stream each layer call is launched on; per call: family, kernel symbol (launch log), FLOPs."""
 
     FAMILY = {
         "gct2_conv4s2_fwd": "conv_form", "gct2_convT4s2_dgrad": "conv_form",
-        "gct2_convT4s2_fwd": "convT_form", "gct2_conv4s2_dgrad": "convT_form",
+        "gct2_convT4s2_fwd": "convT_form", "gct2_conv4s2_dgrad": "convT_form", "gct2_convT4s2_fwd_head_train": "convT_form",
         "gct2_conv4s2_wgrad": "wgrad", "gct2_convT4s2_wgrad": "wgrad",
     }
 
     def __init__(self):
-        self.events = []      # (family, start, end) of the steps inside the timed region (two streams: in-situ durations)
+        self.events = []      # (family, symbol, flops, start, end) of the steps with two streams: in-situ durations
         self.isolated = []    # the same from the serial-stream steps run after the timed region (one kernel at a time)
         self.sink = self.events
         self.streams = {}     # raw stream handle -> torch stream object
         self.enabled = False
+        self.split_adam = False   # isolated leg: the fused optimizer launch of a weight-gradient call is issued BEHIND the end event
+        self.ctxs = {}            # ctx handle -> _lib.Context (launch logs)
 
-    def install(self, engine_module, lib_module):
+    def install(self, engine_module, lib_module, contexts):
+        import ctypes
         orig = lib_module.call
         timer = self
+        for c in contexts:
+            self.ctxs[c.handle] = c
 
         def timed_call(name, *args):
             fam = timer.FAMILY.get(name) if timer.enabled else None
-            # D0 (Cin = 3) runs the direct kernel: keep it out of the MFMA families
-            if fam is not None and ((name == "gct2_conv4s2_fwd" and args[-4] == 3) or
-                                    (name == "gct2_conv4s2_wgrad" and args[-5] == 3)):
-                fam = None
             if fam is None:
                 return orig(name, *args)
             # events go on the stream the kernel is launched on (the last argument): the weight gradients run on the engine's
@@ -89,20 +133,79 @@ class KernelTimer:
             st = timer.streams.get(h)
             if st is None:
                 st = timer.streams[h] = torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream()
+            ctx = timer.ctxs.get(args[0])
+            adam = None
+            if timer.split_adam and fam == "wgrad" and args[-2]:
+                # the engine's deferral mechanism (gct2_adam_args.defer + gct2_adam_apply: the same launch, the same bits), used here so
+                # that the events bracket the weight-gradient kernel alone
+                adam = lib_module.AdamArgs.from_address(int(args[-2]))
+                if adam.defer:
+                    adam = None                      # (already deferred by the engine)
+                else:
+                    adam.defer = 1
+            if ctx is not None:
+                ctx.log_launches(True)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(st)
             orig(name, *args)
             e.record(st)
-            timer.sink.append((fam, s, e))
+            if adam is not None:
+                adam.defer = 0
+                orig("gct2_adam_apply", int(args[-2]), args[6], 16 * args[11] * args[12], args[-1])
+            toks = [t for t in (ctx.read_launch_log() if ctx is not None else []) if not t.startswith("relu_bits")]
+            if ctx is not None:
+                ctx.log_launches(False)
+            sym = kernel_symbol(toks[0]) if toks else name
+            timer.sink.append(("other" if sym.startswith("rgb") else fam, sym, call_flops(name, args), s, e, call_label(name, args)))
 
         engine_module.call = timed_call
 
-    def summary(self, events):
-        tot, cnt = {}, {}
-        for fam, s, e in events:
-            tot[fam] = tot.get(fam, 0.0) + s.elapsed_time(e) * 1e-3
-            cnt[fam] = cnt.get(fam, 0) + 1
-        return tot, cnt
+    @staticmethod
+    def table(events, nsteps, key):
+        tot, cnt, fl = {}, {}, {}
+        for ev in events:
+            k = ev[key]
+            tot[k] = tot.get(k, 0.0) + ev[3].elapsed_time(ev[4]) * 1e-3
+            cnt[k] = cnt.get(k, 0) + 1
+            fl[k] = fl.get(k, 0.0) + ev[2]
+        rows = {k: {"launches_per_step": cnt[k] // nsteps, "ms_per_step": round(tot[k] / nsteps * 1e3, 4),
+                    "gflop_per_launch": round(fl[k] / cnt[k] / 1e9, 3), "avg_launch_us": round(tot[k] / cnt[k] * 1e6, 2),
+                    "tflops": round(fl[k] / tot[k] / 1e12, 2)} for k in tot}
+        return tot, cnt, fl, rows
+
+
+def pmc_evidence(layers, default_config):
+    """(traffic bytes per launch, source, mfma utilisation, source) of the launches `layers` = {("U0", "wgrad"), ...} (the calls of this
+    run that selected the dominant kernel) from the newest committed PMC files over the engine's own launches"""
+    import glob
+    if not default_config or not layers:
+        return None, None, None, None
+    traffic = tsrc = util = usrc = None
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_per_layer.json")))
+    tfiles = [f for f in tfiles if "before" not in f]
+    if tfiles:
+        with open(tfiles[-1]) as f:
+            rows = json.load(f)["layers"]
+        sel = [r for r in rows if (r["layer"], r["dir"].split("+")[0]) in layers]
+        if sel:
+            traffic = sum(r["read_MB"] + r["write_MB"] for r in sel) * 1e6 / len(sel)
+            tsrc = (f"profiles/{os.path.basename(tfiles[-1])}: mean over the {len(sel)} launches of this kernel in the ENGINE'S OWN step (its strides, "
+                    "bit planes, dispatch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections; committed file - not this run)")
+    ufiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.txt")))
+    if ufiles:
+        busy = cyc = 0.0
+        with open(ufiles[-1]) as f:
+            for line in f:
+                c = line.split()
+                if line.startswith(("#", "lay")) or len(c) < 8:
+                    continue
+                if (c[0], c[1].split("+")[0]) in layers:
+                    busy += float(c[-5]); cyc += float(c[-3])
+        if cyc:
+            util = busy / (1024 * cyc)
+            usrc = (f"profiles/{os.path.basename(ufiles[-1])}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) summed over this kernel's "
+                    "launches in the engine's own step (rocprofv3 --pmc; committed file - not this run)")
+    return traffic, tsrc, util, usrc
 
 
 def host_cores() -> int:
@@ -141,6 +244,58 @@ def cpu_baseline(topo_kw, size, batch, steps, warmup, budget_s=25.0):
     return batch * done / dt, dt / done, done
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher in front of it: start the N ranks (one process per GPU) as ONE child -
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same
+    arguments>` - BEFORE this process has made any GPU call (nothing here initialises HIP; the parent never does), relay rank 0's
+    JSON line and return the child's exit code.  A failed rank makes the child, hence this process, exit non-zero."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without a result line\n")
+        rc = 1
+    return rc
+
+
+def launcher_selftest(args, world: int, rank: int) -> int:
+    """GCT2_BENCH_LAUNCH_TEST=1 (tests/test_host_cpu.py, no GPU): the rank side of the launch contract without the workload - gloo
+    rendezvous from the launcher's environment, barrier, MAX over ranks of a per-rank time, ONE JSON line from rank 0.  Never a
+    measurement: `value` is 0 and `data` says so."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("GCT2_BENCH_LAUNCH_TEST_FAIL_RANK") == str(rank):
+        return 3                                            # a failing rank: the launcher must report it (test)
+    dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test", "value": 0.0, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": args.dtype, "data": "none (GCT2_BENCH_LAUNCH_TEST: launch contract only, no GPU work)",
+                          "max_over_ranks": float(t[0])}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,8 +318,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))        # `python bench.py --gpus N`: this process only starts and relays the ranks
+    if os.environ.get("GCT2_BENCH_LAUNCH_TEST") == "1":
+        raise SystemExit(launcher_selftest(args, world, rank))
     # rehearsal of the N > 1 code path on a one-GPU box (never a measurement): GCT2_BENCH_REHEARSAL=1 puts every rank on device 0
     # and exchanges through gloo (RCCL refuses two ranks on one device)
     rehearsal = os.environ.get("GCT2_BENCH_REHEARSAL") == "1"
@@ -198,12 +355,13 @@ def main():
     dp.broadcast_parameters(0)
 
     B, S = args.batch, args.size
+    call_label.size = S
     gen = torch.Generator().manual_seed(rank)          # loader contract: u8/128 - 1 (train.py:292)
     x = (torch.randint(0, 256, (B, S, S, 3), generator=gen).float() / 128 - 1).to(dev)
 
     timer = KernelTimer()
     if not args.no_kernel_events:
-        timer.install(engine_mod, _lib)
+        timer.install(engine_mod, _lib, [eng.ctx, eng.ctx_tail])
 
     def barrier():
         if world > 1:
@@ -235,13 +393,15 @@ def main():
     iso_steps = 0
     if not args.no_kernel_events:
         overlap0, eng.overlap = eng.overlap, False
-        fuse0, eng.fuse_adam = eng.fuse_adam, False              # the fused optimizer step would be timed as part of the wgrad calls
-        timer.sink, timer.enabled = timer.isolated, True
+        # the fused optimizer launch of every weight-gradient call is issued behind the call's end event (KernelTimer.split_adam): the
+        # events bracket the GEMM kernel (+ its helper launches where the call has any), never the optimizer
+        timer.sink, timer.enabled, timer.split_adam = timer.isolated, True, True
         for _ in range(4):
             dp.train_step(x)
             iso_steps += 1
+        eng.flush_deferred()
         barrier()
-        timer.enabled, eng.overlap, eng.fuse_adam = False, overlap0, fuse0
+        timer.enabled, timer.split_adam, eng.overlap = False, False, overlap0
     comm = None
     if world > 1:
         # evidence of what RCCL ran (rank 0): ranks it saw, the buckets of one extra step and the HIP-event time of every collective
@@ -282,57 +442,29 @@ def main():
             "flops_per_image": f_img,
             "step_roofline_frac": round(imgs / world * f_img / MFMA_PEAK, 5),
         }
+        out["roofline"] = {"bound": "mfma", "step_frac": out["step_roofline_frac"], "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s"}
         if timer.isolated:
-            fl = layer_flops(topo, B, S, S)
-
-            def families(events, nsteps):
-                tot, cnt = timer.summary(events)
-                return tot, cnt, {fam: {"launches_per_step": cnt[fam] // nsteps, "ms_per_step": round(tot[fam] / nsteps * 1e3, 4),
-                                        "tflops": round(fl[fam] * nsteps / tot[fam] / 1e12, 2)} for fam in tot}
-
-            tot, cnt, fams = families(timer.isolated, iso_steps)
-            dom = max(tot, key=tot.get)
-            achieved = fl[dom] * iso_steps / tot[dom] / 1e12
-            # achieved = algorithmic FLOPs of ALL launches of the dominant family in the serial-stream steps / their summed
-            # HIP-event time (= average FLOPs per launch / average launch duration).  traffic / mfma_util are NOT measured in this
-            # run: they come from the committed rocprofv3 --pmc passes over the ENGINE'S OWN launches (scripts/engine_layers.py --pmc,
-            # scripts/collect_engine_pmc.py, scripts/profile_round.sh), only for the default config; the *_source fields say so.
-            traffic, traffic_source, mfma_util, mfma_source = None, None, None, None
-            fam_of = lambda lay, d: ("wgrad" if d == "wgrad" else "conv_form" if (lay[0] == "D") == (d == "fwd") else "convT_form")
-            tname = "r04_traffic_per_layer.json"
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath) and (S, B, args.dtype, world) == (128, 64, "bf16", 1):
-                with open(tpath) as f:
-                    rows = [r for r in json.load(f)["layers"] if r["form"] != "rgb" and fam_of(r["layer"], r["dir"].split("+")[0]) == dom]
-                if rows:
-                    traffic = sum(r["read_MB"] + r["write_MB"] for r in rows) * 1e6 / len(rows)
-                    traffic_source = (f"profiles/{tname}: mean of the {len(rows)} launches of this family in the ENGINE'S OWN step (its strides, bit planes, "
-                                      "dispatch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections; committed file - not this run)")
-            uname = "r04_mfma_util.txt"
-            upath = os.path.join(ROOT, "profiles", uname)
-            if os.path.exists(upath) and (S, B, args.dtype, world) == (128, 64, "bf16", 1):
-                busy = cyc = 0.0
-                with open(upath) as f:
-                    for line in f:
-                        c = line.split()
-                        if line.startswith(("#", "lay")) or len(c) < 8 or c[0] == "D0":
-                            continue
-                        if fam_of(c[0], c[1].split("+")[0]) == dom:
-                            busy += float(c[-5]); cyc += float(c[-3])
-                if cyc:
-                    mfma_util = busy / (1024 * cyc)
-                    mfma_source = (f"profiles/{uname}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) summed over this family's launches in the "
-                                   "engine's own step (rocprofv3 --pmc; committed file - not this run); in-kernel clocks: profiles/r04_kernel_clock.txt")
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK / 1e12,
-                               "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_PEAK, 5),
-                               "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_source,
-                               "mfma_util": None if mfma_util is None else round(mfma_util, 4), "mfma_util_source": mfma_source,
-                               "flops_per_launch": fl[dom] / (cnt[dom] // iso_steps), "event_steps": iso_steps,
-                               "avg_launch_us": round(tot[dom] / cnt[dom] * 1e6, 2),
-                               "mode": "one stream (4 extra steps after the timed region): isolated launch durations"}
+            _, _, _, fams = timer.table(timer.isolated, iso_steps, 0)
+            tot, cnt, fl, syms = timer.table(timer.isolated, iso_steps, 1)
+            dom = max(tot, key=tot.get)                       # the kernel symbol with the largest summed time
+            achieved = fl[dom] / tot[dom] / 1e12              # its own algorithmic FLOPs / its own summed HIP-event time
+            # traffic / mfma_util are NOT measured in this run: they come from the committed rocprofv3 --pmc passes over the ENGINE'S
+            # OWN launches (scripts/engine_layers.py --pmc, scripts/collect_engine_pmc.py, scripts/profile_round.sh), default config
+            # only, summed over the layers whose calls selected the dominant kernel; the *_source fields say so.
+            dom_layers = sorted({ev[5] for ev in timer.isolated if ev[1] == dom})
+            traffic, traffic_source, mfma_util, mfma_source = pmc_evidence(set(dom_layers), (S, B, args.dtype, world) == (128, 64, "bf16", 1))
+            out["roofline"].update({
+                "kernel": dom, "kernel_layers": [f"{l}.{d}" for l, d in dom_layers], "achieved": round(achieved, 2), "frac": round(achieved * 1e12 / MFMA_PEAK, 5),
+                "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_source,
+                "mfma_util": None if mfma_util is None else round(mfma_util, 4), "mfma_util_source": mfma_source,
+                "flops_per_launch": fl[dom] / cnt[dom], "launches_per_step": cnt[dom] // iso_steps, "event_steps": iso_steps,
+                "avg_launch_us": round(tot[dom] / cnt[dom] * 1e6, 2),
+                "mode": "one stream (4 extra steps after the timed region): isolated launch durations, HIP events on the launching stream; "
+                        "the kernel of every call from the library's launch log; weight-gradient calls without their optimizer launch"})
+            out["kernel_symbols"] = syms
             out["kernels"] = fams
-            if timer.events:   # the same calls inside the timed region: two streams share the chip, and each wgrad call also
-                out["kernels_two_streams"] = families(timer.events, ev_steps)[2]      # carries its layer's fused Adam launch
+            if timer.events:   # the same calls inside the two-stream step: a launch shares the chip with the other stream's, and each
+                out["kernels_two_streams"] = timer.table(timer.events, ev_steps, 0)[3]      # wgrad call carries its fused Adam launch
         if world == 1 and not args.no_cpu_baseline:
             kw = dict(pixel_size=128, max_size=512)
             v3, s3, n3 = cpu_baseline(dict(octaves=6, **kw), S, 4, 100, 1, budget_s=12.0)   # ~12 s of CPU work

@@ -10,7 +10,7 @@ import os
 
 F32, BF16, F16 = 0, 1, 2
 DTYPE_NAMES = {F32: "f32", BF16: "bf16", F16: "f16"}
-ABI_VERSION = 14
+ABI_VERSION = 15
 # gct2_diffusion_update modes (include/gct2.h; the sampler's objective switches, train.py:29-32)
 SAMPLE_X, SAMPLE_EPS, SAMPLE_SCALED_EPS, SAMPLE_ODE = 0, 1, 2, 3
 BUILD_STAMP = 1
@@ -52,7 +52,7 @@ SIGNATURES = {
     "gct2_ctx_set_stamp_buffer": [_vp, _vp, _sz],
     "gct2_ctx_set_relu_bits": [_vp, _vp, _i],
     "gct2_ctx_log_launches": [_vp, _i],
-    "gct2_ctx_read_launch_log": [_vp, _vp, _sz],
+    "gct2_ctx_read_launch_log": [_vp, _vp, _sz, C.POINTER(C.c_size_t)],
     "gct2_diffusion_mix": [_i, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _sz, _i, _vp],
     "gct2_diffusion_update": [_i, _vp, _vp, _d, _d, _vp, _vp, _sz, _vp],
     "gct2_noise_edits": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
@@ -152,6 +152,8 @@ class Context:
         # HIP graphs of the forward pass) keys its cache on it
         self.version = 0
         self.tuning = 0
+        self.direct = False
+        self.logging = False
 
     def set_relu_bits(self, ptr, ld_bytes: int) -> None:
         """ReLU bit plane for the NEXT forward (written) / input-gradient (read instead of act) call of this context; one-shot.
@@ -167,13 +169,31 @@ class Context:
 
     def log_launches(self, on: bool = True) -> None:
         """launch log of this context (include/gct2.h): clears it and switches it on / off."""
+        self.logging = bool(on)
         call("gct2_ctx_log_launches", self.handle, int(bool(on)))
 
     def read_launch_log(self) -> list:
         """the kernels the layer calls of this context selected since the last read, as text tokens"""
-        buf = C.create_string_buffer(1 << 16)
-        call("gct2_ctx_read_launch_log", self.handle, C.cast(buf, C.c_void_p), len(buf))
+        need = C.c_size_t(0)
+        buf = C.create_string_buffer(1 << 12)
+        rc = load().gct2_ctx_read_launch_log(self.handle, C.cast(buf, C.c_void_p), len(buf), C.byref(need))
+        if rc != 0 and need.value > len(buf):            # too small: nothing was cleared, the call said how much it needs
+            buf = C.create_string_buffer(need.value)
+            rc = load().gct2_ctx_read_launch_log(self.handle, C.cast(buf, C.c_void_p), len(buf), C.byref(need))
+        check(rc, "gct2_ctx_read_launch_log")
         return [t for t in buf.value.decode().split(";") if t]
+
+    def mirror(self, other: "Context") -> None:
+        """take over the steering / observing state of another context (not its scratch): tile knobs, the direct-kernel switch, whether
+        launches are logged, the diagnostic stamp buffer"""
+        if self.tuning != other.tuning:
+            self.set_tuning(other.tuning)
+        if self.direct != other.direct:
+            self.force_direct(other.direct)
+        if self.logging != other.logging:
+            self.log_launches(other.logging)
+        if self._keep[2] is not other._keep[2]:
+            self.set_stamp_buffer(other._keep[2])
 
     def set_workspace(self, tensor) -> None:
         self._keep[0] = tensor
@@ -194,6 +214,7 @@ class Context:
 
     def force_direct(self, on: bool) -> None:
         self.version += 1
+        self.direct = bool(on)
         call("gct2_ctx_force_direct", self.handle, int(bool(on)))
 
     def __del__(self):

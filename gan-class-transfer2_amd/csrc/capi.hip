@@ -67,6 +67,12 @@ void gct2_log(gct2_ctx& c, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
+  // bounded: a log left switched on for a whole run stops growing at 1 MiB and says so once
+  constexpr size_t LOG_CAP = (size_t)1 << 20;
+  if (c.log.size() + sizeof(buf) + 16 > LOG_CAP) {
+    if (!c.log_full) { c.log += "log:truncated;"; c.log_full = true; }
+    return;
+  }
   c.log += buf;
   c.log += ';';
 }
@@ -153,9 +159,10 @@ int wgrad_db(int dtype, const void* dz, int lddz, float* db, size_t pixels, int 
   if (!accumulate) (void)hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), S(stream));
   return pw_colsum(dtype, dz, lddz, db, pixels, Cout, 1.f, S(stream));
 }
-// Keras Adam right behind a weight-gradient launch, on the same stream (gct2_adam_args): the layer's parameters [weights | pad |
-// bias] are one contiguous range of the caller's arenas; the weight gradient comes from the slabs the launch left (never
-// materialised) or from dw (written, not accumulated: no zeroing), the bias gradient from g (written by the dgrad launches); nothing is zeroed
+// Keras Adam right behind a weight-gradient launch, on the same stream (gct2_adam_args): the range [p, p + n) of the caller's arenas
+// starts with the layer's kernel (the engine's ranges hold the kernel only since r04: biases and Dense(3) live in one fp32 zone with
+// a launch of its own); the kernel gradient comes from the slabs the launch left (never materialised) or from dw (written, not
+// accumulated: no zeroing), whatever lies behind the kernel in the range from the gradient arena; nothing is zeroed
 int check_adam_args(const gct2_adam_args* a, const float* dw, size_t nw) {
   if (!a->p || !a->m || !a->v) return gct2_fail(GCT2_EINVAL, "wgrad + adam: null arena pointers");
   if (a->n < nw || ((uintptr_t)a->p | (uintptr_t)a->m | (uintptr_t)a->v | (uintptr_t)dw) % 16)
@@ -174,7 +181,7 @@ int adam_after_wgrad(gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& 
 
 extern "C" {
 
-int gct2_abi_version(void) { return 14; }
+int gct2_abi_version(void) { return 15; }
 int gct2_build_flags(void) {
 #ifdef GCT2_STAMP
   return GCT2_BUILD_STAMP;
@@ -243,14 +250,19 @@ int gct2_ctx_log_launches(gct2_ctx* ctx, int on) {
   if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_log_launches: null ctx");
   ctx->log_on = on != 0;
   ctx->log.clear();
+  ctx->log_full = false;
   return GCT2_OK;
 }
-int gct2_ctx_read_launch_log(gct2_ctx* ctx, char* buf, size_t bytes) {
-  if (!ctx || !buf || bytes == 0) return gct2_fail(GCT2_EINVAL, "ctx_read_launch_log: null ctx / buffer");
-  const size_t n = ctx->log.size() < bytes - 1 ? ctx->log.size() : bytes - 1;
-  memcpy(buf, ctx->log.data(), n);
-  buf[n] = 0;
+int gct2_ctx_read_launch_log(gct2_ctx* ctx, char* buf, size_t bytes, size_t* needed) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_read_launch_log: null ctx");
+  const size_t need = ctx->log.size() + 1;
+  if (needed) *needed = need;
+  if (!buf || bytes < need)       // nothing is copied and nothing is cleared: call again with `needed` bytes
+    return gct2_fail(GCT2_EINVAL, "ctx_read_launch_log: the log holds %zu bytes, the buffer %zu", need, buf ? bytes : (size_t)0);
+  memcpy(buf, ctx->log.data(), need - 1);
+  buf[need - 1] = 0;
   ctx->log.clear();
+  ctx->log_full = false;
   return GCT2_OK;
 }
 int gct2_ctx_force_direct(gct2_ctx* ctx, int on) {

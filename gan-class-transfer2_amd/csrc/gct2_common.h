@@ -36,7 +36,7 @@ struct gct2_ctx {
   // plane in its epilogue (else the forward entry point derives it from y)
   unsigned char* relu_bits = nullptr; int relu_ldbits = 0; int relu_bits_done = 0;
   // launch log (gct2_ctx_log_launches): which kernel every layer call selected, as text tokens - for tests that must know
-  bool log_on = false; std::string log;
+  bool log_on = false, log_full = false; std::string log;
   float* wgrad_scratch(size_t* bytes) const {
     if (wws) { *bytes = wws_bytes; return wws; }
     *bytes = ws_bytes; return ws;

@@ -193,14 +193,15 @@ class ShardedDataParallelStep:
         # is always exposed: keep it small.  It starts at the first of the `tail_layers` last ranges (DownShuffle_1, DownShuffle_0 and
         # the fp32 zone of the reference topology: 0.54 M of the 41.7 M parameters), rounded down to a shard unit;
         # every bucket before it is a fixed-size piece that closes with an earlier layer.
-        tail = A.total
-        if 0 < tail_layers < len(order):
-            tail = A.layer_ranges[order[-tail_layers]][0] // unit * unit
-        if tail <= 0 or tail >= A.total:
-            tail = A.total
+        # tail_layers is clamped into [1, len(order) - 1] and the tail never starts behind the fp32 zone (0, too large or
+        # a tail that rounds to nothing used to leave fixed-size pieces of which the last was marked replicated, with the zone possibly
+        # straddling two of them), so the zone - which every rank reads in fp32 and nobody all-gathers - always sits in ONE replicated bucket
+        tail_layers = min(max(int(tail_layers), 1), len(order) - 1)
+        tail = min(A.layer_ranges[order[-tail_layers]][0], A.layer_ranges["fp32"][0]) // unit * unit
+        if tail <= 0:
+            tail = 0                                           # (a tiny arena: one replicated bucket - a plain all-reduce step)
         self.buckets: List[Tuple[int, int]] = [(lo, min(lo + bsz, tail)) for lo in range(0, tail, bsz)]
-        if tail < A.total:
-            self.buckets.append((tail, A.total))
+        self.buckets.append((tail, A.total))
         self.layer_index = {name: i for i, name in enumerate(order)}
         ends = [A.layer_ranges[name][1] for name in order]
         # last_layer[k]: index of the layer that holds the last element of bucket k (the bucket is complete when it is ready)
@@ -215,7 +216,7 @@ class ShardedDataParallelStep:
         # buckets only all-gather the compute-dtype shadow, so these must live in the replicated last bucket (ParamArena puts them
         # in one zone at the end of the arena for exactly this)
         if self.buckets[-1][0] > A.layer_ranges["fp32"][0]:
-            raise ValueError("the last bucket must contain the arena's fp32 zone (raise tail_layers)")
+            raise ValueError("internal: the replicated last bucket does not contain the arena's fp32 zone")
         engine._masters_sharded = False     # True after a sharded step, until gather_master(): UNetEngine.state_dict refuses
         self._begin()
 

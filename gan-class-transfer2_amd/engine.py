@@ -133,6 +133,17 @@ class ParamArena:
 
     LAYOUT = 2        # bumped when the order of tensors inside the arenas changes (state_dict carries it)
 
+    @staticmethod
+    def legacy_offsets(topo: "Topology") -> Tuple[Dict[str, int], int]:
+        """tensor offsets of the r01-r03 arena layout ([kernel | bias] per layer, backward completion order, dense first) and its
+        length - what checkpoints written before ParamArena.LAYOUT existed hold (UNetEngine.load_state_dict converts them)"""
+        shapes, offs, off = topo.param_shapes(), {}, 0
+        for layer in topo.layer_order():
+            for suffix in (".w", ".b"):
+                offs[layer + suffix] = off
+                off = _round_up(off + int(np.prod(shapes[layer + suffix])), ParamArena.ALIGN)
+        return offs, _round_up(off, 64 * ParamArena.ALIGN)
+
     def ready_order(self) -> List[str]:
         """arena ranges in the order their gradients complete during the reverse pass: the convolution layers (each ready hook
         fires when the layer's weight gradient is enqueued), then the fp32 zone (complete with the last input gradient)."""
@@ -263,6 +274,7 @@ class UNetEngine:
         self.defer_window_at = 3          # the held-back launches start once DownShuffle_<this> of the next forward pass is enqueued
         self._pending: list = []
         self._pending_event = None
+        self._flush_event = None
         self._pending_names: set = set()
         self._defer_ctxs: Dict[str, "_lib.Context"] = {}
         self._defer_ws: Dict[str, torch.Tensor] = {}
@@ -307,12 +319,23 @@ class UNetEngine:
 
     # ---- deferred optimizer steps ------------------------------------------------------------------------------------------
     def _defer_ctx(self, layer: str) -> "_lib.Context":
+        """the call context of a deferred layer's weight gradient: its own slab scratch, everything else mirrored from self.ctx
+        (tile knobs, the direct-kernel switch, the launch log, the diagnostic stamp buffer) so that whoever steers or observes the
+        step through self.ctx steers and observes these launches too"""
         c = self._defer_ctxs.get(layer)
         if c is None:
             c = self._defer_ctxs[layer] = _lib.Context()
             self._defer_ws[layer] = torch.empty_like(self.wgrad_workspace)
             c.set_wgrad_workspace(self._defer_ws[layer])
+        c.mirror(self.ctx)
         return c
+
+    def read_launch_log(self) -> list:
+        """launch tokens of every context this engine drives (the main one, the chain-tail one, the deferred layers'), main first"""
+        out = self.ctx.read_launch_log() + self.ctx_tail.read_launch_log()
+        for c in self._defer_ctxs.values():
+            out += c.read_launch_log()
+        return out
 
     def _launch_pending(self, stream: int) -> None:
         """the optimizer launches held back by the last step, in the order the fused step would have run them"""
@@ -327,10 +350,20 @@ class UNetEngine:
         cur = torch.cuda.current_stream(self.device)
         if self._pending:
             self._launch_pending(cur.cuda_stream)
+            # the launches write p / m / v / shadow of the deferred layers and read their slabs; the caller may be on ANY stream
+            # (predict / state_dict / the sampler on an evaluation stream): whatever uses the parameters or the slabs next - the next
+            # forward pass, the next reverse pass, on whichever stream - waits for this event first
+            self._flush_event = torch.cuda.Event()
+            self._flush_event.record(cur)
         if self._pending_event is not None:
             cur.wait_event(self._pending_event)
             self._pending_event = None
         self._pending_names = set()
+
+    def _after_flush(self, stream: "torch.cuda.Stream") -> None:
+        """orders `stream` behind the last flush_deferred() that ran on another stream (no-op otherwise)"""
+        if self._flush_event is not None:
+            stream.wait_event(self._flush_event)
 
     def check_input_shape(self, H: int, W: int) -> None:
         n = self.topo.octaves
@@ -463,6 +496,7 @@ class UNetEngine:
         if not in_step:
             self.flush_deferred()                              # (a captured graph, the sampler, predict: no side-stream work in here)
         cur = torch.cuda.current_stream(self.device)
+        self._after_flush(cur)
         window_at = min(self.defer_window_at, n - 1)            # deferred Adam starts once DownShuffle_{window_at} is enqueued
 
         def join_pending() -> None:                             # the deferred updates are done before their weights are read
@@ -620,6 +654,7 @@ class UNetEngine:
         main = self._chain_stream if (self.overlap and self.chain_priority) else caller
         if main is not caller:
             main.wait_stream(caller)
+        self._after_flush(main)
         side = self._side if self.overlap else main
         s, sw = main.cuda_stream, side.cuda_stream
         M = b.B * b.H * b.W
@@ -661,10 +696,7 @@ class UNetEngine:
         def wctx(layer: str) -> int:                            # a deferred layer's slabs must outlive the step: its own scratch
             if layer not in deferred:
                 return cx
-            c = self._defer_ctx(layer)
-            if c.tuning != self.ctx.tuning:
-                c.set_tuning(self.ctx.tuning)
-            return c.handle
+            return self._defer_ctx(layer).handle
 
         keep: list = []
         for i in range(n):                                      # UpShuffle_i backward, outermost first
@@ -870,13 +902,59 @@ class UNetEngine:
             sd["loss_scale_state"] = self.ls_state.cpu()
         return sd
 
+    def named_state_dict(self) -> Dict[str, torch.Tensor]:
+        """the same state keyed BY PARAMETER NAME - "p/U0.w", "m/U0.w", "v/U0.w", ... in the tensors' own (Keras) shapes plus the
+        counters - independent of how the arenas are laid out: the exchange format between arena layouts, engines and other
+        frameworks.  CPU tensors, safetensors-ready; load_named_state_dict reads it back."""
+        sd = self.state_dict()
+        A, out = self.arena, {k: v for k, v in sd.items() if not k.startswith("arena.") and k != "topology"}
+        out["topology"] = sd["topology"][:3].clone()
+        for slot in ("p", "m", "v"):
+            flat = sd["arena." + slot]
+            for name, o in A.offsets.items():
+                out[f"{slot}/{name}"] = flat[o:o + A.numel(name)].view(A.shapes[name]).clone()
+        return out
+
+    def load_named_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        A = self.arena
+        if [int(v) for v in sd["topology"][:3]] != [self.topo.pixel_size, self.topo.max_size, self.topo.octaves]:
+            raise ValueError(f"checkpoint topology {[int(v) for v in sd['topology'][:3]]} != engine")
+        flat = {slot: torch.zeros(A.total, dtype=torch.float32) for slot in ("p", "m", "v")}
+        for slot in flat:
+            for name, o in A.offsets.items():
+                t = sd[f"{slot}/{name}"]
+                if tuple(t.shape) != tuple(A.shapes[name]):
+                    raise ValueError(f"{slot}/{name}: shape {tuple(t.shape)} != {tuple(A.shapes[name])}")
+                flat[slot][o:o + A.numel(name)] = t.reshape(-1).to(torch.float32)
+        arena_sd = {k: v for k, v in sd.items() if "/" not in k}
+        arena_sd.update({"arena." + slot: flat[slot] for slot in flat})
+        arena_sd["topology"] = torch.tensor([self.topo.pixel_size, self.topo.max_size, self.topo.octaves, A.total, A.LAYOUT], dtype=torch.int64)
+        self.load_state_dict(arena_sd)
+
+    def _convert_legacy_layout(self, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """a checkpoint of the r01-r03 layout ([kernel | bias] per layer, 4-entry topology record) re-laid into this arena"""
+        A = self.arena
+        old, old_total = ParamArena.legacy_offsets(self.topo)
+        if int(sd["topology"][3]) != old_total:
+            raise ValueError(f"legacy checkpoint holds {int(sd['topology'][3])} elements per arena, this topology's r01-r03 layout {old_total}")
+        out = dict(sd)
+        for slot in ("p", "m", "v"):
+            src, dst = sd["arena." + slot], torch.zeros(A.total, dtype=torch.float32)
+            for name, o in A.offsets.items():
+                dst[o:o + A.numel(name)] = src[old[name]:old[name] + A.numel(name)]
+            out["arena." + slot] = dst
+        out["topology"] = torch.tensor([self.topo.pixel_size, self.topo.max_size, self.topo.octaves, A.total, A.LAYOUT], dtype=torch.int64)
+        return out
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         A = self.arena
         want = [self.topo.pixel_size, self.topo.max_size, self.topo.octaves, A.total, A.LAYOUT]
         have = [int(v) for v in sd["topology"]]
-        if len(have) == 4:
-            raise ValueError("checkpoint written with the r01-r03 arena layout ([kernel | bias] per layer); this engine keeps the biases and "
-                             "Dense(3) in one fp32 zone behind the kernels (ParamArena.LAYOUT = 2): re-export it by parameter name")
+        if len(have) == 4:             # r01-r03 checkpoints carry no layout tag: [kernel | bias] per layer - converted on the way in
+            if have[:3] != want[:3]:
+                raise ValueError(f"checkpoint topology {have[:3]} != engine {want[:3]}")
+            sd = self._convert_legacy_layout(sd)
+            have = [int(v) for v in sd["topology"]]
         if have != want:
             raise ValueError(f"checkpoint topology / layout {have} != engine {want}")
         if ("loss_scale_state" in sd) != (self.ls_state is not None):

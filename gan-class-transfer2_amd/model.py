@@ -71,12 +71,6 @@ def preferred_dtype_code() -> int:
     return F16 if mixed_precision else F32
 
 
-def _unsupported(what: str, line: str):
-    raise NotImplementedError(
-        f"{what} is off in the reference's defaults ({line}) and outside this build's hot-path scope "
-        "(SURVEY.md §8a/§8f); only the default branch is implemented")
-
-
 # ---- optimizer pieces (train.py:47-83) -----------------------------------------------------------------
 class WarmUp:
     """train.py:50-65: lr(step) = base*(step+1)/(warmup_steps+1) while step < warmup_steps, else base."""

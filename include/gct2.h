@@ -37,7 +37,7 @@ enum {
 };
 
 /* library / device identification ------------------------------------------------------------ */
-int gct2_abi_version(void);                 /* bumps when a signature below changes (v13: ReLU bit planes; v14: pruned tuning word, launch log, no deferred row sums) */
+int gct2_abi_version(void);                 /* bumps when a signature below changes (v13: ReLU bit planes; v14: pruned tuning word, launch log, no deferred row sums; v15: launch-log read reports the size it needs, step plans) */
 /* how the library was built: 0 for the product build; bit 0 (GCT2_BUILD_STAMP) = diagnostic build with in-kernel phase stamps
  * (make EXTRA=-DGCT2_STAMP).  Product hosts (the Python binding, bench.py, the tests) refuse a library whose flags are not 0. */
 enum { GCT2_BUILD_STAMP = 1 };
@@ -94,10 +94,12 @@ int gct2_ctx_set_stamp_buffer(gct2_ctx* ctx, void* stamps, size_t bytes);
 /* launch log (tests / diagnostics): while switched on, every layer entry point of this ctx appends the kernel it selected as a
  * text token ("tap:conv:256x128:mask:ksplit=1:bits;", "halo:convT:bias_act;", "wgrad:256q:rsplit=8:slabs;", "rgb:fwd;",
  * "direct:tap;", "relu_bits:derived;" ...).  gct2_ctx_log_launches(ctx, on) clears the log and switches it; read copies the
- * NUL-terminated text (truncated to bytes - 1) and clears it.  A parity test at reduced batch uses it to prove that the kernels it
- * forced are the ones that ran. */
+ * NUL-terminated text and clears the log.  *needed (may be NULL) receives the bytes the text needs including the NUL; when the
+ * buffer is smaller (or NULL) the call returns GCT2_EINVAL and NEITHER copies NOR clears anything (ABI v15; v14 truncated
+ * silently).  The log stops growing at 1 MiB and then ends with "log:truncated;".  A parity test at reduced batch uses it to
+ * prove that the kernels it forced are the ones that ran. */
 int gct2_ctx_log_launches(gct2_ctx* ctx, int on);
-int gct2_ctx_read_launch_log(gct2_ctx* ctx, char* buf, size_t bytes);
+int gct2_ctx_read_launch_log(gct2_ctx* ctx, char* buf, size_t bytes, size_t* needed);
 
 /* ---- DownShuffle = Conv2D(f, 4, 2, 'same', relu)   train.py:158-169 ------------------------- */
 /* y[b,oh,ow,o] = act(bias[o] + sum_{kh,kw,i} x[b,2oh+kh-1,2ow+kw-1,i] * w[kh,kw,i,o])
@@ -124,12 +126,13 @@ int gct2_conv4s2_dgrad(gct2_ctx* ctx, int dtype, const void* dz, int lddz, const
                        int accumulate, float* db, int db_split, float* db2, int db_accumulate, void* stream);
 
 /* optional optimizer step fused behind a weight-gradient call (single-replica training without loss scaling): Keras Adam
- * (as gct2_adam_keras_multi) over the layer's contiguous parameter range [kernel | padding | bias ...] of the caller's
- * arenas, enqueued on the same stream right after the gradient.  p, m, v: fp32, start of the kernel's slice; n: elements of
- * the whole range (>= the kernel's 16*Cin*Cout); dw (the call's gradient pointer) must be the matching start of the gradient
+ * (as gct2_adam_keras_multi) over a contiguous parameter range of the caller's arenas that STARTS with the layer's kernel,
+ * enqueued on the same stream right after the gradient.  p, m, v: fp32, start of the kernel's slice; n: elements of the
+ * whole range (>= the kernel's 16*Cin*Cout; the engine's ranges are the kernel plus alignment padding - its biases live in a
+ * separate fp32 zone with a launch of its own); dw (the call's gradient pointer) must be the matching start of the gradient
  * arena.  The kernel gradient is consumed straight from the launch's partial sums where it has them (it is then never
- * written to dw) or from dw; gradients behind the kernel in the range (the bias, written by the dgrad calls) are read
- * from the gradient arena.  Nothing is zeroed.  Needs accumulate = 0. */
+ * written to dw) or from dw; whatever lies behind the kernel in the range is read from the gradient arena.  Nothing is
+ * zeroed.  Needs accumulate = 0. */
 typedef struct gct2_adam_args {
   float* p; float* m; float* v;
   void* shadow; int shadow_dtype;      /* compute-dtype copy of p over the same range, or NULL */
@@ -139,7 +142,7 @@ typedef struct gct2_adam_args {
    * / nslab / slab_stride: `nslab` partial tensors in the ctx's weight-gradient scratch (nslab = 0: the gradient is in dw) - and the
    * caller runs the step later with gct2_adam_apply(this struct, dw, 16*Cin*Cout, stream): the same launch, the same bits.  Until
    * then the scratch of that ctx must not be handed to another weight-gradient call (the engine gives such layers a ctx of their
-   * own) and dw / the bias gradients behind it must stay untouched.  The engine uses it to run the optimizer step of the layers the
+   * own) and dw (plus whatever the range holds behind the kernel in the gradient arena) must stay untouched.  The engine uses it to run the optimizer step of the layers the
    * forward pass needs LAST inside the bottleneck window of the next forward pass. */
   int defer;
   const float* slab_base; int nslab; size_t slab_stride;     /* out (defer != 0) */

@@ -302,3 +302,19 @@ def test_four_rank_gloo_sharded_step_interior_shards_loss_scaling(tmp_path):
     small_ref = torch.cat([A.param(n).reshape(-1) for n in names]).numpy()
     assert np.abs(small_ref).max() > 0                      # the biases did move (they start at zero)
     assert np.linalg.norm(z["small"] - small_ref) <= 3e-6 * np.linalg.norm(small_ref)
+
+
+@pytest.mark.parametrize("tail_layers", [0, 1, 3, 99])
+def test_sharded_tail_layers_is_clamped(tail_layers):
+    """whatever tail_layers is given (0, larger than the number of ranges, a tail that rounds down to nothing), the bucket
+    list ends with ONE replicated bucket that contains the whole fp32 zone, and the buckets tile the arena without gaps."""
+    import gan_class_transfer2_amd as g
+    from gan_class_transfer2_amd.distributed import ShardedDataParallelStep
+    cfg = O.OracleConfig(size=16, pixel_size=8, max_size=16, octaves=2, batch_size=4)
+    eng = _CpuEngine(cfg, g.Topology(cfg.pixel_size, cfg.max_size, cfg.octaves), O.init_params(cfg, seed=21))
+    dp = ShardedDataParallelStep(eng, bucket_elems=1000, tail_layers=tail_layers)
+    A = eng.arena
+    assert dp.buckets[0][0] == 0 and dp.buckets[-1][1] == A.total
+    assert all(dp.buckets[i][1] == dp.buckets[i + 1][0] for i in range(len(dp.buckets) - 1))
+    assert dp.replicated(len(dp.buckets) - 1) and dp.buckets[-1][0] <= A.layer_ranges["fp32"][0]
+    assert not any(dp.replicated(k) for k in range(len(dp.buckets) - 1))

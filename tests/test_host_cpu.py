@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gct2.h but not exported"
     # and the ctypes table binds exactly the declared entry points (minus last_error, bound separately)
     assert sorted(set(g._lib.SIGNATURES) | {"gct2_last_error"}) == names
-    assert g._lib.load().gct2_abi_version() == g._lib.ABI_VERSION == 14
+    assert g._lib.load().gct2_abi_version() == g._lib.ABI_VERSION == 15
     # the shipped library is the PRODUCT build: no in-kernel stamps, and the diagnostic hook refuses
     assert g._lib.build_flags() == 0
     c = g._lib.Context()
@@ -236,3 +236,45 @@ def test_launch_log_is_per_context_and_host_only():
     c.log_launches(True)
     assert c.read_launch_log() == []                                 # nothing launched yet; reading clears
     c.log_launches(False)
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher in front of it (the form the driver uses): the parent starts N ranks through
+    torch.distributed.run before touching a GPU, relays rank 0's ONE JSON line and the exit code.  The rank body
+    here is the launch-contract self-test (GCT2_BENCH_LAUNCH_TEST=1: gloo rendezvous, barrier, MAX over ranks; no GPU work)."""
+    import json
+    r = _run_bench({"GCT2_BENCH_LAUNCH_TEST": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["max_over_ranks"] == 2.0
+    # a failing rank makes the launcher exit non-zero and print no result line
+    r = _run_bench({"GCT2_BENCH_LAUNCH_TEST": "1", "GCT2_BENCH_LAUNCH_TEST_FAIL_RANK": "1"}, "--gpus", "2")
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_kernel_symbol_and_labels():
+    import bench
+    assert bench.kernel_symbol("wgrad:256q:rsplit=64:slabs") == "wgrad256q_kernel"
+    assert bench.kernel_symbol("wgrad:128:rsplit=1:owner") == "wgrad_kernel"
+    assert bench.kernel_symbol("tap:conv:256x128:mask:ksplit=1:bits") == "tapgemm_kernel<conv,256x128>"
+    assert bench.kernel_symbol("halo:convT:head") == "halo_convT_kernel<head>"
+    bench.call_label.size = 128
+    # gct2_convT4s2_wgrad(ctx, dtype, x, ldx, dz, lddz, dw, db, B, H, W, Cin, Cout, acc, adam, stream) for UpShuffle_0 at config 3
+    a = (0, 1, 0, 256, 0, 64, 0, None, 64, 64, 64, 256, 64, 0, None, None)
+    assert bench.call_label("gct2_convT4s2_wgrad", a) == ("U0", "wgrad")
+    assert bench.call_flops("gct2_convT4s2_wgrad", a) == 2.0 * 64 * 128 * 128 * 64 * 4 * 256
+    a = (0, 1, 0, 512, 0, 0, 0, 512, 64, 16, 16, 512, 512, 1, None)       # gct2_conv4s2_fwd of DownShuffle_3
+    assert bench.call_label("gct2_conv4s2_fwd", a) == ("D3", "fwd")
+    assert abs(bench.call_flops("gct2_conv4s2_fwd", a) / 1e9 - 34.360) < 1e-2

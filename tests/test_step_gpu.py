@@ -304,6 +304,71 @@ def test_checkpoint_roundtrip_continues(gpu, tmp_path):
         wrong.load_checkpoint(path)
 
 
+def test_named_and_legacy_state_dicts_load_into_the_current_layout(gpu):
+    """checkpoints must survive an arena re-layout.  (a) named_state_dict (p/m/v by parameter name, Keras shapes) ->
+    load_named_state_dict into a fresh engine: every arena and counter equal, next step bit-identical; (b) a file in the r01-r03
+    layout ([kernel | bias] per layer, 4-entry topology record, rebuilt here from ParamArena.legacy_offsets) loads through
+    load_state_dict and gives the same arenas."""
+    from gan_class_transfer2_amd.engine import ParamArena
+    cfg = O.OracleConfig(size=32, pixel_size=128, max_size=256, octaves=3, batch_size=4)
+    x = torch.tensor(O.synthetic_batch(cfg, seed=0)[0], dtype=torch.float32, device=gpu)
+    a = make_engine(cfg, 1, gpu, rng_seed=11)
+    a.set_params(O.init_params(cfg, seed=5))
+    for _ in range(2):
+        a.train_step(x)
+    named = a.named_state_dict()
+    assert tuple(named["p/U0.w"].shape) == (4, 4, 64, a.topo.up_in(0)) and tuple(named["v/dense.w"].shape) == (67, 3)
+    b = make_engine(cfg, 1, gpu, rng_seed=99)
+    b.load_named_state_dict(named)
+    old, old_total = ParamArena.legacy_offsets(a.topo)
+    legacy = {k: v for k, v in a.state_dict().items() if not k.startswith("arena.")}
+    legacy["topology"] = torch.tensor([a.topo.pixel_size, a.topo.max_size, a.topo.octaves, old_total], dtype=torch.int64)
+    for slot in ("p", "m", "v"):
+        flat = torch.zeros(old_total, dtype=torch.float32)
+        for name, o in old.items():
+            flat[o:o + a.arena.numel(name)] = named[f"{slot}/{name}"].reshape(-1)
+        legacy["arena." + slot] = flat
+    c = make_engine(cfg, 1, gpu, rng_seed=7)
+    c.load_state_dict(legacy)
+    for e in (b, c):
+        assert (e.iterations, e.rng_seed, e.rng_offset_t, e.rng_offset_eps) == (a.iterations, a.rng_seed, a.rng_offset_t, a.rng_offset_eps)
+        for name in ("p", "m", "v", "shadow"):
+            assert torch.equal(getattr(a.arena, name), getattr(e.arena, name)), name
+    la, lb, lc = a.train_step(x), b.train_step(x), c.train_step(x)
+    torch.cuda.synchronize()
+    assert float(la[0]) == float(lb[0]) == float(lc[0])
+    assert torch.equal(a.arena.p, b.arena.p) and torch.equal(a.arena.p, c.arena.p)
+    legacy["topology"][3] += 64
+    with pytest.raises(ValueError):
+        c.load_state_dict(legacy)
+
+
+def test_flush_on_another_stream_orders_the_next_step(gpu):
+    """predict() / state_dict() between two fused steps may run on ANOTHER stream; the flush they trigger launches the
+    held-back Adam of UpShuffle_0..2 there, and the next train step on the training stream must wait for it.  Bits against an engine
+    that never defers."""
+    cfg = O.OracleConfig(size=64, pixel_size=128, max_size=512, octaves=4, batch_size=4)
+    params = O.init_params(cfg, seed=3)
+    x = torch.tensor(O.synthetic_batch(cfg, seed=0)[0], dtype=torch.float32, device=gpu)
+    engs = [make_engine(cfg, 1, gpu, rng_seed=5) for _ in range(2)]
+    engs[1].defer_adam = False
+    other = torch.cuda.Stream(device=gpu)
+    preds = []
+    for e in engs:
+        e.set_params(params)
+        for k in range(3):
+            e.train_step(x)
+            if k == 1:
+                other.wait_stream(torch.cuda.current_stream(gpu))
+                with torch.cuda.stream(other):
+                    preds.append(e.predict(x[:1]).clone())          # flushes on `other` in the deferring engine
+        torch.cuda.synchronize()
+    assert engs[0]._flush_event is not None
+    assert torch.equal(preds[0], preds[1])
+    for name in ("p", "m", "v", "shadow"):
+        assert torch.equal(getattr(engs[0].arena, name), getattr(engs[1].arena, name)), name
+
+
 def test_config3_full_size_properties(gpu):
     """BASELINE config 3 (3x128x128, bs 64, reference topology, bf16) is too large for the CPU oracle in a test, so the
     headline size is covered by properties the path must have at any size:
