@@ -307,6 +307,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="tapgemm tile variant hook (0 auto, 2, 3): A/B timing only")
+    ap.add_argument("--no-plan", action="store_true", help="run every step through the interpreter (no recorded step plan): A/B of the host side")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run the weight gradients and Adam on the main stream (no overlap): per-kernel profiling runs")
     ap.add_argument("--dp-mode", default="sharded", choices=["sharded", "allreduce"],
@@ -350,6 +351,7 @@ def main():
     if args.variant:
         eng.ctx.set_tuning(args.variant)
     eng.overlap = not args.serial_streams
+    eng.use_plan = not args.no_plan
     sharded = world > 1 and args.dp_mode == "sharded"
     dp = ShardedDataParallelStep(eng) if sharded else DataParallelStep(eng)
     dp.broadcast_parameters(0)
@@ -377,10 +379,12 @@ def main():
     for i in range(args.steps):
         loss = dp.train_step(x)
     eng.flush_deferred()       # the optimizer launches the last step held back for the next forward pass: inside the timed region
+    host_dt = time.perf_counter() - t0                 # host time to enqueue the K steps (the GPU is still running)
     barrier()
     dt = time.perf_counter() - t0
     # in-situ leg: the step as timed (two streams), with events: what a launch takes while it shares the chip with the other stream
     ev_steps = 0
+    plan0, eng.use_plan = eng.use_plan, False       # the event legs intercept every C-ABI call: they run the step eagerly (same calls)
     if not args.no_kernel_events:
         timer.enabled = True
         for _ in range(4):
@@ -402,6 +406,7 @@ def main():
         eng.flush_deferred()
         barrier()
         timer.enabled, timer.split_adam, eng.overlap = False, False, overlap0
+    eng.use_plan = plan0
     comm = None
     if world > 1:
         # evidence of what RCCL ran (rank 0): ranks it saw, the buckets of one extra step and the HIP-event time of every collective
@@ -438,6 +443,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "loss": loss_val,
             "library": {"abi": int(_lib.load().gct2_abi_version()), "build_flags": int(_lib.build_flags())},
+            "host": {"step_plan": bool(eng.use_plan), "enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 4)},
             "comm": comm,
             "flops_per_image": f_img,
             "step_roofline_frac": round(imgs / world * f_img / MFMA_PEAK, 5),

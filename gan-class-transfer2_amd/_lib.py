@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import struct
 
 F32, BF16, F16 = 0, 1, 2
 DTYPE_NAMES = {F32: "f32", BF16: "bf16", F16: "f16"}
@@ -86,6 +87,14 @@ SIGNATURES = {
     "gct2_loss_scale_begin": [_vp, _f, _i, _f, _f, _vp],
     "gct2_scale_check_finite": [_vp, _sz, _vp, _vp],
     "gct2_loss_scale_update": [_vp, _i, _vp],
+    "gct2_plan_create": [C.POINTER(C.c_void_p)],
+    "gct2_plan_destroy": [_vp],
+    "gct2_plan_add_call": [_vp, C.c_char_p, C.POINTER(C.c_uint64), _i, C.POINTER(C.c_int)],
+    "gct2_plan_add_record": [_vp, _vp, C.POINTER(C.c_int)],
+    "gct2_plan_add_wait": [_vp, _vp, _i],
+    "gct2_plan_size": [_vp, C.POINTER(C.c_int)],
+    "gct2_plan_set_arg": [_vp, _i, _i, _u64],
+    "gct2_plan_run": [_vp, _i, _i, C.POINTER(C.c_int)],
 }
 
 _lib = None
@@ -134,8 +143,138 @@ def check(rc: int, what: str = "") -> None:
         raise Gct2Error(f"{what or 'gct2'} failed (status {rc}): {msg}")
 
 
+class Slot:
+    """an argument whose value changes from step to step (the input batch pointer, RNG offsets, the optimizer's alpha): `call`
+    passes the value through; a Plan that records the call remembers (record, argument) under `key` and re-sets it before a run"""
+    __slots__ = ("key", "value")
+
+    def __init__(self, key: str, value):
+        self.key, self.value = key, value
+
+
 def call(name: str, *args) -> None:
-    check(getattr(load(), name)(*args), name)
+    if _recording is not None:
+        _recording.add_call(name, args)
+        if not _recording.execute or name not in PLANNABLE:
+            return
+    check(getattr(load(), name)(*[a.value if type(a) is Slot else a for a in args]), name)
+
+
+# the entry points a plan can hold (csrc/plan.hip ENTRIES): everything that enqueues work on a stream + the one-shot ReLU plane
+PLANNABLE = frozenset(n for n, sig in SIGNATURES.items() if n == "gct2_ctx_set_relu_bits" or (
+    not n.startswith(("gct2_ctx_", "gct2_plan_", "gct2_loss_scale_init")) and n not in ("gct2_abi_version", "gct2_build_flags", "gct2_device_check")))
+_recording = None      # the Plan that is recording calls right now (one host thread drives an engine: _lib.call is not re-entrant)
+_FLOAT_STRUCT = struct.Struct("<f")
+_DOUBLE_STRUCT = struct.Struct("<d")
+
+
+def _slot_bits(ctype, v) -> int:
+    """one argument as the 64-bit slot of include/gct2.h's plan calls"""
+    if ctype is _f:
+        return int.from_bytes(_FLOAT_STRUCT.pack(float(v)), "little")
+    if ctype is _d:
+        return int.from_bytes(_DOUBLE_STRUCT.pack(float(v)), "little")
+    if v is None:
+        return 0
+    return int(v) & 0xFFFFFFFFFFFFFFFF
+
+
+class Plan:
+    """gct2_plan (include/gct2.h): a recorded list of entry-point calls, event records and stream waits that one C call replays.
+
+        plan = Plan(); plan.begin(execute=True)     # every _lib.call(...) from now on is appended (and, with execute, also run)
+        ...                                          # plan.record(stream) / plan.wait(stream, ev) / plan.cut(tag) from the host code
+        plan.end()
+        plan.set("x", ptr); plan.run_segment(k)      # per step
+
+    Segments: plan.cut(payload) closes the current segment; the caller runs segment k, does its own work for payload k (the
+    data-parallel hooks), then segment k + 1."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(load().gct2_plan_create(C.byref(h)), "gct2_plan_create")
+        self.handle = h.value
+        self.execute = True
+        self.slots = {}            # key -> [(record, argument, ctype)]
+        self.values = {}           # key -> last value set
+        self.cuts = []             # (first record of the NEXT segment, payload)
+        self.keep = []             # objects the records point into (gct2_adam_args structs, tensors)
+        self.n = 0
+
+    # ---- recording ----------------------------------------------------------------------------------------------------------
+    def begin(self, execute: bool = True) -> None:
+        global _recording
+        if _recording is not None:
+            raise Gct2Error("a plan is already recording")
+        self.execute = execute
+        _recording = self
+
+    def end(self) -> None:
+        global _recording
+        _recording = None
+        self.cuts.append((self.n, None))
+
+    def add_call(self, name: str, args) -> None:
+        if name not in PLANNABLE:               # host-only state changes (context setters): done now, they persist until the replay
+            check(getattr(load(), name)(*[a.value if type(a) is Slot else a for a in args]), name)
+            return
+        types = SIGNATURES[name]
+        if len(types) != len(args):
+            raise Gct2Error(f"{name}: {len(args)} arguments for {len(types)} parameters")
+        arr = (C.c_uint64 * len(args))()
+        for i, (t, a) in enumerate(zip(types, args)):
+            if type(a) is Slot:
+                self.slots.setdefault(a.key, []).append((self.n, i, t))
+                self.values[a.key] = a.value
+                a = a.value
+            arr[i] = _slot_bits(t, a)
+        idx = C.c_int(-1)
+        check(load().gct2_plan_add_call(self.handle, name.encode(), arr, len(args), C.byref(idx)), "gct2_plan_add_call")
+        self.n = idx.value + 1
+
+    def record(self, stream: int) -> int:
+        ev = C.c_int(-1)
+        check(load().gct2_plan_add_record(self.handle, stream, C.byref(ev)), "gct2_plan_add_record")
+        self.n += 1
+        return ev.value
+
+    def wait(self, stream: int, event: int) -> None:
+        check(load().gct2_plan_add_wait(self.handle, stream, event), "gct2_plan_add_wait")
+        self.n += 1
+
+    def cut(self, payload) -> None:
+        self.cuts.append((self.n, payload))
+
+    # ---- replay -------------------------------------------------------------------------------------------------------------
+    def set(self, key: str, value) -> None:
+        if self.values.get(key) == value:
+            return
+        self.values[key] = value
+        L = load()
+        for rec, arg, t in self.slots.get(key, ()):
+            check(L.gct2_plan_set_arg(self.handle, rec, arg, _slot_bits(t, value)), "gct2_plan_set_arg")
+
+    def segments(self) -> int:
+        return len(self.cuts)
+
+    def run_segment(self, k: int):
+        """runs segment k and returns the payload of the cut that ends it (None for the last)"""
+        first = self.cuts[k - 1][0] if k else 0
+        last, payload = self.cuts[k]
+        if last > first:
+            failed = C.c_int(-1)
+            rc = load().gct2_plan_run(self.handle, first, last - first, C.byref(failed))
+            if rc != 0:
+                check(rc, f"gct2_plan_run (record {failed.value})")
+        return payload
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and _lib is not None:
+                _lib.gct2_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:       # interpreter shutdown
+            pass
 
 
 class Context:

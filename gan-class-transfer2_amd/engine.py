@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, F16, F32, call
+from ._lib import BF16, F16, F32, Slot, call
 
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
@@ -200,6 +200,23 @@ class _Buffers:
     pass
 
 
+class _StepPlan:
+    """one recorded train step (UNetEngine._planned_step): the gct2_plan, the buffer set it was recorded on, the host-side state the
+    step leaves behind"""
+
+    def __init__(self, b: _Buffers):
+        self.plan = _lib.Plan()
+        self.b = b                     # (holds the buffer set: its id() is part of the plan's key)
+        self.loss = None
+        self.after: dict = {}
+        self.d_off_t = self.d_off_eps = self.d_its = 0
+        self.adam_inputs: dict = {}
+        self.x_ref = None
+
+
+_ADAM_INPUT_FIELDS = ("p", "m", "v", "shadow", "shadow_dtype", "n", "beta1", "beta2", "eps", "grad_mul", "defer")
+
+
 class UNetEngine:
     """the planned (zero-copy concat) forward / backward / optimizer step of the Denoiser U-Net."""
 
@@ -279,6 +296,16 @@ class UNetEngine:
         self._defer_ctxs: Dict[str, "_lib.Context"] = {}
         self._defer_ws: Dict[str, torch.Tensor] = {}
         self.arena.before_read = self.flush_deferred
+        # one gct2_adam_args per layer for the engine's lifetime (filled in place every step): a step plan bakes their addresses
+        self._adam_args: Dict[str, "_lib.AdamArgs"] = {}
+        # step plans (r05, include/gct2.h gct2_plan): the C-ABI calls, event records and stream waits of a train step are recorded ONCE
+        # per step shape and replayed by one C call per step (per segment when a gradient-ready hook is installed) instead of ~90
+        # interpreter round trips; same calls, same arguments, same streams - same bits (tests/test_step_gpu.py).  Steps with injected
+        # t_int / eps or a non-default objective, and anything outside train_step, stay eager.
+        self.use_plan = True
+        self._plans: Dict[tuple, "_StepPlan"] = {}
+        self._plan_seen: Dict[tuple, int] = {}
+        self.plan_after = 2              # a step shape is recorded once it has been seen this many times (buffers and deferrals warmed)
         self.ls_state = None
         if loss_scaling:
             self.enable_loss_scaling()
@@ -317,6 +344,26 @@ class UNetEngine:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    # ---- stream plumbing: torch events when the step runs eagerly, plan records while a step plan is being recorded ---------------
+    def _mark(self, stream: "torch.cuda.Stream"):
+        """a point on `stream` that another stream can wait for"""
+        P = _lib._recording
+        if P is not None:
+            return P.record(stream.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
+    def _wait(self, stream: "torch.cuda.Stream", token) -> None:
+        P = _lib._recording
+        if P is not None:
+            P.wait(stream.cuda_stream, token)
+        else:
+            stream.wait_event(token)
+
+    def _wait_stream(self, waiter: "torch.cuda.Stream", other: "torch.cuda.Stream") -> None:
+        self._wait(waiter, self._mark(other))
+
     # ---- deferred optimizer steps ------------------------------------------------------------------------------------------
     def _defer_ctx(self, layer: str) -> "_lib.Context":
         """the call context of a deferred layer's weight gradient: its own slab scratch, everything else mirrored from self.ctx
@@ -353,16 +400,17 @@ class UNetEngine:
             # the launches write p / m / v / shadow of the deferred layers and read their slabs; the caller may be on ANY stream
             # (predict / state_dict / the sampler on an evaluation stream): whatever uses the parameters or the slabs next - the next
             # forward pass, the next reverse pass, on whichever stream - waits for this event first
-            self._flush_event = torch.cuda.Event()
-            self._flush_event.record(cur)
+            if _lib._recording is None:                          # (inside a recorded step the plan's own records order everything)
+                self._flush_event = torch.cuda.Event()
+                self._flush_event.record(cur)
         if self._pending_event is not None:
-            cur.wait_event(self._pending_event)
+            self._wait(cur, self._pending_event)
             self._pending_event = None
         self._pending_names = set()
 
     def _after_flush(self, stream: "torch.cuda.Stream") -> None:
         """orders `stream` behind the last flush_deferred() that ran on another stream (no-op otherwise)"""
-        if self._flush_event is not None:
+        if self._flush_event is not None and _lib._recording is None:      # (train_step has waited before it records or replays)
             stream.wait_event(self._flush_event)
 
     def check_input_shape(self, H: int, W: int) -> None:
@@ -459,8 +507,8 @@ class UNetEngine:
         as sample_noise + noise_into_r0, bit-identical result, no eps round trip through HBM)."""
         s = self._stream()
         out, ldout, out2, ldout2 = self._noise_targets(b)
-        call("gct2_rng_uniform_int", self.rng_seed, 1, self.rng_offset_t, b.t_int.data_ptr(), b.B, 1, self.steps, s)
-        call("gct2_noise_image_rng", self.dtype, x.data_ptr(), b.t_int.data_ptr(), self.rng_seed, 2, self.rng_offset_eps,
+        call("gct2_rng_uniform_int", self.rng_seed, 1, Slot("off_t", self.rng_offset_t), b.t_int.data_ptr(), b.B, 1, self.steps, s)
+        call("gct2_noise_image_rng", self.dtype, Slot("x", x.data_ptr()), b.t_int.data_ptr(), self.rng_seed, 2, Slot("off_eps", self.rng_offset_eps),
              b.eps.data_ptr() if keep_eps else None, out, ldout, out2, ldout2, b.B, b.H * b.W, 3, self.steps, s)
         self.rng_offset_t += b.B
         self.rng_offset_eps += b.eps.numel()
@@ -501,7 +549,7 @@ class UNetEngine:
 
         def join_pending() -> None:                             # the deferred updates are done before their weights are read
             if self._pending_event is not None:
-                cur.wait_event(self._pending_event)
+                self._wait(cur, self._pending_event)
                 self._pending_event = None
                 self._pending_names = set()
 
@@ -519,12 +567,9 @@ class UNetEngine:
                 plane(i + 1, t.fu(i + 1))
             call("gct2_conv4s2_fwd", cx, dt, x, ldx, A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"), y, ldy, b.B, H, W, t.cx(i), t.fd(i), 1, s)
             if i == window_at and self._pending:
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                self._side.wait_event(ev)
+                self._wait_stream(self._side, cur)
                 self._launch_pending(self._side.cuda_stream)
-                self._pending_event = torch.cuda.Event()
-                self._pending_event.record(self._side)
+                self._pending_event = self._mark(self._side)
         for i in reversed(range(n)):                            # UpShuffle_i    (train.py:188)
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
@@ -547,10 +592,10 @@ class UNetEngine:
              M, t.fu(0) + 3, 3, s)
         return b.pred
 
-    def loss_and_dpred(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
+    def loss_and_dpred(self, b: _Buffers, target: torch.Tensor, target_is_x: bool = False) -> torch.Tensor:
         """fp32 MSE against the clean image (predict_x, train.py:243-244,262-272) and its gradient."""
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
-        call("gct2_mse_fwd_bwd", b.pred.data_ptr(), target.data_ptr(), b.dpred.data_ptr(), b.loss.data_ptr(),
+        call("gct2_mse_fwd_bwd", b.pred.data_ptr(), Slot("x", target.data_ptr()) if target_is_x else target.data_ptr(), b.dpred.data_ptr(), b.loss.data_ptr(),
              b.partials.data_ptr(), b.pred.numel(), ls_ptr, self._stream())
         return b.loss
 
@@ -602,12 +647,12 @@ class UNetEngine:
         return (self.use_fused_head and self.dtype != F32 and self.topo.fu(0) == 64 and self.workspace is not None
                 and not self.objective_weighted())
 
-    def head_train(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
+    def head_train(self, b: _Buffers, target: torch.Tensor, target_is_x: bool = False) -> torch.Tensor:
         """Dense(3) + fp32 MSE + both of their gradients in one pass over R_0 (gct2_dense_head_train)."""
         t, A = self.topo, self.arena
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
         call("gct2_dense_head_train", self.ctx.handle, self.dtype, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), A.pptr("dense.b"),
-             target.data_ptr(), b.pred.data_ptr() if self.keep_pred else None, b.dR[0].data_ptr(), b.ldd[0], A.gptr("dense.w"), A.gptr("dense.b"),
+             Slot("x", target.data_ptr()) if target_is_x else target.data_ptr(), b.pred.data_ptr() if self.keep_pred else None, b.dR[0].data_ptr(), b.ldd[0], A.gptr("dense.w"), A.gptr("dense.b"),
              b.loss.data_ptr(), b.partials.data_ptr(), b.B * b.H * b.W, t.fu(0) + 3, 3, t.fu(0), ls_ptr, A.gptr("U0.b"),
              b.img.data_ptr(), 4, 0, self._stream())
         return b.loss
@@ -620,7 +665,7 @@ class UNetEngine:
         Hs, Ws = b.hw[1]
         return Hs % 16 == 0 and Ws % 16 == 0 and self.workspace.numel() >= b.B * (Hs // 16) * (Ws // 16) * 288
 
-    def u0_head_train(self, b: _Buffers, target: torch.Tensor) -> torch.Tensor:
+    def u0_head_train(self, b: _Buffers, target: torch.Tensor, target_is_x: bool = False) -> torch.Tensor:
         """UpShuffle_0 forward + Dense(3) + fp32 MSE + both gradients in one launch: R_0 is never written, dR_0 receives the
         gradient w.r.t. UpShuffle_0's pre-activation (train.py:188, 198-202, 262-272)."""
         t, A, n = self.topo, self.arena, self.topo.octaves
@@ -628,15 +673,26 @@ class UNetEngine:
         x, ldx = (b.R[1].data_ptr(), b.ld[1]) if n > 1 else (b.Dlast.data_ptr(), t.fd(0))
         ls_ptr = self.ls_state.data_ptr() if self.ls_state is not None else None
         call("gct2_convT4s2_fwd_head_train", self.ctx.handle, self.dtype, x, ldx, A.wptr("U0.w"), A.pptr("U0.b"),
-             A.pptr("dense.w"), A.pptr("dense.b"), target.data_ptr(), b.pred.data_ptr() if self.keep_pred else None,
-             b.dR[0].data_ptr(), b.ldd[0],
+             A.pptr("dense.w"), A.pptr("dense.b"), Slot("x", target.data_ptr()) if target_is_x else target.data_ptr(),
+             b.pred.data_ptr() if self.keep_pred else None, b.dR[0].data_ptr(), b.ldd[0],
              A.gptr("dense.w"), A.gptr("dense.b"), b.loss.data_ptr(), b.B, Hi, Wi, t.up_in(0), t.fu(0), t.fu(0) + 3, 3, ls_ptr,
              A.gptr("U0.b"), b.img.data_ptr(), 4, 0, self._stream())
         return b.loss
 
-    def _ready(self, layer: str) -> None:
-        if self.grad_ready_hook is not None:
+    def _ready(self, layer: str, stream: Optional["torch.cuda.Stream"] = None) -> None:
+        """gradient-ready hook of `layer` (data-parallel wrappers), called with `stream` - the stream whose kernels produced the
+        gradients - current.  While a step plan is being recorded the hook is NOT called: the plan is cut here and the replay calls
+        it between two segments."""
+        if self.grad_ready_hook is None:
+            return
+        P = _lib._recording
+        if P is not None:
+            P.cut((layer, stream))
+        elif stream is None:
             self.grad_ready_hook(layer)
+        else:
+            with torch.cuda.stream(stream):
+                self.grad_ready_hook(layer)
 
     def backward(self, b: _Buffers, head_done: bool = False, adam_inline: bool = False) -> None:
         """reverse pass (what tape.gradient does inside Keras fit, train.py:516); fills the g arena.
@@ -653,7 +709,7 @@ class UNetEngine:
             self._chain_stream = torch.cuda.Stream(device=self.device, priority=-1)
         main = self._chain_stream if (self.overlap and self.chain_priority) else caller
         if main is not caller:
-            main.wait_stream(caller)
+            self._wait_stream(main, caller)
         self._after_flush(main)
         side = self._side if self.overlap else main
         s, sw = main.cuda_stream, side.cuda_stream
@@ -661,14 +717,11 @@ class UNetEngine:
         if not head_done:
             call("gct2_dense_bwd", dt, b.R[0].data_ptr(), b.ld[0], A.pptr("dense.w"), b.dpred.data_ptr(), b.dR[0].data_ptr(),
                  b.ldd[0], A.gptr("dense.w"), A.gptr("dense.b"), M, t.fu(0) + 3, 3, t.fu(0), 0, s)
-        with torch.cuda.stream(main):                           # hooks record their events on the stream the gradients come from
-            self._ready("dense")
+        self._ready("dense", main)                              # hooks record their events on the stream the gradients come from
 
         def side_waits_main() -> None:                          # side stream: everything enqueued on main so far is visible
             if side is not main:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
+                self._wait_stream(side, main)
 
         # adam_inline: every layer's Keras-Adam step is fused behind its weight-gradient call (gct2_adam_args): the gradient of
         # the kernel is consumed from the launch's partial sums or from the arena without ever being zeroed.  The update writes
@@ -679,18 +732,24 @@ class UNetEngine:
         if self._pending:                                       # (a reverse pass without a forward pass in front of it: scripts, tests)
             self.flush_deferred()
 
+        alpha = self.adam_alpha() if adam_inline else 0.0
+
         def fused(layer: str):
             if not adam_inline:
                 return None
             lo, hi = A.layer_ranges[layer]
-            args = _lib.AdamArgs(A._p.data_ptr() + 4 * lo, A._m.data_ptr() + 4 * lo, A._v.data_ptr() + 4 * lo,
-                                 (A._shadow.data_ptr() + 2 * lo) if A._shadow is not None else None, self.dtype, hi - lo,
-                                 self.adam_alpha(), self.beta_1, self.beta_2, self.epsilon, 1.0)
+            args = self._adam_args.get(layer)                   # one struct per layer for the engine's lifetime: stable addresses
+            if args is None:
+                args = self._adam_args[layer] = _lib.AdamArgs()
+            args.p, args.m, args.v = A._p.data_ptr() + 4 * lo, A._m.data_ptr() + 4 * lo, A._v.data_ptr() + 4 * lo
+            args.shadow = (A._shadow.data_ptr() + 2 * lo) if A._shadow is not None else None
+            args.shadow_dtype, args.n = self.dtype, hi - lo
+            args.alpha, args.beta1, args.beta2, args.eps, args.grad_mul = alpha, self.beta_1, self.beta_2, self.epsilon, 1.0
+            args.defer = 1 if layer in deferred else 0
             if layer in deferred:
-                args.defer = 1
                 self._pending.append(("layer", layer, args))
                 self._pending_names.add(layer)
-            keep.append(args)
+            used.append(layer)
             return ctypes.addressof(args)
 
         def wctx(layer: str) -> int:                            # a deferred layer's slabs must outlive the step: its own scratch
@@ -698,7 +757,8 @@ class UNetEngine:
                 return cx
             return self._defer_ctx(layer).handle
 
-        keep: list = []
+        used: list = []                                         # layers whose optimizer step rides on their weight-gradient call
+        self._fused_layers = used
         for i in range(n):                                      # UpShuffle_i backward, outermost first
             Hi, Wi = b.hw[i + 1]
             if i < n - 1:
@@ -727,8 +787,7 @@ class UNetEngine:
             side_waits_main()                                   # dz (and this layer's bias gradient) are complete
             call("gct2_convT4s2_wgrad", wctx(f"U{i}"), dt, x, ldx, dz, lddz, A.gptr(f"U{i}.w"), db_u, b.B, Hi, Wi, t.up_in(i), t.fu(i), 0,
                  fused(f"U{i}"), sw)
-            with torch.cuda.stream(side):
-                self._ready(f"U{i}")
+            self._ready(f"U{i}", side)
             if not adam_inline:
                 dgrad_u()
         for i in reversed(range(n)):                            # DownShuffle_i backward, innermost first
@@ -755,27 +814,24 @@ class UNetEngine:
                 # these parameters before the next forward pass); the data-parallel wrappers get their hook at the end instead.
                 if adam_inline:
                     if not head_done and side is not main:      # UpShuffle_0's bias gradient came from its weight-gradient call (side stream)
-                        main.wait_stream(side)
+                        self._wait_stream(main, side)
                     self._apply_adam(*A.layer_ranges["fp32"], stream=s)
             if i == 0 and adam_inline and side is not main and self.tail_on_chain and self.workspace is not None:
                 call("gct2_conv4s2_wgrad", self.ctx_tail.handle, dt, xw, ldxw, dz, lddz, A.gptr("D0.w"), None, b.B, H, W, t.cx(0),
                      t.fd(0), 0, fused("D0"), s)
-                with torch.cuda.stream(main):
-                    self._ready("D0")
+                self._ready("D0", main)
                 continue
             side_waits_main()
             call("gct2_conv4s2_wgrad", cx, dt, xw, ldxw, dz, lddz, A.gptr(f"D{i}.w"), None, b.B, H, W, t.cx(i), t.fd(i), 0,
                  fused(f"D{i}"), sw)
-            with torch.cuda.stream(side):
-                self._ready(f"D{i}")
+            self._ready(f"D{i}", side)
             if not adam_inline:
                 dgrad_d()
         if side is not main:
-            main.wait_stream(side)
-        with torch.cuda.stream(main):                           # last hook: both streams' gradient writers are in front of it
-            self._ready("fp32")
+            self._wait_stream(main, side)
+        self._ready("fp32", main)                               # last hook: both streams' gradient writers are in front of it
         if main is not caller:
-            caller.wait_stream(main)
+            self._wait_stream(caller, main)
 
     # ---- optimizer (train.py:50-65,75) -----------------------------------------------------------
     def learning_rate(self, k: Optional[int] = None) -> float:
@@ -808,7 +864,7 @@ class UNetEngine:
         alpha = 0.0 if self.ls_state is not None else self.adam_alpha()
         shadow = None if A._shadow is None else A._shadow.data_ptr() + 2 * lo
         call("gct2_adam_keras_multi", A._p.data_ptr() + 4 * lo, A._m.data_ptr() + 4 * lo, A._v.data_ptr() + 4 * lo,
-             A.g.data_ptr() + 4 * lo, shadow, self.dtype, hi - lo, alpha, self.beta_1, self.beta_2,
+             A.g.data_ptr() + 4 * lo, shadow, self.dtype, hi - lo, Slot("alpha", alpha), self.beta_1, self.beta_2,
              self.epsilon, 1.0 / grad_div, ls_ptr, 0, s)
 
     def finish_step(self) -> None:
@@ -840,6 +896,16 @@ class UNetEngine:
         B, H, W, _ = x.shape
         b = self.buffers(B, H, W)
         inline = apply and self.fuse_adam and self.ls_state is None
+        cur = torch.cuda.current_stream(self.device)
+        if self._flush_event is not None:                      # a flush on another stream (predict / state_dict there): the step waits once
+            cur.wait_event(self._flush_event)
+            self._flush_event = None
+        if self.use_plan and t_int is None and eps is None and self.default_objective() and _lib._recording is None:
+            return self._planned_step(b, x, apply, inline, cur)
+        return self._step_body(b, x, t_int, eps, apply, inline)
+
+    def _step_body(self, b: _Buffers, x: torch.Tensor, t_int, eps, apply: bool, inline: bool) -> torch.Tensor:
+        """the C-ABI calls of one train step in order (run eagerly, or recorded into a step plan by _planned_step)"""
         if not inline:
             self.flush_deferred()                              # (a fused step schedules them inside its forward pass instead)
         self.begin_step()
@@ -860,16 +926,21 @@ class UNetEngine:
         fused = self.fused_head_ok()
         if fused and self.fused_u0_head_ok(b):
             self.forward(b, head=False, stop_before_u0=True, planes=True, in_step=True)
-            loss = self.u0_head_train(b, target)
+            loss = self.u0_head_train(b, target, default_obj)
         else:
             self.forward(b, head=not fused, planes=True, in_step=True)
             if weighted:
                 loss = self.weighted_loss_and_dpred(b, target, w)
             else:
-                loss = self.head_train(b, target) if fused else self.loss_and_dpred(b, target)
+                loss = self.head_train(b, target, default_obj) if fused else self.loss_and_dpred(b, target, default_obj)
         # single GPU without loss scaling: Adam rides the side stream inside backward(); the loss-scaled step has to see
         # every gradient (finite check) before any update
         self.flush_deferred()                                  # (no-op after a forward pass that scheduled them; covers octaves < 4 corner cases)
+        if _lib._recording is not None:
+            # the per-layer gct2_adam_args structs are read when a call is MADE: the deferred launches of the previous step (enqueued by
+            # the forward pass above) must see the previous step's alpha, the weight-gradient calls below this step's - the replay
+            # refreshes the structs between the two segments
+            _lib._recording.cut(("__alpha__", None))
         self.backward(b, head_done=fused, adam_inline=inline)
         self._grads_in_arena = not inline
         if apply:
@@ -878,6 +949,84 @@ class UNetEngine:
                 self.apply_adam()
             self.finish_step()
         return loss
+
+    # ---- step plans ------------------------------------------------------------------------------------------------------------
+    def _plan_key(self, b: _Buffers, apply: bool, inline: bool, cur: "torch.cuda.Stream") -> tuple:
+        """everything the call list of a step depends on besides the per-step slots"""
+        return (id(b), apply, inline, cur.cuda_stream, self.ctx.version, self.ctx_tail.version,
+                tuple(sorted((k, c.version) for k, c in self._defer_ctxs.items())), tuple(l for _, l, _ in self._pending),
+                self.grad_ready_hook is not None, self.overlap, self.chain_priority, self.fuse_adam, self.defer_adam, tuple(self.defer_layers),
+                self.defer_window_at, self.tail_on_chain, self.use_fused_head, self.fuse_u0_head, self.keep_pred, self.relu_bits,
+                self.ls_state is not None, self.workspace is not None, self.wgrad_workspace is not None, self.steps, self.rng_seed)
+
+    def _planned_step(self, b: _Buffers, x: torch.Tensor, apply: bool, inline: bool, cur: "torch.cuda.Stream") -> torch.Tensor:
+        key = self._plan_key(b, apply, inline, cur)
+        sp = self._plans.get(key)
+        if sp is None:
+            seen = self._plan_seen[key] = self._plan_seen.get(key, 0) + 1
+            if seen < self.plan_after:
+                return self._step_body(b, x, None, None, apply, inline)
+            if len(self._plans) >= 8:                          # bounded: the oldest plan goes (and with it its events)
+                self._plans.pop(next(iter(self._plans)))
+            # record WITHOUT executing (host state - RNG offsets, deferrals, counters - advances exactly as in the eager step), then
+            # replay what was recorded: the recording step itself already runs through the plan
+            off_t, off_eps, its = self.rng_offset_t, self.rng_offset_eps, self._iterations
+            # recording fills the per-layer gct2_adam_args structs for THIS step, but the deferred launches of the previous step (which
+            # the replay below enqueues first) read theirs when they are made: put those back before replaying
+            held = {l: bytes(a) for _, l, a in self._pending}
+            sp = _StepPlan(b)
+            sp.plan.begin(execute=False)
+            try:
+                sp.loss = self._step_body(b, x, None, None, apply, inline)
+            finally:
+                sp.plan.end()
+            sp.after = dict(pending=list(self._pending), pending_names=set(self._pending_names), bits_valid=b.bits_valid,
+                            grads_in_arena=self._grads_in_arena, fused_layers=list(getattr(self, "_fused_layers", [])))
+            # the per-layer gct2_adam_args structs are shared with eager steps (which may fill them differently: another deferral
+            # set, another range): a replay puts the recorded inputs back first
+            sp.adam_inputs = {l: {f: getattr(self._adam_args[l], f) for f in _ADAM_INPUT_FIELDS} for l in sp.after["fused_layers"]}
+            sp.d_off_t, sp.d_off_eps, sp.d_its = self.rng_offset_t - off_t, self.rng_offset_eps - off_eps, self._iterations - its
+            self.rng_offset_t, self.rng_offset_eps, self._iterations = off_t, off_eps, its      # (the replay below advances them)
+            for l, raw in held.items():
+                ctypes.memmove(ctypes.addressof(self._adam_args[l]), raw, len(raw))
+            # the post-step state (deferrals pending for the NEXT forward pass) must be the pre-step state of a steady-state replay:
+            # a plan recorded on a step that started without deferrals is used for exactly such steps (its key says so)
+            self._plans[key] = sp
+        return self._replay(sp, x, inline)
+
+    def _replay(self, sp: "_StepPlan", x: torch.Tensor, inline: bool) -> torch.Tensor:
+        P = sp.plan
+        P.set("x", x.data_ptr())
+        P.set("off_t", self.rng_offset_t)
+        P.set("off_eps", self.rng_offset_eps)
+        alpha = self.adam_alpha() if self.ls_state is None else 0.0
+        P.set("alpha", alpha)
+        sp.x_ref = x                                            # keeps the batch alive until the next step replaces it
+        hook = self.grad_ready_hook
+        for k in range(P.segments()):
+            payload = P.run_segment(k)
+            if payload is None:
+                continue
+            layer, stream = payload
+            if layer == "__alpha__":                            # between the forward and the reverse pass (see _step_body): until here the
+                for l, fields in sp.adam_inputs.items():        # structs of the deferred layers belonged to the PREVIOUS step's launches
+                    a = self._adam_args[l]
+                    for f, v in fields.items():
+                        setattr(a, f, v)
+                    a.alpha = alpha
+            elif hook is not None:
+                if stream is None:
+                    hook(layer)
+                else:
+                    with torch.cuda.stream(stream):
+                        hook(layer)
+        a = sp.after
+        self.rng_offset_t += sp.d_off_t
+        self.rng_offset_eps += sp.d_off_eps
+        self._iterations += sp.d_its
+        self._pending, self._pending_names, self._pending_event = list(a["pending"]), set(a["pending_names"]), None
+        sp.b.bits_valid, self._grads_in_arena = a["bits_valid"], a["grads_in_arena"]
+        return sp.loss
 
     def predict(self, noised: torch.Tensor) -> torch.Tensor:
         B, H, W, _ = noised.shape

@@ -66,6 +66,8 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * bits 0-7  : forward / input-gradient tile: 0 = automatic, 2 = 128x128 (two LDS buffers), 5 = 256x128 (one buffer, 8 waves);
  * bit 8     : the forward / input-gradient GEMMs never split their reduction over work-groups (parity tests at reduced batch: the
  *             kernels of the batch-64 dispatch then run the way they do at batch 64);
+ * bits 9-10 : halo-tile kernel form: 0 = automatic, 1 = 8 waves on 16 x 16 patches (146 KiB of LDS: one work-group per CU), 2 = 4 waves
+ *             on 16 x 8 patches (78 KiB: two work-groups per CU cover each other's prologue / epilogue; bit-identical outputs);
  * bits 16-23: weight-gradient tile: 0 = automatic, 2 = 256x256 five-stage ring, 4 = the same in the r03 stage order (bit-identity
  *             test of the r04 order), 3 = 128x128, 7 = 128x128 with fp32 atomics instead of ordered slabs (arrival-order
  *             dependent: comparison tests only);
@@ -346,6 +348,31 @@ int gct2_adam_keras_multi(float* p, float* m, float* v, float* g, void* shadow, 
 
 /* fp32 -> dtype cast of a flat array (initial weight shadows). */
 int gct2_cast_from_f32(int dtype, const float* src, void* dst, size_t n, void* stream);
+
+/* ---- step plans (ABI v15): Keras `fit` (train.py:516) runs one compiled train function per step; this is its counterpart ----
+ * A plan is a host-side list of records - calls of the entry points above, event records, stream waits - built once and replayed
+ * by ONE call per step (or per segment of a step, where the caller interleaves work of its own: the data-parallel exchange
+ * hooks).  A replayed record is exactly the call it records: same entry point, same arguments, same stream - same kernels, same
+ * bits.  Arguments are passed as one 64-bit slot each: pointers and 64-bit integers as they are, `int` sign-extended, `float` as
+ * its bit pattern in the low 32 bits, `double` as its bit pattern.  Values that change from step to step (the input batch, RNG
+ * offsets, the optimizer's alpha) are re-set with gct2_plan_set_arg before a run; structs passed by pointer (gct2_adam_args) are
+ * read at run time, so the caller may update them in place.  A plan belongs to ONE host thread at a time, like the ctx objects its
+ * records name; it creates one HIP event per event record (no timing, device-scope release) and destroys them with the plan.
+ * Plannable entry points: every function of this header that takes a stream, plus gct2_ctx_set_relu_bits. */
+typedef struct gct2_plan gct2_plan;
+int gct2_plan_create(gct2_plan** plan);
+int gct2_plan_destroy(gct2_plan* plan);
+/* appends a call of entry point `name` ("gct2_conv4s2_fwd", ...); nargs must equal the entry point's parameter count; *index (may
+ * be NULL) receives the record's position */
+int gct2_plan_add_call(gct2_plan* plan, const char* name, const uint64_t* args, int nargs, int* index);
+/* appends "record a new event on `stream`" / "make `stream` wait for event `event`" (an earlier add_record of this plan) */
+int gct2_plan_add_record(gct2_plan* plan, void* stream, int* event);
+int gct2_plan_add_wait(gct2_plan* plan, void* stream, int event);
+int gct2_plan_size(const gct2_plan* plan, int* records);
+int gct2_plan_set_arg(gct2_plan* plan, int index, int arg, uint64_t value);
+/* executes records [first, first + count) in order; stops at the first record that fails, returns its status (message:
+ * gct2_last_error) and, if `failed` is non-NULL, stores its index there (-1 when all succeeded) */
+int gct2_plan_run(gct2_plan* plan, int first, int count, int* failed);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,8 @@ args = ap.parse_args()
 dev = torch.device("cuda", 0)
 dt = {"bf16": g.BF16, "f16": g.F16}[args.dtype]
 eng = g.UNetEngine(g.Topology(128, 512, 6), dt, dev, loss_scaling=(args.dtype == "f16"))
-eng.overlap = False                       # one stream: every call is replayed alone
+eng.overlap = False
+eng.use_plan = False                      # every call goes through the interpreter: this script records / replays them                       # one stream: every call is replayed alone
 if args.no_planes:
     eng.relu_bits = False
 if args.tuning:

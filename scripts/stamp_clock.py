@@ -30,6 +30,7 @@ dev = torch.device("cuda", 0)
 B, S = 64, 128
 eng = g.UNetEngine(g.Topology(128, 512, 6), g.BF16, dev)
 eng.overlap = False
+eng.use_plan = False                      # every call goes through the interpreter: this script records / replays them
 if args.tuning:
     eng.ctx.set_tuning(args.tuning)
 x = (torch.randint(0, 256, (B, S, S, 3)).float() / 128 - 1).to(dev)

@@ -83,7 +83,7 @@ def test_call_context_is_host_only_and_independent():
     assert L.gct2_ctx_set_workspace(a.handle, 4096, 1 << 20) == 0 and L.gct2_ctx_set_workspace(a.handle, None, 0) == 0
     assert L.gct2_ctx_set_tuning(b.handle, 2 | (3 << 16) | (1 << 24)) == 0 and L.gct2_ctx_force_direct(b.handle, 1) == 0
     assert L.gct2_ctx_set_tuning(b.handle, 7) == 1 and b"unknown tuning" in L.gct2_last_error()           # a tile that was pruned in r04
-    assert L.gct2_ctx_set_tuning(b.handle, 0x200) == 1                                                     # ... and a removed switch
+    assert L.gct2_ctx_set_tuning(b.handle, 0x600) == 1                                                     # ... and a removed switch
     assert L.gct2_ctx_set_workspace(None, None, 0) == 1                                                    # null ctx
     for name in ("gct2_set_workspace", "gct2_set_wgrad_workspace", "gct2_debug_tapgemm_variant", "gct2_debug_force_direct"):
         assert not hasattr(L, name), name                           # the process-wide hooks of ABI v10 are gone
@@ -278,3 +278,36 @@ def test_bench_kernel_symbol_and_labels():
     a = (0, 1, 0, 512, 0, 0, 0, 512, 64, 16, 16, 512, 512, 1, None)       # gct2_conv4s2_fwd of DownShuffle_3
     assert bench.call_label("gct2_conv4s2_fwd", a) == ("D3", "fwd")
     assert abs(bench.call_flops("gct2_conv4s2_fwd", a) / 1e9 - 34.360) < 1e-2
+
+
+def test_step_plan_records_replays_and_reports_the_failing_record():
+    """gct2_plan on the host alone (no GPU: every recorded call is rejected by its argument checks, which run before any launch):
+    records are appended in order, slots are re-set by key, a run stops at the first failing record and says which one, segments
+    end at the cuts, entry points a plan cannot hold are executed right away instead of being recorded."""
+    import gan_class_transfer2_amd as g
+    L = g._lib
+    c = L.Context()
+    p = L.Plan()
+    p.begin(execute=False)
+    c.set_tuning(2)                                                   # not plannable: executed immediately, not recorded
+    assert c.tuning == 2 and p.n == 0
+    L.call("gct2_rng_uniform_int", 1, 1, L.Slot("off", 0), None, 4, 1, 200, None)          # record 0: null output -> EINVAL at run time
+    p.cut("after-rng")
+    L.call("gct2_conv4s2_fwd", c.handle, 1, 16, 8, 16, None, 16, 8, 1, L.Slot("H", 5), 4, 8, 8, 1, None)   # record 1: odd H
+    p.end()
+    assert p.n == 2 and p.segments() == 2 and L._recording is None
+    with pytest.raises(g.Gct2Error, match=r"record 0.*rng_uniform_int"):
+        p.run_segment(0)
+    with pytest.raises(g.Gct2Error, match=r"record 1.*must be even"):
+        p.run_segment(1)
+    p.set("H", 4)                                                     # the slot is re-set in place: the same record now fails later,
+    with pytest.raises(g.Gct2Error, match=r"record 1"):               # for another reason (still before any launch)
+        p.run_segment(1)
+    assert "even" not in L.load().gct2_last_error().decode()
+    # direct C calls: unknown entry point, wrong arity, bad indices
+    lib = L.load()
+    arr = (ctypes.c_uint64 * 2)(0, 0)
+    assert lib.gct2_plan_add_call(p.handle, b"gct2_ctx_create", arr, 1, None) == 1 and b"not an entry point" in lib.gct2_last_error()
+    assert lib.gct2_plan_add_call(p.handle, b"gct2_add", arr, 2, None) == 1 and b"takes 8 arguments" in lib.gct2_last_error()
+    assert lib.gct2_plan_set_arg(p.handle, 7, 0, 0) == 1 and lib.gct2_plan_run(p.handle, 1, 5, None) == 1
+    assert lib.gct2_plan_add_wait(p.handle, None, 3) == 1

@@ -99,8 +99,11 @@ def test_medium_step_lowp_vs_rounded_oracle(gpu, dtype, rounding, parity_log):
         assert errs[k] <= tol[2], (k, errs[k])
 
 
-def test_config2_bf16_vs_fp32_cpu_oracle(gpu):
-    """BASELINE.json config 2: 3x64x64, bs 32, octaves 6, bf16 step vs the fp32 CPU oracle: loss within 1e-3 rel."""
+def test_config2_bf16_vs_fp32_cpu_oracle(gpu, parity_log):
+    """BASELINE.json config 2 AT SIZE (3x64x64, bs 32, octaves 6, bf16 step): (a) against the plain fp32 CPU oracle - north_star's bound:
+    loss within 1e-3 relative; (b) against the numpy oracle WITH the bf16 rounding model (operands, stored activations and activation
+    gradients rounded as the kernels round them), tensor by tensor with the per-level bounds of the config-3 slice test (r05: the
+    r04 check at this size was the unrounded comparison only, 25 % per tensor)."""
     from oracle import torch_cross as T
     cfg = O.OracleConfig(size=64, batch_size=32, octaves=6)
     params = O.init_params(cfg, seed=1234, dtype=np.float32)
@@ -112,18 +115,30 @@ def test_config2_bf16_vs_fp32_cpu_oracle(gpu):
     torch.cuda.synchronize()
     assert abs(float(loss[0]) - loss_ref) <= 1e-3 * loss_ref
     b = eng.buffers(32, 64, 64)
-    assert rel_l2(b.pred.cpu().numpy(), pred_ref) <= 1e-2
-    # gradients: bf16 storage of activations / activation gradients through 12 layers whose gradient norms decay
-    # ~10x per level (|g| 4e-1 at the head, 4e-7 at the bottleneck) leaves 0.5 % (U0) .. 16 % (D5) relative error
-    # per tensor against UNROUNDED fp32 (measured; the fp32 HIP mode itself differs from torch-CPU fp32 by 1e-3
-    # there).  Bound the whole gradient vector tightly and every tensor loosely; the tight per-tensor check is
-    # test_medium_step_lowp_vs_rounded_oracle (same rounding model on both sides).
+    pred = b.pred.cpu().numpy()
+    assert rel_l2(pred, pred_ref) <= 1e-2
+    # (a) gradients against UNROUNDED fp32: bf16 storage of activations / activation gradients through 12 layers whose gradient norms
+    # decay ~10x per level leaves 0.5 % (U0) .. 16 % (D5) per tensor, inherent to the storage type: only the whole vector is bounded here
     grads = eng.get_grads()
     names = sorted(grads)
     flat = np.concatenate([grads[k].ravel() for k in names]); flat_ref = np.concatenate([grads_ref[k].ravel() for k in names])
     assert rel_l2(flat, flat_ref) <= 1e-2
-    worst = max(rel_l2(grads[k], grads_ref[k]) for k in grads)
-    assert worst <= 0.25, worst
+    # (b) the same step through the oracle's rounding model: every tensor, bounds by level (gradient norms fall ~10x per level and
+    # every level adds two 16-bit tensors in series: measured growth x1.8 per level, as at config 3)
+    loss_r, pred_r, grads_r, _ = O.trainer_step({k: v.astype(np.float64) for k, v in params.items()}, x.astype(np.float64), t_int,
+                                                eps.astype(np.float64), cfg, operand_round="bf16")
+    gerr = {k: rel_l2(grads[k], grads_r[k]) for k in grads}
+    by_level = {}
+    for k, e in gerr.items():
+        level = int(k[1]) if k[0] in "DU" else 0
+        by_level[level] = max(by_level.get(level, 0.0), e)
+    parity_log("config2_at_size_bf16_vs_rounded_oracle", loss_rel=abs(float(loss[0]) - loss_r) / loss_r, pred_rel_l2=rel_l2(pred, pred_r),
+               loss_rel_vs_fp32=abs(float(loss[0]) - loss_ref) / loss_ref, grad_vector_rel_l2_vs_fp32=rel_l2(flat, flat_ref),
+               **{f"worst_grad_level{l}": e for l, e in sorted(by_level.items())}, **{"grad_" + k: e for k, e in sorted(gerr.items())})
+    assert abs(float(loss[0]) - loss_r) <= 1e-3 * loss_r and rel_l2(pred, pred_r) <= 3e-3
+    for k, e in gerr.items():
+        level = int(k[1]) if k[0] in "DU" else 0
+        assert e <= (1e-2, 2e-2, 3e-2, 4.5e-2, 8e-2, 1.4e-1)[level], (k, e)
 
 
 def test_denoiser_eager_layers_match_planned_engine(gpu):
@@ -363,10 +378,72 @@ def test_flush_on_another_stream_orders_the_next_step(gpu):
                 with torch.cuda.stream(other):
                     preds.append(e.predict(x[:1]).clone())          # flushes on `other` in the deferring engine
         torch.cuda.synchronize()
-    assert engs[0]._flush_event is not None
     assert torch.equal(preds[0], preds[1])
     for name in ("p", "m", "v", "shadow"):
         assert torch.equal(getattr(engs[0].arena, name), getattr(engs[1].arena, name)), name
+
+
+@pytest.mark.parametrize("mode", ["fused", "apply_false", "loss_scaled", "serial"])
+def test_planned_step_equals_eager_step_bit_for_bit(gpu, mode):
+    """step plans (gct2_plan): a train step replayed from its recorded call list - one C call per step - against
+    the same steps run call by call through the interpreter: losses, every arena, the RNG positions and the counters must be EQUAL
+    (the plan holds the same entry-point calls with the same arguments on the same streams).  Six steps each: warm-up steps run
+    eagerly, the third is recorded and replayed, the rest are replays with fresh slots (batch pointer, RNG offsets, alpha)."""
+    import gan_class_transfer2_amd as g
+    cfg = O.OracleConfig(size=64, pixel_size=128, max_size=512, octaves=4, batch_size=4)
+    params = O.init_params(cfg, seed=3)
+    xs = [torch.tensor(O.synthetic_batch(cfg, seed=k)[0], dtype=torch.float32, device=gpu) for k in range(3)]
+    out = []
+    for use_plan in (False, True):
+        eng = make_engine(cfg, 2 if mode == "loss_scaled" else 1, gpu, rng_seed=5, loss_scaling=(mode == "loss_scaled"))
+        eng.use_plan = use_plan
+        eng.overlap = mode != "serial"
+        eng.set_params(params)
+        losses = []
+        for k in range(6):
+            if mode == "apply_false":
+                losses.append(eng.train_step(xs[k % 3], apply=False).clone())
+                eng.check_finite(); eng.apply_adam(); eng.finish_step()
+            else:
+                losses.append(eng.train_step(xs[k % 3]).clone())
+            if k == 3:
+                eng.arena.p                                   # an outside reader between two steps: flushes the deferred updates
+        torch.cuda.synchronize()
+        if use_plan:
+            assert len(eng._plans) >= 1 and all(sp.plan.n > 20 for sp in eng._plans.values())
+        else:
+            assert not eng._plans
+        out.append((torch.cat(losses), {n: getattr(eng.arena, n).clone() for n in ("p", "m", "v", "shadow")},
+                    (eng.iterations, eng.rng_offset_t, eng.rng_offset_eps)))
+    assert torch.equal(out[0][0], out[1][0]), (out[0][0], out[1][0])
+    assert out[0][2] == out[1][2]
+    for n in ("p", "m", "v", "shadow"):
+        assert torch.equal(out[0][1][n], out[1][1][n]), n
+
+
+def test_planned_step_with_gradient_ready_hook_runs_the_hook_between_segments(gpu):
+    """a gradient-ready hook (the data-parallel wrappers) cuts the plan into segments; the replay calls it at the same points, in
+    the same order, with the producing stream current - and the arenas equal the eager run's."""
+    cfg = O.OracleConfig(size=32, pixel_size=128, max_size=256, octaves=3, batch_size=4)
+    params = O.init_params(cfg, seed=3)
+    x = torch.tensor(O.synthetic_batch(cfg, seed=0)[0], dtype=torch.float32, device=gpu)
+    res = []
+    for use_plan in (False, True):
+        eng = make_engine(cfg, 1, gpu, rng_seed=5)
+        eng.use_plan = use_plan
+        eng.set_params(params)
+        seen = []
+        names = {eng._side.cuda_stream: "side", torch.cuda.current_stream(gpu).cuda_stream: "caller"}      # (stream handles differ per engine)
+        eng.grad_ready_hook = lambda layer: seen.append((layer, names[torch.cuda.current_stream(gpu).cuda_stream]))
+        for _ in range(4):
+            del seen[:]
+            eng.train_step(x, apply=False)
+            eng.apply_adam(); eng.finish_step()
+        torch.cuda.synchronize()
+        res.append((list(seen), eng.arena.p.clone(), eng.arena.g.clone()))
+    assert [l for l, _ in res[0][0]] == [l for l, _ in res[1][0]] and len(res[0][0]) == 2 * 3 + 2     # dense, U0-2, D2-0, fp32
+    assert res[0][0] == res[1][0]                                   # ... on the same streams
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
 def test_config3_full_size_properties(gpu):
