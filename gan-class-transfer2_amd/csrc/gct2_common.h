@@ -26,7 +26,6 @@ struct gct2_ctx {
   int tap_variant = 0;                             // forward / input-gradient tile: 0 = automatic, 2 = 128 x 128, 5 = 256 x 128
   int wgrad_variant = 0;                           // weight-gradient tile: 0 = automatic, 2 = 256 x 256, 4 = 256 x 256 in the r03 stage order, 3 = 128 x 128, 7 = 128 x 128 with atomics
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
-  int halo_waves = 0;                              // halo kernel form: 0 = automatic, 1 = 8 waves on 16 x 16 patches (one work-group per CU), 2 = 4 waves on 16 x 8 (two)
   int xcd_order = 0;                               // tile -> XCD order: 0 = automatic, 1 = m-tile bands, 2 = weight slices
   int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile: 0 = automatic, v: 2^(v-1)
   int no_splitk = 0;                               // 1: forward / input-gradient GEMMs never split their reduction (tuning bit 8)
@@ -283,7 +282,6 @@ struct TapGemmParams {
   int bits_words = 0;                    // 1: plane and strides are 4-byte aligned and N % 32 == 0 -> the four lane rows of a pixel merge their bytes into ONE 32-bit store
   unsigned char* bits = nullptr; int ldbits = 0;   // ReLU bit plane [pixel][ldbits bytes], bit k of byte c = (channel 8c + k of the view > 0):
                                          // EPI_BIAS_ACT writes it beside y, EPI_MASK reads it instead of act (16-byte epilogues only)
-  int stagger = 0;                       // halo kernel, 4-wave form: start offset of the second work-group of every CU (10-ns ticks)
   int ws_shift = -1, hs_shift = -1;      // log2 of Ws / Hs when they are powers of two (filled by the launcher), else -1: the per-lane
                                          // pixel decode then uses shifts instead of four integer divisions per row
 #ifdef GCT2_STAMP

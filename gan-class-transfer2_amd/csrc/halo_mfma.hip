@@ -17,7 +17,6 @@
 // Needs Hs, Ws multiples of 16.  Epilogues: bias + ReLU (forward) or mask / accumulate / bias-gradient rows (Conv2D dgrad).
 #include "gct2_common.h"
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -35,14 +34,6 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_pie
 __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_piece, 16, (int)voff, (int)soff, 0, 0);
 }
-// the same as inline asm: invisible to hipcc's own vmcnt bookkeeping, so the counted waits of the 4-wave K loop are exactly the ones
-// written there (hipcc drains to vmcnt(0) at loop heads and in front of LDS reads it cannot tell apart from a DMA target)
-__device__ __forceinline__ void dma16s_hidden(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, unsigned voff, unsigned soff) {
-  const unsigned lds_addr = (unsigned)(uintptr_t)(lds_void_t*)lds_piece;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory", "m0");
-}
-#define GCT2_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 __device__ __forceinline__ int halo_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1); }
 // Weight image: fragment i of a wave holds the output channels 32 (i>>1) + 8 g + 4 (i&1) + r in its lane group g, so that the
 // fragments 2k and 2k+1 together give every lane EIGHT consecutive channels of its pixel -> 16-byte stores / mask loads in the
@@ -55,19 +46,6 @@ constexpr int HP = 18;                        // halo pitch (pixels per halo row
 constexpr int HPIECES = 41;                   // 1-KiB pieces (8 pixel rows each) covering the 324 halo pixels
 constexpr int HALO_BYTES = HPIECES * 1024;
 constexpr int WB_BYTES = 4 * 64 * 128;        // 4 phases x 64 n-rows x 128 B
-// ---- the 4-wave form (r05): a work-group = ONE wave per output phase on a 16 x 8 patch (the tile of one wave of the 8-wave form) ----
-// Two such work-groups share a CU (same 234 registers per wave, 78 KiB of LDS each), so one's prologue and epilogue - 10-40 % of
-// a work-group's life, all of it exposed at one work-group per CU (profiles/r04_kernel_clock.txt; without the epilogue's memory
-// accesses the eleven big forward / input-gradient launches take 833 instead of 1015 us, gpurun ablation r05) - run under the
-// other's K loop.  Weights are WAVE-PRIVATE here (a phase has one wave): each wave streams its own 64 n x 32 k half-round images
-// (4 KiB, 64-byte rows) through a two-deep ping-pong with counted vmcnt waits and NO barrier; only the halo image (10 x 18 pixel
-// rows, double-buffered) is shared, so the work-group meets at ONE barrier per 64-channel chunk (256 multiplies per wave).
-constexpr int HPIECES4 = 23;                  // 180 halo pixel rows = 22.5 pieces
-constexpr int HALO4_BYTES = HPIECES4 * 1024;
-constexpr int WH_BYTES = 64 * 64;             // one half-round weight image of one wave: 64 n-rows x 64 B (32 k)
-// chunk swizzle of the 64-byte-row weight image: keyed on bits 3-4 of the row, conflict-free for ds_read_b128 with the gathered
-// rows w_row(i, q) (checked against the lane groups of MI355X_MICROARCH.md, LDS table: scripts/lds_swizzle_search.py)
-__device__ __forceinline__ int w4_swz(int n) { return (4 - ((n >> 3) & 3)) & 3; }
 
 #ifdef GCT2_STAMP
 __device__ __forceinline__ unsigned long long stamp() {
@@ -84,49 +62,33 @@ __device__ __forceinline__ unsigned long long stamp() {
 // The DMA pieces of the next round (and of the next halo) are issued BETWEEN the MFMA groups of the current round instead of in
 // front of them: a piece costs 60-185 cycles of issue time (MI355X_MICROARCH.md), during which the wave issues nothing else, and the
 // two waves of a SIMD reach that block together (r03: -3..-6 % against the r02 order, which is gone)
-template <typename T, int EPI, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p) {
-  static_assert(NW == 8 || NW == 4, "8 waves on a 16 x 16 patch, or 4 waves on a 16 x 8 patch");
-  constexpr int PR = NW == 8 ? 16 : 8;                         // patch rows
-  constexpr int NT = NW * 64;
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void halo_convT_kernel(TapGemmParams p) {
 #ifdef GCT2_STAMP
   unsigned long long st[6];
   STAMP(0);
 #endif
   // ONE array, the halo images first: every fragment address of the lean rounds is a per-lane register + a 16-bit immediate
   // (EPI_HEAD: 14 KiB more - the rest of the CU's 160 KiB - for the operand images of the Dense kernel, built while the first DMA is in flight)
-  // NW = 4: [halo 0 | halo 1 | per wave: two half-round weight images]; the operand images of the Dense kernel (EPI_HEAD) are built
-  // AFTER the K loop there, into the then-free buffers (48 KiB behind the start: clear of the park images and tables)
-  constexpr int HB = NW == 8 ? HALO_BYTES : HALO4_BYTES;
-  constexpr int KLOOP_BYTES = NW == 8 ? 2 * HALO_BYTES + 2 * WB_BYTES : 2 * HALO4_BYTES + 4 * 2 * WH_BYTES;
-  constexpr int HEAD_CT_OFF = NW == 8 ? KLOOP_BYTES : 48 * 1024, HEAD_CT_BYTES = 14 * 1024;
-  static_assert(NW == 8 || HEAD_CT_OFF + HEAD_CT_BYTES <= KLOOP_BYTES, "NW = 4: the Dense operand images fit into the K loop's buffers");
-  __shared__ __attribute__((aligned(16))) char lds_all[KLOOP_BYTES + ((EPI == EPI_HEAD && NW == 8) ? HEAD_CT_BYTES : 0)];
+  constexpr int HEAD_CT_OFF = 2 * HALO_BYTES + 2 * WB_BYTES, HEAD_CT_BYTES = 14 * 1024;
+  __shared__ __attribute__((aligned(16))) char lds_all[2 * HALO_BYTES + 2 * WB_BYTES + (EPI == EPI_HEAD ? HEAD_CT_BYTES : 0)];
   char* const halo0 = lds_all;
-  char* const wb0 = lds_all + 2 * HALO_BYTES;                  // (NW = 8)
+  char* const halo1 = lds_all + HALO_BYTES;
+  char* const wb0 = lds_all + 2 * HALO_BYTES;
+  char* const wb1 = lds_all + 2 * HALO_BYTES + WB_BYTES;
 
   GCT2_CLOCK_DECL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int phase = NW == 8 ? wave >> 1 : wave, mhalf = NW == 8 ? (wave & 1) : 0;
+  const int phase = wave >> 1, mhalf = wave & 1;
   const int ph = phase >> 1, pw = phase & 1;
   const int g = lane >> 4, q = lane & 15;
   const int Hs = p.Hs, Ws = p.Ws, K = p.K, N = p.N;
-  const int tx_n = Ws >> 4, ty_n = Hs / PR;
+  const int tx_n = Ws >> 4, ty_n = Hs >> 4;
   int m_tile, n_tile;
   if (!xcd_tile((int)blockIdx.x, p.m_tiles, p.n_tiles, p.xcd_chunk, m_tile, n_tile)) return;
-  if constexpr (NW == 4) {
-    // two work-groups share a CU and would run in lock step (same start, same work): both in their K loops, then both in their
-    // epilogues.  The SECOND work-group of every CU (ids 256..511 under the observed round-robin placement: speed only) starts
-    // p.stagger x 10 ns late, once; the offset carries over to every later work-group of that slot, so one slot's prologue / epilogue
-    // runs under the other's K loop.  Bounded wait on the 100-MHz counter.
-    if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      for (int spin = 0; spin < 4096 && __builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger; spin++) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   const int tx = m_tile % tx_n, tq = m_tile / tx_n, ty = tq % ty_n, b = tq / ty_n;
-  const int sh0 = ty * PR, sw0 = tx * 16, n0 = n_tile * 64;
+  const int sh0 = ty * 16, sw0 = tx * 16, n0 = n_tile * 64;
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x), rs_w = make_rsrc(p.w);
   const int ldx2 = p.ldx * 2;
 
@@ -137,15 +99,13 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
   int h_lchunk[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    // NW = 4: 23 pieces over 4 waves; wave 3 has five - its sixth slot repeats its fifth piece (the same bytes to the same place), so
-    // that every wave issues the same number of DMA operations and the counted waits of the K loop are immediates
-    const int pi = NW == 8 ? wave + 8 * i : ((wave + 4 * i) < HPIECES4 ? wave + 4 * i : wave + 4 * (i - 1));
+    const int pi = wave + 8 * i;
     const int row = 8 * pi + (lane >> 3);
     const int hy = row / HP, hx = row - hy * HP;
     const int lchunk = (lane & 7) ^ halo_swz(hx);
     h_lchunk[i] = lchunk;
     h_voff[i] = OOB;
-    if (pi < (NW == 8 ? HPIECES : HPIECES4) && row < HP * (PR + 2)) {
+    if (pi < HPIECES && row < HP * HP) {
       const int y = sh0 - 1 + hy, x = sw0 - 1 + hx;
       if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) h_voff[i] = (unsigned)(((b * Hs + y) * Ws + x) * ldx2 + lchunk * 16);
     }
@@ -159,13 +119,12 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
   const int nk = (K + 63) / 64;
   const int nround = 4 * nk;                                   // (k-chunk, tap round (a, c))
 
-  auto halo_piece = [&](int i) { return NW == 8 ? wave + 8 * i : ((wave + 4 * i) < HPIECES4 ? wave + 4 * i : wave + 4 * (i - 1)); };
   auto issue_halo = [&](int kc, char* hbuf) {
     const int c0 = kc * 64;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      const int pi = halo_piece(i);
-      if (pi < (NW == 8 ? HPIECES : HPIECES4))                 // wave-uniform
+      const int pi = wave + 8 * i;
+      if (pi < HPIECES)                                        // wave-uniform
         dma16s(rs_x, hbuf + pi * 1024, (c0 + h_lchunk[i] * 8) < K ? h_voff[i] : OOB, (unsigned)(c0 * 2));
     }
   };
@@ -205,19 +164,6 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
     const int n = w_row(0, q);
     fw[kk] = 2 * HALO_BYTES + phase * 8192 + n * 128 + (((4 * kk + g) ^ w_swz(n)) << 4);
   }
-  // ---- NW = 4: wave-private weight stream ------------------------------------------------------------------------------
-  // half-round image of this wave: [64 n][64 B]; DMA piece pc = rows 16 pc .. 16 pc + 15: lane -> row 16 pc + (lane >> 2), physical
-  // chunk lane & 3 = logical chunk ^ w4_swz(row); fragment i of lane (g, q): row w_row(i, q), logical chunk g (w4_swz is the same for
-  // the four fragments: bits 3-4 of w_row(i, q) come from q alone)
-  constexpr int W4_OFF = 2 * HALO4_BYTES;
-  unsigned w4_voff[4];
-#pragma unroll
-  for (int pc = 0; pc < 4; pc++) {
-    const int row = 16 * pc + (lane >> 2);
-    const int lc = (lane & 3) ^ w4_swz(row);
-    w4_voff[pc] = (n0 + row) < N ? (unsigned)(((n0 + row) * K + lc * 8) * 2) : OOB;
-  }
-  const int fw4 = W4_OFF + wave * (2 * WH_BYTES) + w_row(0, q) * 64 + ((g ^ w4_swz(w_row(0, q))) << 4);
   const int kfull4 = 4 * (K / 64);                             // rounds of FULL 64-channel chunks
   // idx = round & 7 (literal at every call site: tap and buffer roles fold into immediates); hcur/hnext/wcur/wnext = byte offsets
   // of the buffers inside their group.  FAST: every piece of the next round exists and lies in a full chunk - no tail logic.
@@ -246,7 +192,7 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
           dma16s(rs_w, lds_all + 2 * HALO_BYTES + wnext + i * 8192 + wave * 1024, wv, (unsigned)tap16 * NK2 + s_k);
         }
         if (kk == 1 && j < 6 && halo_due) {                    // halo piece j of the next k-chunk
-          const int pi = halo_piece(j);
+          const int pi = wave + 8 * j;
           if (pi < HPIECES)
             dma16s(rs_x, lds_all + hnext + pi * 1024, FAST ? h_voff[j] : ((c0n + h_lchunk[j] * 8) < K ? h_voff[j] : OOB), s_k);
         }
@@ -265,11 +211,13 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
     r = r - to_f32<T>(b2);
     return (uint32_t)__builtin_bit_cast(uint16_t, from_f32<T>(r));
   };
-  auto build_head_operands = [&]() {
-    {
+  GCT2_CLOCK_BEGIN;
+  issue_halo(0, halo0);
+  issue_w(0, wb0);
+  if constexpr (EPI == EPI_HEAD) {
     const HeadFuse& hd = p.head;
     const int Cout = hd.Cout;
-    for (int e = tid; e < 14 * 64; e += NT) {
+    for (int e = tid; e < 14 * 64; e += 512) {
       const int ent = e >> 6, L = e & 63, r16 = L & 15, kg = L >> 4;
       uint32_t v[8];
 #pragma unroll
@@ -290,12 +238,6 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
       *reinterpret_cast<u32x4_t*>(lds_all + HEAD_CT_OFF + e * 16) = u32x4_t{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
     }
   }
-  };
-  if constexpr (NW == 8) {
-  GCT2_CLOCK_BEGIN;
-  issue_halo(0, halo0);
-  issue_w(0, wb0);
-  if constexpr (EPI == EPI_HEAD) build_head_operands();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #define GCT2_LEAN_ROUND(FAST, R, IDX, HCUR, HNEXT, WCUR, WNEXT)                              \
@@ -321,81 +263,8 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
   }
 #undef GCT2_LEAN_TRIP
 #undef GCT2_LEAN_ROUND
-  } else {
-    // ---- NW = 4: one wave per phase, wave-private weight halves, the halo image shared; half h = 2 * round + kk ----------------
-    // position t = 0..7 of a half inside its 64-channel chunk: tap round t >> 1 = (a, c), k-half kk = t & 1 (weight buffer kk).
-    // At position t the wave needs W(h) (issued two positions earlier), multiplies, and issues W(h + 2) into the buffer it has just
-    // read its four weight fragments from (behind the first multiplies, which consumed them) and - positions 0..5, while a next
-    // chunk exists - ONE piece of the next chunk's halo.  Everything issued after W(h): the halo piece of position t - 2, W(h + 1)
-    // (4 pieces), the halo piece of position t - 1 -> the counted waits below.  Chunk end: this wave's halo pieces are older than
-    // W(h + 1), W(h + 2) only (8 pieces), then the ONE barrier of the chunk.
-    const unsigned w4_lds = W4_OFF + wave * (2 * WH_BYTES);
-    auto issue_wh_piece = [&](int r, int kk, int pc) __attribute__((always_inline)) {
-      const int kc2 = r >> 2, a2 = (r >> 1) & 1, c2 = r & 1;
-      const int tap16 = (1 - ph + 2 * a2) * 4 + (1 - pw + 2 * c2);
-      dma16s_hidden(rs_w, lds_all + w4_lds + kk * WH_BYTES + pc * 1024, w4_voff[pc], (unsigned)tap16 * NK2 + (unsigned)((kc2 * 64 + kk * 32) * 2));
-    };
-    const bool live = nk > 0;                                  // always true, opaque: every half stays its own scheduling region
-    int fac[2][2];
-    auto mul_half = [&](auto t_c, auto issue_c, auto halo_c, int kc, int hnext) __attribute__((always_inline)) {
-      constexpr int t = decltype(t_c)::value;
-      constexpr bool ISSUE = decltype(issue_c)::value, HALO = decltype(halo_c)::value;
-      constexpr int a = (t >> 2) & 1, c = (t >> 1) & 1, kk = t & 1;
-      const int r2 = 4 * kc + ((t + 2) >> 1);
-      // all twelve fragment reads of the half up front (the DMA statements below are compiler-level memory barriers: a read placed
-      // behind one could not be hoisted over it, and 4 multiplies do not cover an LDS read), then the 32 multiplies back to back
-      // with this half's five DMA pieces between them
-      u32x4_t wf[4], af[8];
-#pragma unroll
-      for (int i = 0; i < 4; i++) wf[i] = lds_read128(lds_all, fw4 + kk * WH_BYTES + (32 * (i >> 1) + 4 * (i & 1)) * 64);
-#pragma unroll
-      for (int j = 0; j < 8; j++) af[j] = lds_read128(lds_all, fac[c][kk] + (1 - a + j) * HP * 128);
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
-        if (ISSUE && j < 4) issue_wh_piece(r2, kk, j);
-        if (HALO && j == 4) dma16s_hidden(rs_x, lds_all + hnext + halo_piece(t < 6 ? t : 0) * 1024, h_voff[t < 6 ? t : 0], (unsigned)((kc + 1) * 128));
-      }
-    };
-#define GCT2_H4(T_, N_, ISSUE_, HALO_)                                                                                                         \
-    GCT2_WAIT_VM(N_);                                                                                                                          \
-    if (live) mul_half(std::integral_constant<int, T_>{}, std::integral_constant<bool, ISSUE_>{}, std::integral_constant<bool, HALO_>{}, kc, hnext);
-    // prologue: the first halo, the two weight halves of round 0
-    GCT2_CLOCK_BEGIN;
-#pragma unroll
-    for (int i = 0; i < 6; i++) dma16s_hidden(rs_x, lds_all + halo_piece(i) * 1024, h_voff[i], 0u);
-#pragma unroll
-    for (int pc = 0; pc < 4; pc++) { issue_wh_piece(0, 0, pc); }
-#pragma unroll
-    for (int pc = 0; pc < 4; pc++) { issue_wh_piece(0, 1, pc); }
-    GCT2_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
-    int kc = 0;
-    for (; kc + 1 < nk; kc++) {                                // chunks that prefetch the next chunk's halo
-      const int hcur = (kc & 1) * HALO4_BYTES, hnext = HALO4_BYTES - hcur;
-#pragma unroll
-      for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int k2 = 0; k2 < 2; k2++) fac[c][k2] = fa[c][k2] + hcur;
-      GCT2_H4(0, 4, true, true) GCT2_H4(1, 5, true, true) GCT2_H4(2, 6, true, true) GCT2_H4(3, 6, true, true)
-      GCT2_H4(4, 6, true, true) GCT2_H4(5, 6, true, true) GCT2_H4(6, 6, true, false) GCT2_H4(7, 5, true, false)
-      GCT2_WAIT_VM(8);
-      __builtin_amdgcn_s_barrier();
-    }
-    {                                                          // the last chunk: no halo to fetch, the weight stream runs out
-      const int hcur = (kc & 1) * HALO4_BYTES, hnext = 0;
-#pragma unroll
-      for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int k2 = 0; k2 < 2; k2++) fac[c][k2] = fa[c][k2] + hcur;
-      GCT2_H4(0, 4, true, false) GCT2_H4(1, 4, true, false) GCT2_H4(2, 4, true, false) GCT2_H4(3, 4, true, false)
-      GCT2_H4(4, 4, true, false) GCT2_H4(5, 4, true, false) GCT2_H4(6, 4, false, false) GCT2_H4(7, 0, false, false)
-    }
-#undef GCT2_H4
-  }
 #ifdef GCT2_STAMP
-  GCT2_CLOCK_END(p.clock ? p.stamps : nullptr, NW, wave, lane);
+  GCT2_CLOCK_END(p.clock ? p.stamps : nullptr, 8, wave, lane);
 #endif
 
   // ---- epilogue: lane holds out[pixel (row mhalf*8 + j, col q)][n = n0 + 32 (i>>1) + 8 g + 4 (i&1) + r], phase (ph, pw) ----
@@ -429,19 +298,15 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
     const int Cout = hd.Cout;
     constexpr int YP_WAVE = 64 * 128;                       // park image of HALF a wave's pixels: 64 pixel rows x 128 B
     constexpr int CT_OFF = HEAD_CT_OFF;                     // operand images of the Dense kernel: 6 (F) + 8 (G) entries x 64 lanes x 16 B (built before the K loop)
-    constexpr int DT_OFF = NW * YP_WAVE;                    // dpred^T terms: [wave][2 terms][3 outputs][64 pixels] x 2 B
+    constexpr int DT_OFF = 8 * YP_WAVE;                     // dpred^T terms: [wave][2 terms][3 outputs][64 pixels] x 2 B
     constexpr int DT_WAVE = 2 * 3 * 64 * 2;
-    constexpr int PC_OFF = DT_OFF + NW * DT_WAVE;           // per-pixel constants of lane group 0: [3 image channels][4] Dense rows, then the Dense bias [4]
+    constexpr int PC_OFF = DT_OFF + 8 * DT_WAVE;            // per-pixel constants of lane group 0: [3 image channels][4] Dense rows, then the Dense bias [4]
     constexpr int LB_OFF = PC_OFF + 64;                     // the layer's own bias [64] (LDS reads per row instead of global loads: those would sit in
     static_assert(LB_OFF + 256 <= HEAD_CT_OFF, "epilogue LDS map");                      // vmcnt behind the previous row's stores and wait for them)
     auto fsw = [](int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); };      // chunk swizzle of the park image (conflict-free transposed reads)
     auto term_bits = head_term_bits;
     const T* __restrict__ x2 = reinterpret_cast<const T*>(hd.x2);
     const int nimg = (x2 != nullptr) ? min(hd.Cin - 64, 3) : 0;
-    if constexpr (NW == 4) {                                 // every wave is out of the K loop's buffers; the Dense operand images go there now
-      __builtin_amdgcn_s_barrier();
-      build_head_operands();
-    }
     if (tid < 16) {                                          // lane group 0's per-pixel constants (read back per row: registers are scarce here)
       const int c = tid >> 2, o = tid & 3;
       float v = 0.f;
@@ -589,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
     __syncthreads();                                       // every wave is done with its park image and tables
     STAMP(4);
     float* red = reinterpret_cast<float*>(lds_all);        // [8][HEAD_ROW]
-    for (int i = tid; i < NW * HEAD_ROW; i += NT) red[i] = 0.f;
+    for (int i = tid; i < 8 * HEAD_ROW; i += 512) red[i] = 0.f;
     __syncthreads();
     float* rw = red + wave * HEAD_ROW;
     if (eg == 0) {                                         // (W): rows o = r of lane group 0, column = channel 16 f + (lane & 15)
@@ -619,19 +484,19 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
       if (elane == 0) rw[219] = t;
     }
     __syncthreads();
-    for (int e = tid; e < HEAD_ROW; e += NT) {               // (288 entries: more than the 256 threads of the 4-wave form)
-      float t = red[e];
+    if (tid < HEAD_ROW) {
+      float t = red[tid];
 #pragma unroll
-      for (int k = 1; k < NW; k++) t += red[k * HEAD_ROW + e];
-      hd.part[(size_t)m_tile * HEAD_ROW + e] = t;
+      for (int k = 1; k < 8; k++) t += red[k * HEAD_ROW + tid];
+      hd.part[(size_t)m_tile * HEAD_ROW + tid] = t;
     }
 #ifdef GCT2_STAMP
     STAMP(5);
     if (p.stamps && (tid & 63) == 0) {
-      unsigned long long* o = p.stamps + ((size_t)m_tile * NW + wave) * 8;
+      unsigned long long* o = p.stamps + ((size_t)m_tile * 8 + wave) * 8;
       for (int k = 0; k < 6; k++) o[k] = st[k];
     }
-    GCT2_CLOCK_EXIT(p.clock ? p.stamps : nullptr, NW, wave, lane);
+    GCT2_CLOCK_EXIT(p.clock ? p.stamps : nullptr, 8, wave, lane);
 #endif
     return;
   }
@@ -719,8 +584,7 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
   if (EPI == EPI_MASK && (p.db || p.db2)) {
     // all 8 waves cover the same 64 channels: butterfly over the 16 pixel lanes, meet in LDS (free after the last barrier of the
     // K loop), ONE partial row per work-group for the ordered row reduction (no atomics); without a workspace: atomics
-    float* red = reinterpret_cast<float*>(NW == 8 ? wb0 : lds_all);
-    if constexpr (NW == 4) __builtin_amdgcn_s_barrier();       // (the 4-wave K loop ends without one: slower waves may still read the halo)
+    float* red = reinterpret_cast<float*>(wb0);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -742,13 +606,13 @@ __global__ __launch_bounds__(NW * 64, 2) void halo_convT_kernel(TapGemmParams p)
       if (tid < 64 && n0 + tid < N) {
         float t = red[tid];
 #pragma unroll
-        for (int k = 1; k < NW; k++) t += red[k * 64 + tid];
+        for (int k = 1; k < 8; k++) t += red[k * 64 + tid];
         p.dbws[(size_t)m_tile * N + n0 + tid] = t;
       }
     }
   }
 #ifdef GCT2_STAMP
-  GCT2_CLOCK_EXIT(p.clock ? p.stamps : nullptr, NW, wave, lane);
+  GCT2_CLOCK_EXIT(p.clock ? p.stamps : nullptr, 8, wave, lane);
 #endif
 }
 
@@ -761,13 +625,12 @@ int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, h
 bool halo_convT_wanted(const gct2_ctx& c, int epi, const TapGemmParams& p) {
   const int g_halo_mode = c.halo_mode;
   if (g_halo_mode == 1) return false;
-  const bool four_ok = c.halo_waves != 1 && p.K % 64 == 0;      // (the 4-wave form tiles the grid into 16 x 8 patches)
-  if ((p.Hs & (four_ok ? 7 : 15)) || (p.Ws & 15)) return false;
+  if ((p.Hs & 15) || (p.Ws & 15)) return false;
   // 16-byte epilogue accesses: output (and mask) views aligned to 16 bytes with pixel strides that are multiples of 8 elements
   if ((uintptr_t)p.y % 16 || p.ldy % 8 || (p.act && ((uintptr_t)p.act % 16 || p.ldact % 8))) return false;
   if (g_halo_mode == 2) return true;
   // automatic: layers whose source-tile traffic dominates (few output channels per pixel) and that fill the chip
-  const int tiles = p.B * ((p.Hs + 15) >> 4) * (p.Ws >> 4) * ((p.N + 63) / 64);
+  const int tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4) * ((p.N + 63) / 64);
   return p.N <= 256 && tiles >= 256;          // measured vs tapgemm: U0 fwd 177 -> 136 us, U1 fwd 126 -> 120, U2 fwd 124 -> 122, D1 dgrad 88 -> 81, D2 dgrad 70 -> 66
 }
 
@@ -776,30 +639,16 @@ int pw_head_finish(const float* part, int rows, float* dw, float* db, float* los
 
 // UpShuffle_0 forward with the train-step head in its epilogue (EPI_HEAD): needs N = 64 (one n-tile: a wave owns every channel
 // of its pixels), the shape constraints of the halo kernel and room for one partial row per work-group in the workspace.
-// the 4-wave form (16 x 8 patches, two work-groups per CU) wherever its K loop applies: whole 64-channel chunks; tuning bits 9-10 force
-// one form (1 = 8 waves, 2 = 4 waves)
-static bool halo_four_waves(const gct2_ctx& c, const TapGemmParams& p) {
-  if (c.halo_waves == 1 || p.K % 64 || (p.Hs & 7)) return false;
-  return true;
-}
-// start offset of the second work-group of every CU (4-wave form), in 10-ns ticks; 0 = none
-static int halo_stagger(const TapGemmParams& p, int head) {
-  if (const char* e = getenv("GCT2_HALO_STAGGER")) return atoi(e);      // diagnostics: A/B of the offset
-  (void)p; (void)head;
-  return 0;
-}
 bool halo_head_supported(const gct2_ctx& c, int dtype, const TapGemmParams& p) {
   if (dtype != GCT2_BF16 && dtype != GCT2_F16) return false;
   if (p.N != 64 || (p.Hs & 15) || (p.Ws & 15) || p.K % 8 || p.ldx % 8) return false;
   if ((uintptr_t)p.y % 16 || p.ldy % 8 || (uintptr_t)p.x % 16 || (uintptr_t)p.w % 16) return false;
-  const size_t rows = (size_t)p.B * (p.Hs >> 4) * (p.Ws >> 4);          // (the 4-wave form leaves two rows per 16 x 16 patch: it needs twice this
-  return c.ws && c.ws_bytes >= rows * HEAD_ROW * sizeof(float);          // and falls back to 8 waves below that)
+  const size_t rows = (size_t)p.B * (p.Hs >> 4) * (p.Ws >> 4);
+  return c.ws && c.ws_bytes >= rows * HEAD_ROW * sizeof(float);
 }
 int halo_head(gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, float* loss, float* db_up, int accumulate,
               hipStream_t s) {
-  const bool four = halo_four_waves(c, p) && c.ws_bytes >= (size_t)p.B * (p.Hs >> 3) * (p.Ws >> 4) * HEAD_ROW * sizeof(float);
-  p.stagger = four ? halo_stagger(p, 1) : 0;
-  p.m_tiles = p.B * (p.Hs >> (four ? 3 : 4)) * (p.Ws >> 4);
+  p.m_tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4);
   p.n_tiles = 1;
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   p.ksplit = 1;
@@ -810,22 +659,15 @@ int halo_head(gct2_ctx& c, int dtype, TapGemmParams p, float* dw, float* db, flo
   p.clock = c.stamps_bytes >= GCT2_CLOCK_BYTES ? 1 : 0;
 #endif
   dim3 grid(8 * p.xcd_chunk);
-  gct2_log(c, "halo:convT:head%s", four ? ":w4" : "");
-  if (four) {
-    if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_HEAD, 4>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_HEAD, 4>), grid, dim3(256), 0, s, p);
-  } else {
-    if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_HEAD, 8>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_HEAD, 8>), grid, dim3(512), 0, s, p);
-  }
+  gct2_log(c, "halo:convT:head");
+  if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_HEAD>), grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_HEAD>), grid, dim3(512), 0, s, p);
   if (int e = gct2_check_launch("halo_head")) return e;
   return pw_head_finish(c.ws, p.m_tiles, dw, db, loss, db_up, p.head.Cin * p.head.Cout, p.head.Cout, 1.0f / p.head.count, accumulate, s);
 }
 
 int halo_convT(gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) {
-  const bool four = halo_four_waves(c, p);
-  p.stagger = four ? halo_stagger(p, 0) : 0;
-  p.m_tiles = p.B * (p.Hs >> (four ? 3 : 4)) * (p.Ws >> 4);
+  p.m_tiles = p.B * (p.Hs >> 4) * (p.Ws >> 4);
   p.n_tiles = (p.N + 63) / 64;
   p.xcd_chunk = (p.m_tiles + 7) / 8;
   p.ksplit = 1;
@@ -841,20 +683,14 @@ int halo_convT(gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) 
   p.clock = c.stamps_bytes >= GCT2_CLOCK_BYTES ? 1 : 0;
 #endif
   dim3 grid(8 * p.xcd_chunk * p.n_tiles);
-  gct2_log(c, "halo:convT:%s%s%s", epi == EPI_BIAS_ACT ? "bias_act" : "mask", p.bits ? ":bits" : "", four ? ":w4" : "");
-#define GCT2_HALO_LAUNCH(TT, E)                                                                              \
-  do {                                                                                                       \
-    if (four) hipLaunchKernelGGL((halo_convT_kernel<TT, E, 4>), grid, dim3(256), 0, s, p);                   \
-    else hipLaunchKernelGGL((halo_convT_kernel<TT, E, 8>), grid, dim3(512), 0, s, p);                        \
-  } while (0)
+  gct2_log(c, "halo:convT:%s%s", epi == EPI_BIAS_ACT ? "bias_act" : "mask", p.bits ? ":bits" : "");
   if (epi == EPI_BIAS_ACT) {
-    if (dtype == GCT2_BF16) GCT2_HALO_LAUNCH(__bf16, EPI_BIAS_ACT);
-    else GCT2_HALO_LAUNCH(_Float16, EPI_BIAS_ACT);
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_BIAS_ACT>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_BIAS_ACT>), grid, dim3(512), 0, s, p);
   } else {
-    if (dtype == GCT2_BF16) GCT2_HALO_LAUNCH(__bf16, EPI_MASK);
-    else GCT2_HALO_LAUNCH(_Float16, EPI_MASK);
+    if (dtype == GCT2_BF16) hipLaunchKernelGGL((halo_convT_kernel<__bf16, EPI_MASK>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((halo_convT_kernel<_Float16, EPI_MASK>), grid, dim3(512), 0, s, p);
   }
-#undef GCT2_HALO_LAUNCH
   if (epi == EPI_BIAS_ACT && p.bits) c.relu_bits_done = 1;      // the epilogue wrote the ReLU bit plane
   if (p.dbws) {
     if (int e = tapgemm_dbpart_reduce(p.dbws, p.m_tiles, p, s)) return e;

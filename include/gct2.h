@@ -66,8 +66,6 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * bits 0-7  : forward / input-gradient tile: 0 = automatic, 2 = 128x128 (two LDS buffers), 5 = 256x128 (one buffer, 8 waves);
  * bit 8     : the forward / input-gradient GEMMs never split their reduction over work-groups (parity tests at reduced batch: the
  *             kernels of the batch-64 dispatch then run the way they do at batch 64);
- * bits 9-10 : halo-tile kernel form: 0 = automatic, 1 = 8 waves on 16 x 16 patches (146 KiB of LDS: one work-group per CU), 2 = 4 waves
- *             on 16 x 8 patches (78 KiB: two work-groups per CU cover each other's prologue / epilogue; bit-identical outputs);
  * bits 16-23: weight-gradient tile: 0 = automatic, 2 = 256x256 five-stage ring, 4 = the same in the r03 stage order (bit-identity
  *             test of the r04 order), 3 = 128x128, 7 = 128x128 with fp32 atomics instead of ordered slabs (arrival-order
  *             dependent: comparison tests only);

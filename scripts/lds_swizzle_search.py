@@ -9,8 +9,6 @@ q = lane&15) fetch logical chunk 4*kk + g of row base + r(q); the image stores l
  1. nimg  : f(row) = (row >> 1) & 7, rows base + q with base % 16 == 0            (gct2_common.h nimg_off)         -> verified
  2. halo  : rows base + q for EVERY base (the tap shift of the halo kernel)       (halo_mfma.hip halo_swz)         -> search
  3. wperm : rows 32(i>>1) + 8(q>>2) + 4(i&1) + (q&3), fragment i = 0..3           (halo_mfma.hip w_row / w_swz)    -> search
- 4. wperm4: the same rows in a 64-byte-row image (32 k per row: the half-round weight images of the 4-wave halo kernel): a byte
-            address row*64 + chunk'*16 falls into slot (row & 3) * 4 + chunk', logical chunk g             (w4_swz)    -> verified
 """
 QA, QB = [0, 1, 2, 3, 12, 13, 14, 15], [4, 5, 6, 7, 8, 9, 10, 11]      # q values of the g-even / g-odd lanes of a group
 
@@ -49,35 +47,6 @@ def main():
     assert all(conflict_free(w_swz, [w_row(i, q) for q in range(16)]) for i in range(4))
     assert not all(conflict_free(nimg, [w_row(i, q) for q in range(16)]) for i in range(4))
     print("3. permuted weight rows: 2*bit3(row) + 4*bit1(row) is conflict-free for all 4 fragments; the nimg swizzle is not")
-
-
-def conflict_free64(f, rows_of_q):
-    """64-byte rows, one k-half per image: lane (g, q) reads logical chunk g of row rows_of_q[q]"""
-    for g_even, g_odd in ((0, 1), (2, 3)):
-        for A, B in ((QA, QB), (QB, QA)):
-            slots = {((rows_of_q[q] & 3) * 4 + (g_even ^ f(rows_of_q[q]))) for q in A}
-            slots |= {((rows_of_q[q] & 3) * 4 + (g_odd ^ f(rows_of_q[q]))) for q in B}
-            if len(slots) < 16:
-                return False
-    return True
-
-
-def main4():
-    w_row = lambda i, q: 32 * (i >> 1) + 8 * (q >> 2) + 4 * (i & 1) + (q & 3)
-    w4_swz = lambda r: (4 - ((r >> 3) & 3)) & 3
-    assert all(conflict_free64(w4_swz, [w_row(i, q) for q in range(16)]) for i in range(4))
-    assert not all(conflict_free64(lambda r: 0, [w_row(i, q) for q in range(16)]) for i in range(4))
-    # the swizzle must not depend on the fragment index (one per-lane address + immediates): bits 3-4 of w_row come from q alone
-    assert all(w4_swz(w_row(i, q)) == w4_swz(w_row(0, q)) for i in range(4) for q in range(16))
-    print("4. 64-byte-row weight halves: chunk ^ {0,3,2,1}[(row >> 3) & 3] is conflict-free for all 4 fragments; no swizzle is not")
-
-
-_main123 = main
-
-
-def main():
-    _main123()
-    main4()
 
 
 if __name__ == "__main__":

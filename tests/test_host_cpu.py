@@ -83,7 +83,7 @@ def test_call_context_is_host_only_and_independent():
     assert L.gct2_ctx_set_workspace(a.handle, 4096, 1 << 20) == 0 and L.gct2_ctx_set_workspace(a.handle, None, 0) == 0
     assert L.gct2_ctx_set_tuning(b.handle, 2 | (3 << 16) | (1 << 24)) == 0 and L.gct2_ctx_force_direct(b.handle, 1) == 0
     assert L.gct2_ctx_set_tuning(b.handle, 7) == 1 and b"unknown tuning" in L.gct2_last_error()           # a tile that was pruned in r04
-    assert L.gct2_ctx_set_tuning(b.handle, 0x600) == 1                                                     # ... and a removed switch
+    assert L.gct2_ctx_set_tuning(b.handle, 0x200) == 1                                                     # ... and a removed switch
     assert L.gct2_ctx_set_workspace(None, None, 0) == 1                                                    # null ctx
     for name in ("gct2_set_workspace", "gct2_set_wgrad_workspace", "gct2_debug_tapgemm_variant", "gct2_debug_force_direct"):
         assert not hasattr(L, name), name                           # the process-wide hooks of ABI v10 are gone

@@ -862,66 +862,6 @@ def test_conv_dgrad_halo_kernel(gpu, shape, use_ws):
         set_ws(None)
 
 
-@pytest.mark.parametrize("dt", [BF16, F16])
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (3, 16, 32, 256, 128), (1, 8, 16, 128, 200), (2, 24, 16, 192, 64)])
-def test_halo_four_wave_form_equals_eight_wave_form(gpu, dt, shape):
-    """the two forms of the halo-tile kernel (tuning bits 9-10: 1 = 8 waves on 16 x 16 patches, 2 = 4 waves - one per output phase -
-    on 16 x 8 patches with a wave-private weight stream, two work-groups per CU) run the same multiplies in the same order per
-    output element: forward outputs (bias + ReLU + bit plane) and input gradients (mask from the plane, accumulation, fused bias
-    sums through partial rows) must be EQUAL bit for bit; both against the oracle.  Shapes: one / several patches, several images,
-    ragged N, a grid whose height tiles into 16 x 8 but not 16 x 16 patches (8-wave form impossible: only the oracle then)."""
-    B, H, W, Cin, Cout = shape
-    L = lib()
-    rng = np.random.default_rng(5)
-    x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
-    wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
-    b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
-    xd, wtd, bd = dev(x, dt, gpu), dev(wt, dt, gpu), torch.tensor(b, dtype=torch.float32, device=gpu)
-    ref = np.maximum(O.convT4s2_fwd(x, wt, b), 0)
-    # input gradient of a Conv2D whose output grid is (H, W): dx on the (2H, 2W) grid, Cin_d = Cout channels, reduction over Cin
-    act = rnd(np.maximum(rng.standard_normal((B, 2 * H, 2 * W, Cout)), 0), dt)
-    wd_ = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)        # Keras Conv2D kernel (kh, kw, Cin_d = Cout, Cout_d = Cin)
-    dz = rnd(rng.standard_normal((B, H, W, Cin)), dt)
-    prev = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
-    contrib = O.conv4s2_bwd(act, wd_, dz)[0] * (act > 0)
-    ws = torch.empty(8 << 18, dtype=torch.float32, device=gpu)
-    set_ws(ws)
-    forms = (1, 2) if H % 16 == 0 else (2,)
-    outs, logs = {}, {}
-    try:
-        for form in forms:
-            set_tuning((2 << 24) | (form << 9))
-            ctx_obj().log_launches(True)
-            y = torch.full((B, 2 * H, 2 * W, Cout), 7.0, dtype=TDT[dt], device=gpu)
-            bits = torch.zeros(B * 4 * H * W, Cout // 8, dtype=torch.uint8, device=gpu)
-            ctx_obj().set_relu_bits(bits.data_ptr(), Cout // 8)
-            L.call("gct2_convT4s2_fwd", ctx(), dt, xd.data_ptr(), Cin, wtd.data_ptr(), bd.data_ptr(), y.data_ptr(), Cout, B, H, W, Cin, Cout, 1, stream())
-            dxd, dzd, wdd, actd = dev(prev, dt, gpu), dev(dz, dt, gpu), dev(wd_, dt, gpu), dev(act, dt, gpu)
-            planes = torch.tensor(_packbits(act, Cout), device=gpu)
-            db = torch.zeros(Cout, device=gpu)
-            ctx_obj().set_relu_bits(planes.data_ptr(), Cout // 8)
-            L.call("gct2_conv4s2_dgrad", ctx(), dt, dzd.data_ptr(), Cin, wdd.data_ptr(), actd.data_ptr(), Cout,
-                   dxd.data_ptr(), Cout, B, 2 * H, 2 * W, Cout, Cin, 1, db.data_ptr(), Cout, None, 0, stream())
-            torch.cuda.synchronize()
-            logs[form] = ctx_obj().read_launch_log()
-            outs[form] = (y, bits, dxd, db)
-            assert rel_l2(y.double().cpu().numpy(), ref) <= TOL_OUT[dt], form
-            assert rel_l2(dxd.double().cpu().numpy(), contrib + prev) <= TOL_OUT[dt], form
-            assert np.array_equal(bits.cpu().numpy(), _packbits(y.float().cpu().numpy(), Cout)), form
-    finally:
-        ctx_obj().log_launches(False)
-        set_tuning(0)
-        set_ws(None)
-    assert sum(t.startswith("halo:convT") and t.endswith(":w4") for t in logs[2]) == 2, logs[2]
-    if 1 in outs:
-        assert sum(t.startswith("halo:convT") and not t.endswith(":w4") for t in logs[1]) == 2, logs[1]
-        for a, c in zip(outs[1][:3], outs[2][:3]):
-            assert torch.equal(a, c)
-        # bias sums: the same masked values, grouped into twice as many partial rows
-        scale = float(outs[1][3].abs().max()) + 1e-6
-        assert float((outs[1][3] - outs[2][3]).abs().max()) <= 1e-5 * scale
-
-
 def _packbits(y, C):
     """bit k of byte c <-> channel 8c + k (include/gct2.h, gct2_ctx_set_relu_bits)"""
     return np.packbits((y[..., :C] > 0).reshape(-1, C), axis=1, bitorder="little")
