@@ -24,6 +24,32 @@ import torch
 import torch.distributed as dist
 
 
+class _Plumbing:
+    """stream ordering and host calls of a data-parallel wrapper.  Through the engine when it has the hooks for it (UNetEngine: while
+    a step plan is being recorded a stream wait becomes a plan record and a collective the end of a plan segment, so a replayed
+    step runs nothing of the wrapper from the interpreter but its collectives); directly otherwise (the CPU stand-in of the tests,
+    a stand-alone reducer)."""
+
+    def __init__(self, engine=None):
+        self.engine = engine
+
+    def stream_waits(self, waiter, other) -> None:
+        f = getattr(self.engine, "_wait_stream", None)
+        if f is not None:
+            f(waiter, other)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(other)
+            waiter.wait_event(ev)
+
+    def host_call(self, fn) -> None:
+        f = getattr(self.engine, "host_call", None)
+        if f is not None:
+            f(fn)
+        else:
+            fn()
+
+
 class BucketedAllReducer:
     """sums `flat[lo:hi]` across ranks, one collective per bucket of consecutive layers.
 
@@ -32,8 +58,9 @@ class BucketedAllReducer:
     collectives beat many small ones: layers are merged until a bucket holds >= bucket_elems elements."""
 
     def __init__(self, flat: torch.Tensor, layer_order: Sequence[str], layer_ranges: Dict[str, Tuple[int, int]],
-                 bucket_elems: int = 4 << 20, group=None, force_exchange: bool = False):
+                 bucket_elems: int = 4 << 20, group=None, force_exchange: bool = False, engine=None):
         self.flat, self.group = flat, group
+        self.pl = _Plumbing(engine)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # force_exchange: issue the collectives even at world size 1 (tests drive the stream plumbing on one GPU)
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
@@ -64,22 +91,31 @@ class BucketedAllReducer:
         lo, hi = self.buckets[idx]
         view = self.flat[lo:hi]
         if self.on_cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.flat.device))
-            self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
-                self.works[idx] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # the communication stream waits for the gradients, then carries the collective: a stream-synchronous call (the
+            # communication stream is blocked until the sum is there, the host is not), so whatever is enqueued on that stream behind
+            # it - the bucket's optimizer step - is ordered without a work handle
+            self.pl.stream_waits(self.comm_stream, torch.cuda.current_stream(self.flat.device))
+            self.pl.host_call(lambda idx=idx: self._issue(idx))
         else:
             self.works[idx] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.launched += 1
 
+    def _issue(self, idx: int) -> None:
+        lo, hi = self.buckets[idx]
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+
     def wait_bucket(self, idx: int) -> Tuple[int, int]:
         """block the CURRENT stream (not the host, on a GPU) until bucket idx holds the global sum."""
+        if self.on_cuda:
+            if self.exchange:
+                cur = torch.cuda.current_stream(self.flat.device)
+                if cur != self.comm_stream:
+                    self.pl.stream_waits(cur, self.comm_stream)
+            return self.buckets[idx]
         w = self.works[idx]
         if w is not None:
             w.wait()
-            if self.on_cuda:
-                torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
         return self.buckets[idx]
 
 
@@ -105,8 +141,11 @@ class DataParallelStep:
     def __init__(self, engine, bucket_elems: int = 4 << 20, group=None, force_exchange: bool = False):
         self.engine = engine
         A = engine.arena
-        self.reducer = BucketedAllReducer(A.g, A.ready_order(), A.layer_ranges, bucket_elems, group, force_exchange)
+        self.reducer = BucketedAllReducer(A.g, A.ready_order(), A.layer_ranges, bucket_elems, group, force_exchange, engine=engine)
+        self.pl = self.reducer.pl
         engine.grad_ready_hook = self._grad_ready
+        engine.hook_plan_aware = True          # the hook below does its plumbing through the engine: recorded with the step
+        engine.post_backward = self._tail
         self.world = self.reducer.world
         self._adam_next = 0            # first bucket whose update has not been enqueued in this step
         _one_stream_less(engine, self.reducer.exchange)
@@ -118,9 +157,9 @@ class DataParallelStep:
 
     def _adam_bucket(self, idx: int) -> None:
         red, eng = self.reducer, self.engine
-        with torch.cuda.stream(red.comm_stream):
-            lo, hi = red.wait_bucket(idx)                       # the comm stream waits for the collective, not the host
-            eng.apply_adam(lo, hi, grad_div=float(self.world))  # mean over ranks folded into the gradient read
+        lo, hi = red.buckets[idx]
+        # on the communication stream, behind the bucket's (stream-synchronous) all-reduce; mean over ranks folded into the gradient read
+        eng.apply_adam(lo, hi, grad_div=float(self.world), stream=red.comm_stream.cuda_stream)
         self._adam_next = idx + 1
 
     def _grad_ready(self, layer: str) -> None:
@@ -138,7 +177,17 @@ class DataParallelStep:
             return eng.train_step(x, t_int, eps, apply=True)
         red.begin()
         self._adam_next = 0
-        loss = eng.train_step(x, t_int, eps, apply=False)      # backward fires _grad_ready per layer
+        self._tail_done = False
+        loss = eng.train_step(x, t_int, eps, apply=False)      # backward fires _grad_ready per layer, then post_backward = _tail
+        if not (self._tail_done or getattr(eng, "post_backward_ran", False)):
+            self._tail()                                         # (an engine without the post_backward hook: the tests' CPU stand-in)
+        return loss
+
+    def _tail(self) -> None:
+        """what follows the reverse pass: the updates of the buckets still open, the caller's stream joins the communication stream,
+        the step counter - part of the step body (UNetEngine.post_backward), so a step plan records it"""
+        eng, red = self.engine, self.reducer
+        self._tail_done = True
         if eng.ls_state is not None:
             # fp16 + dynamic loss scale (train.py:82-83): an inf/nan on ANY rank survives the SUM all-reduce, so the
             # finite check of the reduced arena gives every rank the same skip decision without a second collective
@@ -149,13 +198,12 @@ class DataParallelStep:
         elif red.on_cuda:
             while self._adam_next < len(red.buckets):
                 self._adam_bucket(self._adam_next)
-            torch.cuda.current_stream(eng.device).wait_stream(red.comm_stream)
+            self.pl.stream_waits(torch.cuda.current_stream(eng.device), red.comm_stream)
         else:
             for idx in range(len(red.buckets)):
                 lo, hi = red.wait_bucket(idx)
                 eng.apply_adam(lo, hi, grad_div=float(self.world))
         eng.finish_step()
-        return loss
 
 
 class ShardedDataParallelStep:
@@ -208,7 +256,10 @@ class ShardedDataParallelStep:
         self.last_layer = [next(i for i, e in enumerate(ends) if e >= hi) for _, hi in self.buckets]
         self.on_cuda = A.g.is_cuda
         self.comm_stream = torch.cuda.Stream(device=A.g.device) if self.on_cuda else None
+        self.pl = _Plumbing(engine)
         engine.grad_ready_hook = self._grad_ready
+        engine.hook_plan_aware = True          # the hook does its plumbing through the engine: recorded with the step
+        engine.post_backward = self._tail
         _one_stream_less(engine, self.exchange)
         self.events: List[Tuple[int, object, object]] = []      # (bucket, start, end) of the collectives when timing is on
         self.time_collectives = False
@@ -241,9 +292,7 @@ class ShardedDataParallelStep:
 
     def _comm_waits_current(self) -> None:
         if self.on_cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.engine.device))
-            self.comm_stream.wait_event(ev)
+            self.pl.stream_waits(self.comm_stream, torch.cuda.current_stream(self.engine.device))
 
     def _timed(self, k: int, fn) -> None:
         if self.time_collectives and self.on_cuda:
@@ -256,6 +305,11 @@ class ShardedDataParallelStep:
             fn()
 
     def _reduce_scatter(self, k: int) -> None:
+        self.pl.host_call(lambda k=k: self._issue_reduce(k))
+        self.launched += 1
+
+    def _issue_reduce(self, k: int) -> None:
+        """the bucket's gradient exchange on the communication stream (stream-synchronous: what is enqueued there behind it is ordered)"""
         g = self.engine.arena.g
         lo, hi = self.buckets[k]
         slo, shi = self.shard(k)
@@ -264,18 +318,22 @@ class ShardedDataParallelStep:
                 self._timed(k, lambda: dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group))
             else:
                 self._timed(k, lambda: dist.reduce_scatter_tensor(g[slo:shi], g[lo:hi], op=dist.ReduceOp.SUM, group=self.group))
-        self.launched += 1
 
     def _optimize_and_gather(self, k: int) -> None:
-        eng, A = self.engine, self.engine.arena
+        eng = self.engine
+        slo, shi = self.shard(k)
+        stream = self.comm_stream.cuda_stream if self.on_cuda else None
+        eng.apply_adam(slo, shi, grad_div=float(self.world), stream=stream)       # on the communication stream, behind the exchange
+        if self.replicated(k):                  # updated identically everywhere: nothing to gather
+            return
+        self.pl.host_call(lambda k=k: self._issue_gather(k))
+
+    def _issue_gather(self, k: int) -> None:
+        A = self.engine.arena
         lo, hi = self.buckets[k]
         slo, shi = self.shard(k)
+        w = A._shadow if A._shadow is not None else A._p
         with self._on_comm():
-            stream = self.comm_stream.cuda_stream if self.on_cuda else None
-            eng.apply_adam(slo, shi, grad_div=float(self.world), stream=stream)
-            if self.replicated(k):              # updated identically everywhere: nothing to gather
-                return
-            w = A.shadow if A.shadow is not None else A.p
             self._timed(k, lambda: dist.all_gather_into_tensor(w[lo:hi], w[slo:shi], group=self.group))
 
     def _grad_ready(self, layer: str) -> None:
@@ -310,25 +368,36 @@ class ShardedDataParallelStep:
         if not self.exchange:
             return eng.train_step(x, t_int, eps, apply=True)
         self._begin()
-        loss = eng.train_step(x, t_int, eps, apply=False)       # backward fires _grad_ready per layer
+        self._tail_done = False
+        loss = eng.train_step(x, t_int, eps, apply=False)       # backward fires _grad_ready per layer, then post_backward = _tail
+        if not (self._tail_done or getattr(eng, "post_backward_ran", False)):
+            self._tail()                                         # (an engine without the post_backward hook: the tests' CPU stand-in)
+        eng._masters_sharded = True
+        return loss
+
+    def _tail(self) -> None:
+        """what follows the reverse pass - part of the step body (UNetEngine.post_backward), so a step plan records it"""
+        eng = self.engine
+        self._tail_done = True
         assert self.next_rs == len(self.buckets)
         self._comm_waits_current()                               # every input-gradient launch has been enqueued by now
         if eng.ls_state is not None:
             # fp16 + dynamic loss scale (train.py:82-83): each rank checks the shards it owns; one 4-byte MAX all-reduce makes
             # the skip decision global before any update
-            with self._on_comm():
-                stream = self.comm_stream.cuda_stream if self.on_cuda else None
-                for k in range(len(self.buckets)):
-                    eng.check_finite(*self.shard(k), stream=stream)
-                dist.all_reduce(eng.ls_state[3:4], op=dist.ReduceOp.MAX, group=self.group)
+            stream = self.comm_stream.cuda_stream if self.on_cuda else None
+            for k in range(len(self.buckets)):
+                eng.check_finite(*self.shard(k), stream=stream)
+            self.pl.host_call(self._issue_found_inf)
         while self.next_opt < len(self.buckets):
             self._optimize_and_gather(self.next_opt)
             self.next_opt += 1
         if self.on_cuda:
-            torch.cuda.current_stream(eng.device).wait_stream(self.comm_stream)
-        eng._masters_sharded = True
+            self.pl.stream_waits(torch.cuda.current_stream(eng.device), self.comm_stream)
         eng.finish_step()
-        return loss
+
+    def _issue_found_inf(self) -> None:
+        with self._on_comm():
+            dist.all_reduce(self.engine.ls_state[3:4], op=dist.ReduceOp.MAX, group=self.group)
 
     def gather_master(self) -> None:
         """assemble the full fp32 parameter and Adam-slot arenas on every rank from the per-rank shards (a collective: every rank

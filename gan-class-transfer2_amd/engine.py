@@ -311,6 +311,14 @@ class UNetEngine:
             self.enable_loss_scaling()
         # called with the layer name as soon as that layer's gradient kernels are enqueued (DP all-reduce)
         self.grad_ready_hook: Optional[Callable[[str], None]] = None
+        # plan-aware hooks (the data-parallel wrappers): the hook does its stream plumbing through _wait_stream / apply_adam(stream=...)
+        # and issues its collectives through host_call(), so it can be RECORDED with the step - a replay then runs only the collectives
+        # from the interpreter.  A plain hook (False) is called between two plan segments at every step instead.
+        self.hook_plan_aware = False
+        # called once per train_step(apply=False) right after the reverse pass, inside the (recorded) step body: the wrappers' tail
+        # (remaining bucket updates, joining the communication stream, finish_step)
+        self.post_backward: Optional[Callable[[], None]] = None
+        self.post_backward_ran = False
         self._grads_in_arena = True    # False after a step whose fused optimizer consumed weight-gradient slabs in place
 
     # ------------------------------------------------------------------------------------------
@@ -679,14 +687,23 @@ class UNetEngine:
              A.gptr("U0.b"), b.img.data_ptr(), 4, 0, self._stream())
         return b.loss
 
+    def host_call(self, fn: Callable[[], None]) -> None:
+        """a Python callable that must run at THIS point of the step (a collective of the data-parallel exchange): run now - or, while a
+        step plan is being recorded, noted as the end of a plan segment; every replay calls it between that segment and the next"""
+        P = _lib._recording
+        if P is not None:
+            P.cut(("__call__", fn))
+        else:
+            fn()
+
     def _ready(self, layer: str, stream: Optional["torch.cuda.Stream"] = None) -> None:
         """gradient-ready hook of `layer` (data-parallel wrappers), called with `stream` - the stream whose kernels produced the
-        gradients - current.  While a step plan is being recorded the hook is NOT called: the plan is cut here and the replay calls
-        it between two segments."""
+        gradients - current.  While a step plan is being recorded a plain hook is NOT called: the plan is cut here and the replay calls
+        it between two segments; a plan-aware hook (hook_plan_aware) runs now and is recorded like the rest of the step."""
         if self.grad_ready_hook is None:
             return
         P = _lib._recording
-        if P is not None:
+        if P is not None and not self.hook_plan_aware:
             P.cut((layer, stream))
         elif stream is None:
             self.grad_ready_hook(layer)
@@ -896,6 +913,7 @@ class UNetEngine:
         B, H, W, _ = x.shape
         b = self.buffers(B, H, W)
         inline = apply and self.fuse_adam and self.ls_state is None
+        self.post_backward_ran = self.post_backward is not None and not apply
         cur = torch.cuda.current_stream(self.device)
         if self._flush_event is not None:                      # a flush on another stream (predict / state_dict there): the step waits once
             cur.wait_event(self._flush_event)
@@ -943,6 +961,8 @@ class UNetEngine:
             _lib._recording.cut(("__alpha__", None))
         self.backward(b, head_done=fused, adam_inline=inline)
         self._grads_in_arena = not inline
+        if self.post_backward is not None and not apply:
+            self.post_backward()
         if apply:
             if not inline:
                 self.check_finite()
@@ -955,7 +975,7 @@ class UNetEngine:
         """everything the call list of a step depends on besides the per-step slots"""
         return (id(b), apply, inline, cur.cuda_stream, self.ctx.version, self.ctx_tail.version,
                 tuple(sorted((k, c.version) for k, c in self._defer_ctxs.items())), tuple(l for _, l, _ in self._pending),
-                self.grad_ready_hook is not None, self.overlap, self.chain_priority, self.fuse_adam, self.defer_adam, tuple(self.defer_layers),
+                id(self.grad_ready_hook), self.hook_plan_aware, id(self.post_backward), self.overlap, self.chain_priority, self.fuse_adam, self.defer_adam, tuple(self.defer_layers),
                 self.defer_window_at, self.tail_on_chain, self.use_fused_head, self.fuse_u0_head, self.keep_pred, self.relu_bits,
                 self.ls_state is not None, self.workspace is not None, self.wgrad_workspace is not None, self.steps, self.rng_seed)
 
@@ -1008,7 +1028,9 @@ class UNetEngine:
             if payload is None:
                 continue
             layer, stream = payload
-            if layer == "__alpha__":                            # between the forward and the reverse pass (see _step_body): until here the
+            if layer == "__call__":                             # a collective of a recorded data-parallel hook (host_call)
+                stream()
+            elif layer == "__alpha__":                          # between the forward and the reverse pass (see _step_body): until here the
                 for l, fields in sp.adam_inputs.items():        # structs of the deferred layers belonged to the PREVIOUS step's launches
                     a = self._adam_args[l]
                     for f, v in fields.items():

@@ -245,6 +245,47 @@ def test_data_parallel_exchange_streams_single_rank(gpu):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("scheme", ["allreduce", "sharded", "sharded_loss_scaled"])
+def test_data_parallel_step_recorded_in_a_plan_equals_the_eager_one(gpu, scheme):
+    """the data-parallel wrappers' hooks are recorded WITH the step (stream waits and per-bucket Adam as plan records, every collective
+    the end of a plan segment that the replay issues from the interpreter): six steps from the device RNG on a 1-rank RCCL group with
+    the exchange forced, step plans on against off - parameters, Adam slots, the operand copies and the counters must be EQUAL."""
+    import socket
+    import torch.distributed as dist
+    from gan_class_transfer2_amd.distributed import DataParallelStep, ShardedDataParallelStep
+    cfg = O.OracleConfig(size=32, pixel_size=128, max_size=256, octaves=3, batch_size=4)     # (reference width: the matrix-core head - no kernel of the step adds with atomics)
+    params = O.init_params(cfg, seed=5)
+    xs = [torch.tensor(O.synthetic_batch(cfg, seed=k)[0], dtype=torch.float32, device=gpu) for k in range(3)]
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=gpu)
+    try:
+        outs = []
+        for use_plan in (False, True):
+            ls = scheme == "sharded_loss_scaled"
+            eng = make_engine(cfg, 2 if ls else 1, gpu, rng_seed=3, loss_scaling=ls)
+            eng.use_plan = use_plan
+            eng.set_params(params)
+            dp = (DataParallelStep if scheme == "allreduce" else ShardedDataParallelStep)(eng, bucket_elems=100_000, force_exchange=True)
+            losses = [dp.train_step(xs[k % 3]).clone() for k in range(6)]
+            torch.cuda.synchronize()
+            assert bool(eng._plans) == use_plan
+            if use_plan:                                          # hooks and tail are inside the plan: one segment per collective (+ the alpha cut)
+                sp = next(iter(eng._plans.values()))
+                ncoll = sum(1 for _, pay in sp.plan.cuts if pay is not None and pay[0] == "__call__")
+                assert ncoll >= len(dp.reducer.buckets if scheme == "allreduce" else dp.buckets)
+            if scheme != "allreduce":
+                dp.gather_master()
+            outs.append((torch.cat(losses), {n: getattr(eng.arena, n).clone() for n in ("p", "m", "v", "shadow")},
+                         (eng.iterations, eng.rng_offset_t, eng.rng_offset_eps)))
+        assert torch.equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
+        for n in ("p", "m", "v", "shadow"):
+            assert torch.equal(outs[0][1][n], outs[1][1][n]), n
+    finally:
+        dist.destroy_process_group()
+
+
 def test_fp16_loss_scaling_step(gpu):
     """mixed_precision=True path (train.py:34,43-45,82-83): fp16 operands, dynamic loss scale, finite grads applied; a skipped
     step halves the scale and advances NEITHER the parameters NOR optimizer.iterations (so the WarmUp step and Adam's bias
@@ -359,9 +400,11 @@ def test_named_and_legacy_state_dicts_load_into_the_current_layout(gpu):
 
 
 def test_flush_on_another_stream_orders_the_next_step(gpu):
-    """predict() / state_dict() between two fused steps may run on ANOTHER stream; the flush they trigger launches the
-    held-back Adam of UpShuffle_0..2 there, and the next train step on the training stream must wait for it.  Bits against an engine
-    that never defers."""
+    """whatever reads parameters between two fused steps (state_dict, predict, arena.p) may run on ANOTHER stream; the flush
+    it triggers launches the held-back Adam of UpShuffle_0..2 there - it writes their weights and reads their slabs - and the next train
+    step on the training stream must wait for it WITHOUT the caller's help.  (a) a bare flush on a second stream, no synchronisation by
+    the caller: the following steps must give the bits of an engine that never defers; (b) predict on the second stream (here the
+    caller does what any two-stream user must: the training stream waits for the evaluation stream before it goes on) - equal too."""
     cfg = O.OracleConfig(size=64, pixel_size=128, max_size=512, octaves=4, batch_size=4)
     params = O.init_params(cfg, seed=3)
     x = torch.tensor(O.synthetic_batch(cfg, seed=0)[0], dtype=torch.float32, device=gpu)
@@ -371,12 +414,18 @@ def test_flush_on_another_stream_orders_the_next_step(gpu):
     preds = []
     for e in engs:
         e.set_params(params)
-        for k in range(3):
+        for k in range(5):
             e.train_step(x)
-            if k == 1:
+            if k == 1:                                            # (a)
                 other.wait_stream(torch.cuda.current_stream(gpu))
                 with torch.cuda.stream(other):
-                    preds.append(e.predict(x[:1]).clone())          # flushes on `other` in the deferring engine
+                    e.flush_deferred()
+                assert (e._flush_event is not None) == e.defer_adam
+            if k == 3:                                            # (b)
+                other.wait_stream(torch.cuda.current_stream(gpu))
+                with torch.cuda.stream(other):
+                    preds.append(e.predict(x[:1]).clone())
+                torch.cuda.current_stream(gpu).wait_stream(other)
         torch.cuda.synchronize()
     assert torch.equal(preds[0], preds[1])
     for name in ("p", "m", "v", "shadow"):
