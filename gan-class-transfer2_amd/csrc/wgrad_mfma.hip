@@ -218,8 +218,20 @@ __device__ __forceinline__ void dma16_hidden(__amdgpu_buffer_rsrc_t rsrc, char* 
 //            place for every lane: the position counters, the stage's byte offsets and its border bits are scalar, a lane adds a
 //            constant offset and tests constant flags - 8 vector instructions per stage instead of ~45.
 // Same sources, same zero fill, same multiplies in the same order: bit-identical to the r03 order (which other shapes keep).
-template <typename T, bool TURNS, bool ALIGNED>
+//
+// r05, PIPE: the fragments of stage s+1 are read UNDER the multiplies of stage s (behind every row of four multiplies the reads that
+// refill that row's big-operand registers and one small-operand fragment), so a wave's turn is "multiply" / "issue DMA" without a read
+// phase in front.  What it takes: stage s+1 must have landed, and every wave must know it, one barrier EARLIER than before (two stages
+// stay in flight across a barrier instead of three; the ring keeps five buffers: s+1 is read, s+2 landed, s+3 / s+4 in flight, the
+// buffer of s-1 is the DMA target); 16 more registers (the next stage's four small-operand fragments; a big-operand fragment's
+// registers are free again as soon as its row is issued: 234 registers, no spill).  Same multiplies in the same order: bit-identical
+// to the other orders.  Measured (profiles/r05_step_ab.txt): launch by launch within +-2 % of the r04 order (as were three more
+// placements of the reads and the DMA pieces: one read behind every multiply, every wave issuing in front, one piece behind every
+// second row) - a wave's multiplies take 820 cycles with the reads between them instead of 577 - but 17-30 us per STEP faster in
+// interleaved in-process rounds on two boxes, which is why it is the default (tuning 16-23 = 5 keeps the r04 order).
+template <typename T, bool TURNS, bool ALIGNED, bool PIPE = false>
 __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
+  static_assert(!PIPE || (TURNS && ALIGNED), "the pipelined order exists for the aligned, turn-taking stage only");
   constexpr int NST = 5;
   constexpr int IMG = 32 * 256;                                   // one T image of a stage: 32 r-rows x 128 columns
   constexpr int STAGE = 4 * IMG;
@@ -398,13 +410,6 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
     else wait_tail(st_hi - 1 - (st + 1));
     __builtin_amdgcn_s_barrier();
   };
-  GCT2_CLOCK_BEGIN;
-  issue_x(lds);
-  if (st_lo + 1 < st_hi) issue_x(lds + STAGE);
-  if (st_lo + 2 < st_hi) issue_x(lds + 2 * STAGE);
-  if (st_lo + 3 < st_hi) issue_x(lds + 3 * STAGE);
-  wait_tail(min(st_lo + 3, st_hi - 1) - st_lo);
-  __builtin_amdgcn_s_barrier();
   // steady state: every stage of the trip still has a stage to issue (st + 4 + 4 < st_hi): no tail logic, one constant wait
 #if defined(GCT2_STAMP) && defined(GCT2_PHASES)
   // cycles per steady-state stage by phase (every stamp waits for its own value - the compiler may copy an asm output at once; in
@@ -423,6 +428,93 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
 #else
 #define GCT2_PH(x)
 #endif
+  GCT2_CLOCK_BEGIN;
+  issue_x(lds);
+  if (st_lo + 1 < st_hi) issue_x(lds + STAGE);
+  if (st_lo + 2 < st_hi) issue_x(lds + 2 * STAGE);
+  if (st_lo + 3 < st_hi) issue_x(lds + 3 * STAGE);
+  if constexpr (PIPE) {
+    // stages st_lo and st_lo + 1 landed (stages come in pairs: a split has at least two), the next two may stay in flight
+    if (st_lo + 3 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
+    else if (st_lo + 2 < st_hi) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
+    else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
+    __builtin_amdgcn_s_barrier();
+    u32x4_t sf[4], bf[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sf[j] = frag(lds, sf_off[j]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) bf[i] = frag(lds, bf_off[i]);
+    const bool front = wm != 0;
+    // multiply the stage in registers; behind row i's four multiplies read row i of the next stage (and one small-operand fragment)
+    auto rows = [&](const char* nxt, bool has_next) {
+      u32x4_t sn[4];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16<T>(sf[j], bf[i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);                         // the reads stay behind the row whose registers they reuse
+        if (has_next) {
+          bf[i] = frag(nxt, bf_off[i]);
+          if (i < 4) sn[i] = frag(nxt, sf_off[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (has_next) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) sf[j] = sn[j];
+      }
+    };
+    auto pstage_fast = [&](const char* nxt, char* tgt) {          // steady state: stages s+1 .. s+4 exist
+      GCT2_PH(const unsigned long long t0 = now();)
+      if (front) issue_aligned(tgt);
+      GCT2_PH(const unsigned long long t1 = now();)
+      __builtin_amdgcn_sched_barrier(0);
+      if (live) rows(nxt, true);
+      __builtin_amdgcn_sched_barrier(0);
+      GCT2_PH(const unsigned long long t3 = now();)               // (waits for the next stage's fragment reads as well)
+      if (!front) issue_aligned(tgt);
+      GCT2_PH(const unsigned long long t4 = now();)
+      __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));      // s+2 landed; s+3, s+4 stay in flight
+      GCT2_PH(const unsigned long long t5 = now();)
+      __builtin_amdgcn_s_barrier();
+      GCT2_PH(const unsigned long long t6 = now();
+              ph[0] += t1 - t0; ph[2] += t3 - t1; ph[3] += t4 - t3; ph[4] += t5 - t4; ph[5] += t6 - t5; nstages++;)
+    };
+    auto pstage = [&](int s, const char* nxt, char* tgt) {
+      const bool more = s + NST - 1 < st_hi, has_next = s + 1 < st_hi;   // block-uniform
+      if (more && front) issue_aligned(tgt);
+      __builtin_amdgcn_sched_barrier(0);
+      if (live) rows(nxt, has_next);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more && !front) issue_aligned(tgt);
+      const int ahead = st_hi - 1 - (s + 2);                       // stages behind s+2 that this wave has issued
+      if (ahead >= 2) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(2 * NDMA));
+      else if (ahead == 1) __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(NDMA));
+      else __builtin_amdgcn_s_waitcnt(GCT2_VMCNT_ONLY(0));
+      __builtin_amdgcn_s_barrier();
+    };
+    int s = st_lo;
+    for (; s + 8 < st_hi; s += 5) {
+      pstage_fast(lds + STAGE, lds + 4 * STAGE);
+      pstage_fast(lds + 2 * STAGE, lds);
+      pstage_fast(lds + 3 * STAGE, lds + STAGE);
+      pstage_fast(lds + 4 * STAGE, lds + 2 * STAGE);
+      pstage_fast(lds, lds + 3 * STAGE);
+    }
+    for (; s < st_hi; s += 5) {
+      pstage(s, lds + STAGE, lds + 4 * STAGE);
+      if (s + 1 >= st_hi) break;
+      pstage(s + 1, lds + 2 * STAGE, lds);
+      if (s + 2 >= st_hi) break;
+      pstage(s + 2, lds + 3 * STAGE, lds + STAGE);
+      if (s + 3 >= st_hi) break;
+      pstage(s + 3, lds + 4 * STAGE, lds + 2 * STAGE);
+      if (s + 4 >= st_hi) break;
+      pstage(s + 4, lds, lds + 3 * STAGE);
+    }
+  } else {
+  wait_tail(min(st_lo + 3, st_hi - 1) - st_lo);
+  __builtin_amdgcn_s_barrier();
   auto stage_fast = [&](const char* cur, char* tgt) {
     const bool front = TURNS ? wm != 0 : true;                     // issue block in front of the multiplies (else behind them)
     GCT2_PH(const unsigned long long t0 = now(); unsigned long long t2 = 0;)
@@ -475,6 +567,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256q_kernel(WgradParams p) {
     stage(st + 3, lds + 3 * STAGE, lds + 2 * STAGE);
     if (st + 4 >= st_hi) break;
     stage(st + 4, lds + 4 * STAGE, lds + 3 * STAGE);
+  }
   }
 #ifdef GCT2_STAMP
   GCT2_CLOCK_END(p.clock ? p.stamps : nullptr, 8, wave, lane);
@@ -595,7 +688,7 @@ int wgrad_mfma(gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs*
   const int tiles256 = ((taps * p.Cb + 255) / 256) * ((p.Cs + 255) / 256);
   const int minsteps = tiles128 < 256 ? 4 : 8;
   const int blocks256 = tiles256 * std::max(1, std::min((256 + tiles256 - 1) / tiles256, steps_total / minsteps));
-  const bool big_tile = !p.ks && (variant == 2 || variant == 4 || (variant == 0 && tiles128 < 512 && blocks256 >= 192));
+  const bool big_tile = !p.ks && (variant == 2 || variant == 4 || variant == 5 || (variant == 0 && tiles128 < 512 && blocks256 >= 192));
   const int tiles = big_tile ? tiles256 : tiles128;
   // pixel splits: ~256 work-groups for the big tile; ~768 (3 per CU) for the small one, one owner per tile once the tiles alone
   // give every CU two work-groups, two splits in between; always >= 4 steps of 64 rows per split
@@ -622,18 +715,21 @@ int wgrad_mfma(gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs*
   if (!p.ws && rsplit > 1 && !p.accumulate) {     // atomics add into the target: start it from zero
     (void)hipMemsetAsync(p.dw, 0, n * sizeof(float), s);
   }
-  gct2_log(c, "wgrad:%s:rsplit=%d:%s", p.ks ? "s1" : (big_tile ? (variant == 4 ? "256q-r03" : "256q") : "128"), rsplit, p.ws ? "slabs" : (rsplit == 1 ? "owner" : "atomics"));
+  gct2_log(c, "wgrad:%s:rsplit=%d:%s", p.ks ? "s1" : (big_tile ? (variant == 4 ? "256q-r03" : (variant == 5 ? "256q-r04" : "256q")) : "128"), rsplit, p.ws ? "slabs" : (rsplit == 1 ? "owner" : "atomics"));
   if (p.ks) {
     if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad_kernel<__bf16, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<_Float16, true>), grid, dim3(256), 0, s, p);
   } else if (big_tile) {
     // stage-aligned geometry -> scalar address code and waves taking turns (see the kernel); other shapes keep the r03 stage order
     const bool aligned = (p.Ws % 32 == 0 || (32 % p.Ws == 0 && p.Hs % (32 / p.Ws) == 0)) && variant != 4;
+    const bool pipe = aligned && variant != 5;       // r05: the next stage's fragments read under the multiplies (5 = the r04 order)
     if (dtype == GCT2_BF16) {
-      if (aligned) hipLaunchKernelGGL((wgrad256q_kernel<__bf16, true, true>), grid, dim3(512), 0, s, p);
+      if (pipe) hipLaunchKernelGGL((wgrad256q_kernel<__bf16, true, true, true>), grid, dim3(512), 0, s, p);
+      else if (aligned) hipLaunchKernelGGL((wgrad256q_kernel<__bf16, true, true>), grid, dim3(512), 0, s, p);
       else hipLaunchKernelGGL((wgrad256q_kernel<__bf16, false, false>), grid, dim3(512), 0, s, p);
     } else {
-      if (aligned) hipLaunchKernelGGL((wgrad256q_kernel<_Float16, true, true>), grid, dim3(512), 0, s, p);
+      if (pipe) hipLaunchKernelGGL((wgrad256q_kernel<_Float16, true, true, true>), grid, dim3(512), 0, s, p);
+      else if (aligned) hipLaunchKernelGGL((wgrad256q_kernel<_Float16, true, true>), grid, dim3(512), 0, s, p);
       else hipLaunchKernelGGL((wgrad256q_kernel<_Float16, false, false>), grid, dim3(512), 0, s, p);
     }
   } else {

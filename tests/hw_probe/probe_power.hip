@@ -122,6 +122,118 @@ __global__ __launch_bounds__(512, 2) void loop_a(float* out, Stamp* st, int iter
   out[blockIdx.x * 512 + tid] = s;
 }
 
+
+// ---- the same questions for v_mfma_f32_32x32x16_bf16 (half the matrix instructions per FLOP, 24 instead of 8 free issue cycles per
+// instruction): R32 registers only; A32 / P32 the 256 x 256 x 32 stage with 8 waves of 128 x 64 (WAVES = 8) or 4 waves of 128 x 128
+// (WAVES = 4, one wave per SIMD, 256 accumulator registers).  Fragment of 32 columns x 16 rows: lane l reads rows
+// 16 kk + 8 (l >> 5) + ((l >> 2) & 3) (+ 4), 32-byte chunk 2 f + ((l >> 4) & 1), stored at chunk ^ 2 (row & 3): conflict-free for both
+// 32-lane halves of ds_read_b64_tr_b16 (4 rows x 2 chunks -> 8 distinct 32-byte bank groups).
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+__device__ __forceinline__ f32x16_t mfma32(u32x4_t a, u32x4_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4_t frag32(const char* img, int f, int kk, int lane) {
+  const int k0 = 16 * kk + 8 * (lane >> 5) + ((lane >> 2) & 3);
+  const int chunk = 2 * f + ((lane >> 4) & 1);
+  const int o0 = k0 * 256 + ((chunk ^ (2 * (k0 & 3))) << 5) + (lane & 3) * 8;       // row k0 + 4 has the same swizzle
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + o0));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + o0 + 4 * 256));
+  const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+  return u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+}
+
+__global__ __launch_bounds__(512, 2) void loop_r32(float* out, Stamp* st, int iters, int zero) {
+  const int tid = threadIdx.x;
+  u32x4_t sf[2], bf[4];
+  for (int j = 0; j < 2; j++) for (int e = 0; e < 4; e++)
+    sf[j][e] = rnd_bf16(tid * 64 + j * 8 + e * 2, 7, zero) | ((unsigned)rnd_bf16(tid * 64 + j * 8 + e * 2 + 1, 7, zero) << 16);
+  for (int i = 0; i < 4; i++) for (int e = 0; e < 4; e++)
+    bf[i][e] = rnd_bf16(tid * 64 + i * 8 + e * 2, 9, zero) | ((unsigned)rnd_bf16(tid * 64 + i * 8 + e * 2 + 1, 9, zero) << 16);
+  f32x16_t acc[4][2];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  STAMP_BEGIN;
+  for (int it = 0; it < 8 * iters; it++) {            // 8 MFMAs of 32 cycles per trip = half a stage
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      asm volatile("" : "+v"(bf[i]));
+#pragma unroll
+      for (int j = 0; j < 2; j++) acc[i][j] = mfma32(sf[j], bf[i], acc[i][j]);
+    }
+  }
+  STAMP_END(st);
+  float s = 0.f;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) s += acc[i][j][e];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int MODE, int WAVES>      // MODE 0: reads, multiplies, barrier per stage   2: next k-step's fragments read under this one's multiplies
+__global__ __launch_bounds__(WAVES * 64, 2) void loop_a32(float* out, Stamp* st, int iters, int zero) {
+  constexpr int NJ = WAVES == 8 ? 2 : 4;              // 32-column fragments of the small operand per wave
+  constexpr int NT = WAVES * 64;
+  __shared__ __attribute__((aligned(16))) char l0[4 * IMG], l1[4 * IMG], l2[4 * IMG], l3[4 * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = WAVES == 8 ? wave >> 2 : wave >> 1;
+  const int simg = WAVES == 8 ? 2 + ((wave & 3) >> 1) : 2 + (wave & 1);
+  const int sf0 = WAVES == 8 ? 2 * (wave & 1) : 0;    // first fragment of the small image
+  fill(l0, 4 * IMG, tid, NT, 1, zero); fill(l1, 4 * IMG, tid, NT, 2, zero); fill(l2, 4 * IMG, tid, NT, 3, zero); fill(l3, 4 * IMG, tid, NT, 4, zero);
+  __syncthreads();
+  f32x16_t acc[4][NJ];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < NJ; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  int ql = lane;
+  asm volatile("" : "+v"(ql));
+  auto load = [&](u32x4_t* f, const char* base, int kk) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) f[j] = frag32(base + simg * IMG, sf0 + j, kk, ql);
+#pragma unroll
+    for (int i = 0; i < 4; i++) f[NJ + i] = frag32(base + wm * IMG, i, kk, ql);
+  };
+  auto mul = [&](const u32x4_t* f) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[i][j] = mfma32(f[j], f[NJ + i], acc[i][j]);
+  };
+  auto mul_load = [&](const u32x4_t* f, u32x4_t* nf, const char* nbase, int nkk) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (i < NJ) nf[i] = frag32(nbase + simg * IMG, sf0 + i, nkk, ql);
+      nf[NJ + i] = frag32(nbase + wm * IMG, i, nkk, ql);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[i][j] = mfma32(f[j], f[NJ + i], acc[i][j]);
+    }
+  };
+  const bool live = iters > 0;
+  u32x4_t fa[NJ + 4], fb[NJ + 4];
+  STAMP_BEGIN;
+  if (MODE == 2) {
+    load(fa, l0, 0);
+    for (int it = 0; it < iters; it++) {
+      if (live) mul_load(fa, fb, l0, 1);
+      if (live) mul_load(fb, fa, l1, 0);
+      if (live) mul_load(fa, fb, l1, 1);
+      if (live) mul_load(fb, fa, l2, 0);
+      if (live) mul_load(fa, fb, l2, 1);
+      if (live) mul_load(fb, fa, l3, 0);
+      if (live) mul_load(fa, fb, l3, 1);
+      if (live) mul_load(fb, fa, l0, 0);
+    }
+  } else {
+    const char* ring[4] = {l0, l1, l2, l3};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        if (live) { load(fa, ring[b], 0); load(fb, ring[b], 1); mul(fa); mul(fb); }
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+  STAMP_END(st);
+  float s = 0.f;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < NJ; j++) for (int e = 0; e < 16; e++) s += acc[i][j][e];
+  s += __builtin_bit_cast(float, fa[0][0]) * 1e-30f;
+  out[blockIdx.x * NT + tid] = s;
+}
+
 template <typename F>
 static void run(const char* name, F launch, Stamp* dst, int iters, int blocks) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -131,6 +243,7 @@ static void run(const char* name, F launch, Stamp* dst, int iters, int blocks) {
     hipEventRecord(e0); for (int k = 0; k < 20; k++) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1); total += ms;
   }
+  hipMemset(dst, 0, (size_t)blocks * 8 * sizeof(Stamp));      // kernels with 4 waves leave half the entries untouched
   hipEventRecord(e0); for (int k = 0; k < 20; k++) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
   hipEventElapsedTime(&ms, e0, e1); ms /= 20;
   std::vector<Stamp> h(blocks * 8);
@@ -159,6 +272,16 @@ int main() {
     run(nm, [&] { hipLaunchKernelGGL(loop_a<1>, dim3(blocks), dim3(512), 0, 0, d, st, iters, zero); }, st, iters, blocks);
     snprintf(nm, sizeof nm, "P next stage's reads under the MFMAs, %s", z);
     run(nm, [&] { hipLaunchKernelGGL(loop_a<2>, dim3(blocks), dim3(512), 0, 0, d, st, iters, zero); }, st, iters, blocks);
+    snprintf(nm, sizeof nm, "R32 registers only, 32x32x16, %s", z);
+    run(nm, [&] { hipLaunchKernelGGL(loop_r32, dim3(blocks), dim3(512), 0, 0, d, st, iters, zero); }, st, iters, blocks);
+    snprintf(nm, sizeof nm, "A32 8 waves, reads + barrier, %s", z);
+    run(nm, [&] { hipLaunchKernelGGL((loop_a32<0, 8>), dim3(blocks), dim3(512), 0, 0, d, st, iters, zero); }, st, iters, blocks);
+    snprintf(nm, sizeof nm, "P32 8 waves, reads under MFMAs, %s", z);
+    run(nm, [&] { hipLaunchKernelGGL((loop_a32<2, 8>), dim3(blocks), dim3(512), 0, 0, d, st, iters, zero); }, st, iters, blocks);
+    snprintf(nm, sizeof nm, "A32 4 waves 128x128, reads + barrier, %s", z);
+    run(nm, [&] { hipLaunchKernelGGL((loop_a32<0, 4>), dim3(blocks), dim3(256), 0, 0, d, st, iters, zero); }, st, iters, blocks);
+    snprintf(nm, sizeof nm, "P32 4 waves 128x128, reads under MFMAs, %s", z);
+    run(nm, [&] { hipLaunchKernelGGL((loop_a32<2, 4>), dim3(blocks), dim3(256), 0, 0, d, st, iters, zero); }, st, iters, blocks);
   }
   if (hipGetLastError() != hipSuccess) { printf("HIP error\n"); return 1; }
   return 0;

@@ -254,11 +254,12 @@ def test_wgrad_tile_variants(gpu, variant, shape, use_ws):
 
 @pytest.mark.parametrize("shape", [(2, 64, 64, 64, 256), (3, 32, 32, 72, 136), (5, 16, 16, 128, 64), (2, 128, 64, 64, 64), (3, 40, 24, 64, 128)])
 def test_wgrad_turns_and_scalar_addresses_equal_r03_order_bit_for_bit(gpu, shape):
-    """r04 stage order of the 256x256 weight-gradient tile (the two waves of a SIMD take turns between DMA issue and multiplies; stage
-    position, offsets and border bits in SGPRs where a 32-row stage is aligned with the image rows) against the r03 order (tuning
-    16-23 = 4): same sources, same zero fill, same multiplies in the same order, hence the same bits - grids of 64 / 32 / 16 / 8
-    columns (stage = part of a row, one row, 2 and 4 rows), ragged channel counts, several images per split, and one shape that is
-    not aligned (both tunings then run the r03 order)."""
+    """The stage orders of the 256x256 weight-gradient tile: r05 (default: the next stage's fragments read under the multiplies, one
+    barrier earlier in the ring), r04 (tuning 16-23 = 5: the two waves of a SIMD take turns between DMA issue and multiplies; stage
+    position, offsets and border bits in SGPRs where a 32-row stage is aligned with the image rows) and r03 (4): same sources, same
+    zero fill, same multiplies in the same order, hence the same bits - grids of 64 / 32 / 16 / 8 columns (stage = part of a row,
+    one row, 2 and 4 rows), ragged channel counts, several images per split, and one shape that is not aligned (all three tunings
+    then run the r03 order)."""
     B, H, W, Cin, Cout = shape
     dt, L = BF16, lib()
     rng = np.random.default_rng(71)
@@ -270,7 +271,7 @@ def test_wgrad_turns_and_scalar_addresses_equal_r03_order_bit_for_bit(gpu, shape
     set_ws(ws)
     res = {}
     try:
-        for variant in (2, 4):
+        for variant in (2, 5, 4):
             set_tuning(variant << 16)
             dw = torch.full((4, 4, Cin, Cout), float("nan"), dtype=torch.float32, device=gpu)
             dwt = torch.full((4, 4, Cout, Cin), float("nan"), dtype=torch.float32, device=gpu)
@@ -279,6 +280,7 @@ def test_wgrad_turns_and_scalar_addresses_equal_r03_order_bit_for_bit(gpu, shape
             torch.cuda.synchronize()
             res[variant] = (dw, dwt)
         assert torch.equal(res[2][0], res[4][0]) and torch.equal(res[2][1], res[4][1])
+        assert torch.equal(res[5][0], res[4][0]) and torch.equal(res[5][1], res[4][1])
         assert rel_l2(res[2][0].cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
         assert rel_l2(res[2][1].cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
     finally:
