@@ -195,36 +195,34 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(WgradParams p) {
   const int ac = tid & 7, arow0 = tid >> 3;          // A: 64 rows x 8 chunks -> 2 per thread
   const int sc = tid & 15, srow0 = tid >> 4;         // dz: 64 rows x 16 chunks -> 4 per thread
   const bool s_ok = (n0 + sc * 8) < N;
-  u32x4_t a_reg[2], s_reg[4];
-  auto gload = [&](int step) {
+  // Two register sets: the loads of step s+2 are issued before step s is multiplied and written to LDS one step later, so that
+  // TWO steps of dz (2 x 16 KiB per work-group, 64 KiB per CU) are in flight towards HBM instead of one - this launch only streams dz
+  // (67 MB at config 3) and one step in flight kept it at 2.3 TB/s (r05).
+  u32x4_t a_reg[2][2], s_reg[2][4];
+  auto gload = [&](int step, int set) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int r = step * 64 + arow0 + 32 * i;
       const int sw = r % Ws, t = r / Ws, sh = t % Hs, b = t / Hs;
-      a_reg[i] = gather_chunk<T>(x, p.ldbig, Cin, b * Hb * Wb, sh, sw, ac, Hb, Wb, r < R);
+      a_reg[set][i] = gather_chunk<T>(x, p.ldbig, Cin, b * Hb * Wb, sh, sw, ac, Hb, Wb, r < R);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = step * 64 + srow0 + 16 * i;
-      s_reg[i] = u32x4_t{0u, 0u, 0u, 0u};
-      if (s_ok && r < R) s_reg[i] = gload128(dz + (size_t)r * p.ldsmall + n0 + sc * 8);
+      s_reg[set][i] = u32x4_t{0u, 0u, 0u, 0u};
+      if (s_ok && r < R) s_reg[set][i] = gload128(dz + (size_t)r * p.ldsmall + n0 + sc * 8);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, int set) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) lds_write128(a_img[buf], timg_off(arow0 + 32 * i, ac), a_reg[i]);
+    for (int i = 0; i < 2; i++) lds_write128(a_img[buf], timg_off(arow0 + 32 * i, ac), a_reg[set][i]);
 #pragma unroll
-    for (int i = 0; i < 4; i++) lds_write128(s_img[buf], timg_off(srow0 + 16 * i, sc), s_reg[i]);
+    for (int i = 0; i < 4; i++) lds_write128(s_img[buf], timg_off(srow0 + 16 * i, sc), s_reg[set][i]);
   };
   f32x4_t acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; i++) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
-  gload(step_lo);
-  sstore(0);
-  __syncthreads();
-  for (int step = step_lo; step < step_hi; step++) {
-    const int buf = (step - step_lo) & 1;
-    if (step + 1 < step_hi) gload(step + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
       u32x4_t af[4], sf[2];
@@ -237,7 +235,21 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = mfma16<T>(af[i], sf[j], acc[i][j]);
     }
-    if (step + 1 < step_hi) sstore(buf ^ 1);
+  };
+  gload(step_lo, 0);
+  sstore(0, 0);
+  if (step_lo + 1 < step_hi) gload(step_lo + 1, 1);
+  __syncthreads();
+  // step s is in LDS buffer (s - step_lo) & 1, step s+1 in register set (s + 1 - step_lo) & 1; two steps per trip: static register names
+  for (int step = step_lo; step < step_hi; step += 2) {
+    if (step + 2 < step_hi) gload(step + 2, 0);
+    compute(0);
+    if (step + 1 < step_hi) sstore(1, 1);
+    __syncthreads();
+    if (step + 1 >= step_hi) break;
+    if (step + 3 < step_hi) gload(step + 3, 1);
+    compute(1);
+    if (step + 2 < step_hi) sstore(0, 0);
     __syncthreads();
   }
   // lane holds dW'[k' = 16 i + 4 (lane>>4) + r][n = n0 + 32 wave + 16 j + (lane&15)]; channel slot = r.

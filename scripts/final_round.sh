@@ -7,8 +7,10 @@ python scripts/stamp_clock.py --seconds 2.0 --layers U0.wgrad,U1.wgrad,U2.wgrad,
 python scripts/engine_layers.py > gpurun_out/layers.txt 2>&1
 python scripts/engine_layers.py --zeros > gpurun_out/layers_zero_data.txt 2>&1
 ( echo "# per-stage phases of wgrad256q_kernel's steady-state K loop (diagnostic build: make phases; cycles per 32-row stage, mean over the waves of a group)"
-  echo "## r04 order: waves take turns, reads up front, scalar stage position (tuning 0)"
+  echo "## r05 order: waves take turns, the next stage's fragments read under the multiplies (tuning 0; 'reads' is part of '32 MFMA' here)"
   python scripts/stamp_clock.py --phases --seconds 0.5 --layers U0.wgrad,U1.wgrad,U2.wgrad,D1.wgrad,D2.wgrad,D3.wgrad | grep -v amdgpu.ids
+  echo "## r04 order: waves take turns, reads up front, scalar stage position (tuning bits 16-23 = 5)"
+  python scripts/stamp_clock.py --phases --tuning 0x50000 --seconds 0.5 --layers U0.wgrad,U1.wgrad,U2.wgrad,D1.wgrad,D2.wgrad,D3.wgrad | grep -v "amdgpu.ids\|^#"
   echo "## r03 order (tuning bits 16-23 = 4)"
   python scripts/stamp_clock.py --phases --tuning 0x40000 --seconds 0.5 --layers U0.wgrad,U1.wgrad,U2.wgrad,D1.wgrad,D2.wgrad,D3.wgrad | grep -v "amdgpu.ids\|^#" ) > gpurun_out/wgrad_stage_phases.txt 2>&1 || true
 tests/hw_probe/probe_power > gpurun_out/probe_power.txt 2>&1 || true
