@@ -252,7 +252,8 @@ def test_wgrad_tile_variants(gpu, variant, shape, use_ws):
         set_ws(None)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 256), (3, 32, 32, 72, 136), (5, 16, 16, 128, 64), (2, 128, 64, 64, 64), (3, 40, 24, 64, 128)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 256), (3, 32, 32, 72, 136), (5, 16, 16, 128, 64), (2, 128, 64, 64, 64), (3, 40, 24, 64, 128),
+                                   (21, 16, 16, 16, 64)])      # 21 steps of 64 rows over 5 pixel splits: the last split has ONE step = two stages
 def test_wgrad_turns_and_scalar_addresses_equal_r03_order_bit_for_bit(gpu, shape):
     """The stage orders of the 256x256 weight-gradient tile: r05 (default: the next stage's fragments read under the multiplies, one
     barrier earlier in the ring), r04 (tuning 16-23 = 5: the two waves of a SIMD take turns between DMA issue and multiplies; stage
