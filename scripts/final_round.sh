@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 tail -c 600 gpurun_out/bench_default.json
 bash scripts/profile_round.sh > gpurun_out/profile_round.log 2>&1 || true
-python scripts/stamp_clock.py --seconds 2.0 --layers U0.wgrad,U1.wgrad,U2.wgrad,D1.wgrad,D2.wgrad,D3.wgrad,U0.fwd,U1.fwd,U2.fwd,D1.dgrad,D2.dgrad,U0.dgrad,U1.dgrad,U2.dgrad,D1.fwd,D2.fwd > gpurun_out/kernel_clock.txt 2>&1
+python scripts/stamp_clock.py --seconds 1.0 --layers D3.fwd,D4.fwd,D5.fwd,U5.fwd,U4.fwd,U3.fwd,U3.dgrad,U4.dgrad,U5.dgrad,D5.dgrad,D4.dgrad,D3.dgrad,U3.wgrad,U4.wgrad,U5.wgrad,D5.wgrad,D4.wgrad,D3.wgrad,U0.wgrad,U1.wgrad,U2.wgrad,D1.wgrad,D2.wgrad,U0.fwd,U1.fwd,U2.fwd,D1.dgrad,D2.dgrad,U0.dgrad,U1.dgrad,U2.dgrad,D1.fwd,D2.fwd > gpurun_out/kernel_clock.txt 2>&1
 python scripts/engine_layers.py > gpurun_out/layers.txt 2>&1
 python scripts/engine_layers.py --zeros > gpurun_out/layers_zero_data.txt 2>&1
 ( echo "# per-stage phases of wgrad256q_kernel's steady-state K loop (diagnostic build: make phases; cycles per 32-row stage, mean over the waves of a group)"
