@@ -11,7 +11,7 @@ import struct
 
 F32, BF16, F16 = 0, 1, 2
 DTYPE_NAMES = {F32: "f32", BF16: "bf16", F16: "f16"}
-ABI_VERSION = 15
+ABI_VERSION = 16
 # gct2_diffusion_update modes (include/gct2.h; the sampler's objective switches, train.py:29-32)
 SAMPLE_X, SAMPLE_EPS, SAMPLE_SCALED_EPS, SAMPLE_ODE = 0, 1, 2, 3
 BUILD_STAMP = 1
@@ -48,6 +48,8 @@ SIGNATURES = {
     "gct2_ctx_destroy": [_vp],
     "gct2_ctx_set_workspace": [_vp, _vp, _sz],
     "gct2_ctx_set_wgrad_workspace": [_vp, _vp, _sz],
+    "gct2_ctx_set_bias_queue": [_vp, _vp, _sz],
+    "gct2_bias_queue_flush": [_vp, _vp],
     "gct2_ctx_set_tuning": [_vp, _i],
     "gct2_ctx_force_direct": [_vp, _i],
     "gct2_ctx_set_stamp_buffer": [_vp, _vp, _sz],
@@ -344,6 +346,13 @@ class Context:
         self._keep[1] = tensor
         self.version += 1
         call("gct2_ctx_set_wgrad_workspace", self.handle, tensor.data_ptr() if tensor is not None else None,
+             tensor.numel() * tensor.element_size() if tensor is not None else 0)
+
+    def set_bias_queue(self, tensor) -> None:
+        """queue buffer for the deferred bias-gradient row sums of this context's input-gradient calls (None: immediate reductions)"""
+        self._keep.append(tensor)
+        self.version += 1
+        call("gct2_ctx_set_bias_queue", self.handle, tensor.data_ptr() if tensor is not None else None,
              tensor.numel() * tensor.element_size() if tensor is not None else 0)
 
     def set_tuning(self, v: int) -> None:

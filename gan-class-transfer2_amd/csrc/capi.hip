@@ -181,7 +181,7 @@ int adam_after_wgrad(gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& 
 
 extern "C" {
 
-int gct2_abi_version(void) { return 15; }
+int gct2_abi_version(void) { return 16; }
 int gct2_build_flags(void) {
 #ifdef GCT2_STAMP
   return GCT2_BUILD_STAMP;
@@ -213,6 +213,19 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes) {
   ctx->wws = ws ? reinterpret_cast<float*>(ws) : nullptr;
   ctx->wws_bytes = ws ? bytes : 0;
   return GCT2_OK;
+}
+int gct2_ctx_set_bias_queue(gct2_ctx* ctx, void* buf, size_t bytes) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_bias_queue: null ctx");
+  if (buf && ((uintptr_t)buf % 16)) return gct2_fail(GCT2_EINVAL, "ctx_set_bias_queue: pointer must be 16-byte aligned");
+  ctx->dbq_jobs.clear();                     // (row sets recorded and not flushed are dropped: flush before changing the buffer)
+  ctx->dbq_used = 0;
+  ctx->dbq = buf ? reinterpret_cast<float*>(buf) : nullptr;
+  ctx->dbq_floats = buf ? bytes / sizeof(float) : 0;
+  return GCT2_OK;
+}
+int gct2_bias_queue_flush(gct2_ctx* ctx, void* stream) {
+  if (!ctx) return gct2_fail(GCT2_EINVAL, "bias_queue_flush: null ctx");
+  return tapgemm_dbq_flush(*ctx, S(stream));
 }
 int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_tuning: null ctx");

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <vector>
 #include "../../include/gct2.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -37,6 +38,20 @@ struct gct2_ctx {
   unsigned char* relu_bits = nullptr; int relu_ldbits = 0; int relu_bits_done = 0;
   // launch log (gct2_ctx_log_launches): which kernel every layer call selected, as text tokens - for tests that must know
   bool log_on = false, log_full = false; std::string log;
+  // deferred bias-gradient row sums (gct2_ctx_set_bias_queue, ABI v16): while a queue buffer is registered, the input-gradient calls
+  // leave the partial rows of their fused bias gradients THERE (not at the tail of the workspace, which the next call reuses) and record
+  // the job; gct2_bias_queue_flush sums every recorded row set - same geometry and order as the immediate reduction launch, hence the
+  // same bits - in two launches (the targets a job overwrites first, the ones it adds to second) instead of one per call
+  struct DbJob { const float* part; int rows, N; float* db; int db_split; float* db2; int db_acc; };
+  float* dbq = nullptr; size_t dbq_floats = 0, dbq_used = 0;
+  std::vector<DbJob> dbq_jobs;
+  float* dbq_alloc(size_t floats) {
+    floats = (floats + 3) / 4 * 4;
+    if (!dbq || dbq_jobs.size() >= 16 || dbq_used + floats > dbq_floats) return nullptr;
+    float* q = dbq + dbq_used;
+    dbq_used += floats;
+    return q;
+  }
   float* wgrad_scratch(size_t* bytes) const {
     if (wws) { *bytes = wws_bytes; return wws; }
     *bytes = ws_bytes; return ws;
@@ -318,6 +333,9 @@ __device__ __forceinline__ bool xcd_tile(int id, int m_tiles, int inner, int chu
 }
 
 // the atomic fall-backs of the fused bias gradients add into their targets: overwritten targets start from zero
+// bias queue of a call context (tapgemm_mfma.hip): record the partial rows a launch left in the queue buffer / reduce everything recorded
+int tapgemm_dbq_push(gct2_ctx& c, const float* part, int rows, const TapGemmParams& p, hipStream_t s);
+int tapgemm_dbq_flush(gct2_ctx& c, hipStream_t s);
 inline void zero_overwritten_db(const TapGemmParams& p, hipStream_t s) {
   if (p.db && !(p.db_acc & 1) && p.db_split > 0) (void)hipMemsetAsync(p.db, 0, (size_t)p.db_split * sizeof(float), s);
   if (p.db2 && !(p.db_acc & 2) && p.N > p.db_split) (void)hipMemsetAsync(p.db2, 0, (size_t)(p.N - p.db_split) * sizeof(float), s);

@@ -673,9 +673,15 @@ int halo_convT(gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) 
   p.ksplit = 1;
   p.dbws = nullptr;
   p.bits_words = (p.bits && (uintptr_t)p.bits % 4 == 0 && p.ldbits % 4 == 0 && p.N % 32 == 0) ? 1 : 0;
+  float* queued = nullptr;
   if (epi == EPI_MASK && (p.db || p.db2)) {      // partial bias-gradient rows at the tail of the workspace, one per work-group row
     const size_t need = (size_t)p.m_tiles * p.N * sizeof(float);
     if (c.ws && c.ws_bytes >= need + 16) p.dbws = c.ws + (c.ws_bytes - need) / sizeof(float) / 4 * 4;
+    if (p.dbws && c.dbq) {                         // a registered bias queue takes the rows (tapgemm_mfma.hip)
+      queued = c.dbq_alloc(need / sizeof(float));
+      if (queued) p.dbws = queued;
+      else if (int e = tapgemm_dbq_flush(c, s)) return e;
+    }
     if (!p.dbws) zero_overwritten_db(p, s);
   }
 #ifdef GCT2_STAMP
@@ -693,7 +699,8 @@ int halo_convT(gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) 
   }
   if (epi == EPI_BIAS_ACT && p.bits) c.relu_bits_done = 1;      // the epilogue wrote the ReLU bit plane
   if (p.dbws) {
-    if (int e = tapgemm_dbpart_reduce(p.dbws, p.m_tiles, p, s)) return e;
+    if (queued) { if (int e = tapgemm_dbq_push(c, queued, p.m_tiles, p, s)) return e; }
+    else if (int e = tapgemm_dbpart_reduce(p.dbws, p.m_tiles, p, s)) return e;
   }
   return gct2_check_launch("halo_convT");
 }

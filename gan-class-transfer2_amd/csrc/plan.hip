@@ -1,4 +1,4 @@
-// Step plans (include/gct2.h, ABI v15): a pre-built list of launch records - entry-point calls of this library, event records and
+// Step plans (include/gct2.h, ABI v15; v16 adds the bias-queue flush to the entry table): a pre-built list of launch records - entry-point calls of this library, event records and
 // stream waits - that ONE C call walks.  The host mirror (engine.py) records the calls of a train step once and replays the list
 // every step: the same entry points with the same arguments on the same streams, hence the same kernels and the same bits, without
 // ~90 interpreter round trips per step (0.68 ms of Python enqueue per 2.5-ms step, 1.2-1.5 ms with the
@@ -30,7 +30,7 @@ struct Entry { const char* name; int (*call)(const uint64_t*); int nargs; };
 #define GCT2_ENTRY(f) {#f, [](const uint64_t* a) -> int { return thunk(&f, a); }, arity(&f)}
 // every entry point that enqueues work on a stream (the context setters that a step uses are included: the one-shot ReLU plane)
 const Entry ENTRIES[] = {
-    GCT2_ENTRY(gct2_ctx_set_relu_bits),
+    GCT2_ENTRY(gct2_ctx_set_relu_bits), GCT2_ENTRY(gct2_bias_queue_flush),
     GCT2_ENTRY(gct2_conv4s2_fwd), GCT2_ENTRY(gct2_conv4s2_dgrad), GCT2_ENTRY(gct2_conv4s2_wgrad),
     GCT2_ENTRY(gct2_convT4s2_fwd), GCT2_ENTRY(gct2_convT4s2_fwd_head_train), GCT2_ENTRY(gct2_convT4s2_dgrad), GCT2_ENTRY(gct2_convT4s2_wgrad),
     GCT2_ENTRY(gct2_adam_apply), GCT2_ENTRY(gct2_adam_keras_multi),

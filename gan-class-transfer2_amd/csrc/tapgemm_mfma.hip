@@ -578,6 +578,45 @@ __global__ __launch_bounds__(1024) void dbpart_reduce_kernel(const float* __rest
   }
 }
 
+// the same reduction for every row set of a bias queue (gct2_ctx_set_bias_queue) in ONE launch: work-group = 32 columns of one job
+// (blk0[k] = first work-group of job k), same row lanes, same order of additions as dbpart_reduce_kernel - the same bits.  A launch
+// writes only the targets of its phase: 0 = the ones a job overwrites, 1 = the ones it adds to (a target gets its first writer's sums
+// before its second writer's: two launches, in this order).
+struct DbJobs { int njobs, phase; int blk0[17]; gct2_ctx::DbJob j[16]; };
+__global__ __launch_bounds__(1024) void dbpart_reduce_multi_kernel(const DbJobs J) {
+  int k = 0;
+  while (k + 1 < J.njobs && (int)blockIdx.x >= J.blk0[k + 1]) k++;
+  const gct2_ctx::DbJob job = J.j[k];
+  const int N = job.N, rows = job.rows;
+  const float* __restrict__ part = job.part;
+  const int tid = threadIdx.x, cq = tid & 7, rl = tid >> 3;
+  const int n = ((int)blockIdx.x - J.blk0[k]) * 32 + cq * 4;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  if (n < N)
+    for (int r = rl; r < rows; r += 128) acc += *reinterpret_cast<const f32x4_t*>(part + (size_t)r * N + n);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float t = acc[i];
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    acc[i] = t;
+  }
+  __shared__ f32x4_t red[16][8];
+  if ((tid & 63) < 8) red[tid >> 6][cq] = acc;
+  __syncthreads();
+  if (tid < 8 && n < N) {
+    f32x4_t t = red[0][tid];
+#pragma unroll
+    for (int i = 1; i < 16; i++) t += red[i][tid];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int col = n + r;
+      float* q = col < job.db_split ? (job.db ? job.db + col : nullptr) : (job.db2 ? job.db2 + (col - job.db_split) : nullptr);
+      const int adds = (job.db_acc >> (col < job.db_split ? 0 : 1)) & 1;
+      if (q && adds == J.phase) *q = adds ? *q + t[r] : t[r];
+    }
+  }
+}
+
 // sums the split-K slabs and applies the epilogue the GEMM kernel skipped.  Work-group = 8 pixels x 128 channels,
 // thread = 4 channels of one pixel (split-K layers have few pixels: keep the grid wide), and the bias-gradient
 // column sums of the 8 pixels are reduced in LDS into one partial row for dbpart_reduce_kernel.
@@ -703,6 +742,11 @@ int launch(gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   p.bits_words = (p.bits && (uintptr_t)p.bits % 4 == 0 && p.ldbits % 4 == 0 && p.N % 32 == 0) ? 1 : 0;
   auto kern = tapgemm_kernel<T, FORM, BM, BN, EPI, NBUF>;
   p.dbws = db_rows ? ws + (ws_bytes - dbws_bytes) / sizeof(float) / 4 * 4 : nullptr;
+  // a registered bias queue takes the partial rows instead (same rows, same later reduction; the tile / split-K choice above does not
+  // depend on it); no room in the queue: everything queued so far is reduced first, then this call reduces its own rows at once
+  float* queued = (db_rows && c.dbq) ? c.dbq_alloc((p.ksplit > 1 ? fin_rows : (size_t)p.m_tiles * PH) * p.N) : nullptr;   // (the rows this launch really leaves)
+  if (queued) p.dbws = queued;
+  else if (db_rows && c.dbq) { if (int e = tapgemm_dbq_flush(c, s)) return e; }
   if (want_db && !p.dbws) zero_overwritten_db(p, s);
   gct2_log(c, "tap:%s:%dx%d:%s:ksplit=%d%s%s", FORM == FORM_CONV ? "conv" : FORM == FORM_CONVT ? "convT" : "s1", BM, BN,
            EPI == EPI_BIAS_ACT ? "bias_act" : "mask", p.ksplit, p.wstat ? ":wstat" : "", (p.bits && p.wide && p.ksplit == 1) ? ":bits" : "");
@@ -713,7 +757,8 @@ int launch(gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   if (EPI == EPI_BIAS_ACT && p.bits && p.wide && p.ksplit == 1) c.relu_bits_done = 1;   // the 16-byte epilogue wrote the ReLU bit plane
   if (p.dbws) {
     const int rows = p.ksplit > 1 ? (int)fin_rows : p.m_tiles * PH;
-    hipLaunchKernelGGL(dbpart_reduce_kernel, dim3((p.N + 31) / 32), dim3(1024), 0, s, p.dbws, rows, p);
+    if (queued) { if (int e = tapgemm_dbq_push(c, queued, rows, p, s)) return e; }
+    else hipLaunchKernelGGL(dbpart_reduce_kernel, dim3((p.N + 31) / 32), dim3(1024), 0, s, p.dbws, rows, p);
   }
   return gct2_check_launch("tapgemm_mfma");
 }
@@ -767,6 +812,54 @@ bool halo_convT_wanted(const gct2_ctx& c, int epi, const TapGemmParams& p);     
 int halo_convT(gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s);
 
 // the ordered row reduction of the fused bias gradients, for the other translation units that leave partial rows
+// bias queue: record a row set / reduce everything recorded (two launches: overwriting targets, then adding ones)
+int tapgemm_dbq_flush(gct2_ctx& c, hipStream_t s) {
+  if (c.dbq_jobs.empty()) { c.dbq_used = 0; return GCT2_OK; }
+  DbJobs J{};
+  J.njobs = (int)c.dbq_jobs.size();
+  int blocks = 0, any[2] = {0, 0};
+  for (int k = 0; k < J.njobs; k++) {
+    J.j[k] = c.dbq_jobs[k];
+    J.blk0[k] = blocks;
+    blocks += (J.j[k].N + 31) / 32;
+    const gct2_ctx::DbJob& j = J.j[k];
+    if (j.db && j.db_split > 0) any[j.db_acc & 1] = 1;
+    if (j.db2 && j.db_split < j.N) any[(j.db_acc >> 1) & 1] = 1;
+  }
+  J.blk0[J.njobs] = blocks;
+  gct2_log(c, "bias_queue:flush:sets=%d", J.njobs);
+  c.dbq_jobs.clear();
+  c.dbq_used = 0;
+  for (int phase = 0; phase < 2; phase++) {
+    if (!any[phase]) continue;
+    J.phase = phase;
+    hipLaunchKernelGGL(dbpart_reduce_multi_kernel, dim3(blocks), dim3(1024), 0, s, J);
+  }
+  return gct2_check_launch("bias_queue_flush");
+}
+int tapgemm_dbq_push(gct2_ctx& c, const float* part, int rows, const TapGemmParams& p, hipStream_t s) {
+  // two jobs that ADD to one target would race inside the second launch: reduce what is queued before recording the second of them
+  for (const gct2_ctx::DbJob& j : c.dbq_jobs) {
+    const bool a0 = (p.db_acc & 1) && p.db && p.db_split > 0, a1 = (p.db_acc & 2) && p.db2 && p.db_split < p.N;
+    const bool b0 = (j.db_acc & 1) && j.db && j.db_split > 0, b1 = (j.db_acc & 2) && j.db2 && j.db_split < j.N;
+    auto overlap = [](const float* x, int nx, const float* y, int ny) { return x < y + ny && y < x + nx; };
+    bool clash = false;
+    if (a0 && b0) clash |= overlap(p.db, p.db_split, j.db, j.db_split);
+    if (a0 && b1) clash |= overlap(p.db, p.db_split, j.db2, j.N - j.db_split);
+    if (a1 && b0) clash |= overlap(p.db2, p.N - p.db_split, j.db, j.db_split);
+    if (a1 && b1) clash |= overlap(p.db2, p.N - p.db_split, j.db2, j.N - j.db_split);
+    if (clash) {
+      // (the rows of THIS job are already in the queue buffer: keep them valid across the flush by flushing the jobs only)
+      const size_t used = c.dbq_used;
+      if (int e = tapgemm_dbq_flush(c, s)) return e;
+      c.dbq_used = used;
+      break;
+    }
+  }
+  c.dbq_jobs.push_back(gct2_ctx::DbJob{part, rows, p.N, p.db, p.db_split, p.db2, p.db_acc});
+  return GCT2_OK;
+}
+
 int tapgemm_dbpart_reduce(const float* part, int rows, const TapGemmParams& p, hipStream_t s) {
   hipLaunchKernelGGL(dbpart_reduce_kernel, dim3((p.N + 31) / 32), dim3(1024), 0, s, part, rows, p);
   return gct2_check_launch("dbpart_reduce");

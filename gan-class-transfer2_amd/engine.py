@@ -289,6 +289,11 @@ class UNetEngine:
         self.defer_adam = True
         self.defer_layers = ("U0", "U1", "U2")
         self.defer_window_at = 3          # the held-back launches start once DownShuffle_<this> of the next forward pass is enqueued
+        # r05: the eleven small launches that sum the partial rows of the fused bias gradients leave the input-gradient chain - the calls
+        # queue their rows (gct2_ctx_set_bias_queue) and ONE flush (two launches) behind the last input gradient sums them: same bits
+        self.defer_rowsums = True
+        self._bias_queue = None
+        self._bias_queue_on = False
         self._pending: list = []
         self._pending_event = None
         self._flush_event = None
@@ -721,6 +726,12 @@ class UNetEngine:
         scaling): each layer's Adam step is fused behind its weight-gradient call (gct2_adam_args) once the layer's dgrad -
         the last reader of its weights - is done.  The current stream joins the side stream before returning."""
         t, n, dt, A, cx = self.topo, self.topo.octaves, self.dtype, self.arena, self.ctx.handle
+        want_queue = bool(self.defer_rowsums) and self.workspace is not None
+        if want_queue != self._bias_queue_on:
+            if want_queue and self._bias_queue is None:
+                self._bias_queue = torch.empty(4 << 20, dtype=torch.float32, device=self.device)       # 16 MiB: ~6 MB of rows per pass at config 3
+            self.ctx.set_bias_queue(self._bias_queue if want_queue else None)
+            self._bias_queue_on = want_queue
         caller = torch.cuda.current_stream(self.device)
         if self.overlap and self.chain_priority and self._chain_stream is None:
             self._chain_stream = torch.cuda.Stream(device=self.device, priority=-1)
@@ -825,6 +836,8 @@ class UNetEngine:
 
             if adam_inline:
                 dgrad_d()
+            if i == 0 and self._bias_queue_on:                  # every input-gradient launch is enqueued: sum the queued bias rows
+                call("gct2_bias_queue_flush", cx, s)
             if i == 0:
                 # every input-gradient launch (the writers of the bias gradients) and the head are enqueued on the chain's stream: the
                 # fp32 zone - Dense(3) and all biases - is complete.  Its optimizer step is one small launch right here (nothing reads
@@ -976,7 +989,7 @@ class UNetEngine:
         return (id(b), apply, inline, cur.cuda_stream, self.ctx.version, self.ctx_tail.version,
                 tuple(sorted((k, c.version) for k, c in self._defer_ctxs.items())), tuple(l for _, l, _ in self._pending),
                 id(self.grad_ready_hook), self.hook_plan_aware, id(self.post_backward), self.overlap, self.chain_priority, self.fuse_adam, self.defer_adam, tuple(self.defer_layers),
-                self.defer_window_at, self.tail_on_chain, self.use_fused_head, self.fuse_u0_head, self.keep_pred, self.relu_bits,
+                self.defer_window_at, self.defer_rowsums, self.tail_on_chain, self.use_fused_head, self.fuse_u0_head, self.keep_pred, self.relu_bits,
                 self.ls_state is not None, self.workspace is not None, self.wgrad_workspace is not None, self.steps, self.rng_seed)
 
     def _planned_step(self, b: _Buffers, x: torch.Tensor, apply: bool, inline: bool, cur: "torch.cuda.Stream") -> torch.Tensor:

@@ -37,7 +37,7 @@ enum {
 };
 
 /* library / device identification ------------------------------------------------------------ */
-int gct2_abi_version(void);                 /* bumps when a signature below changes (v13: ReLU bit planes; v14: pruned tuning word, launch log, no deferred row sums; v15: launch-log read reports the size it needs, step plans) */
+int gct2_abi_version(void);                 /* bumps when a signature below changes (v13: ReLU bit planes; v14: pruned tuning word, launch log, no deferred row sums; v15: launch-log read reports the size it needs, step plans; v16: bias queue) */
 /* how the library was built: 0 for the product build; bit 0 (GCT2_BUILD_STAMP) = diagnostic build with in-kernel phase stamps
  * (make EXTRA=-DGCT2_STAMP).  Product hosts (the Python binding, bench.py, the tests) refuse a library whose flags are not 0. */
 enum { GCT2_BUILD_STAMP = 1 };
@@ -61,6 +61,16 @@ int gct2_ctx_set_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
 /* optional second scratch used by the weight-gradient entry points only (their partial-tile slabs): with it *_wgrad calls
  * may run on a second stream concurrently with the forward/dgrad calls of the same ctx (the engine's reverse pass does). */
 int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
+/* Bias queue (ABI v16).  The input-gradient entry points fuse the bias gradient of the tensor they write into their epilogue and leave
+ * partial rows that ONE small launch per call sums in a fixed order.  Eleven such launches sit between the input-gradient launches of a
+ * reverse pass; with a queue buffer registered (16-byte aligned device memory; a few MB: rows x channels x 4 bytes per call) the calls of
+ * this ctx leave their partial rows in the buffer and record the row set instead, and gct2_bias_queue_flush sums every recorded set -
+ * same geometry, same order of additions, same "first writer overwrites, second adds" as the immediate launches, hence the same bits -
+ * in two launches on `stream`.  All calls that fill one queue and its flush must be enqueued on ONE stream; a call whose rows do not fit
+ * (or a 17th row set) first flushes what is queued and then reduces its own rows at once; buf = NULL returns to the immediate form and
+ * drops row sets that were recorded and not flushed. */
+int gct2_ctx_set_bias_queue(gct2_ctx* ctx, void* buf, size_t bytes);
+int gct2_bias_queue_flush(gct2_ctx* ctx, void* stream);
 /* tuning: forces a tile / order instead of the automatic per-layer choice (same results for every value within the stated
  * tolerances; the parity tests and scripts/bench_layer.py use it).  Unknown words are rejected.
  * bits 0-7  : forward / input-gradient tile: 0 = automatic, 2 = 128x128 (two LDS buffers), 5 = 256x128 (one buffer, 8 waves);

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gct2.h but not exported"
     # and the ctypes table binds exactly the declared entry points (minus last_error, bound separately)
     assert sorted(set(g._lib.SIGNATURES) | {"gct2_last_error"}) == names
-    assert g._lib.load().gct2_abi_version() == g._lib.ABI_VERSION == 15
+    assert g._lib.load().gct2_abi_version() == g._lib.ABI_VERSION == 16
     # the shipped library is the PRODUCT build: no in-kernel stamps, and the diagnostic hook refuses
     assert g._lib.build_flags() == 0
     c = g._lib.Context()

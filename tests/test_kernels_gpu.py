@@ -475,6 +475,74 @@ def test_dgrad_fused_bias_gradients(gpu, dt, shape, use_ws):
         set_ws(None)
 
 
+@pytest.mark.parametrize("queue_floats", [1 << 20, 3000])
+def test_bias_queue_flush_equals_the_immediate_row_sums(gpu, queue_floats):
+    """ABI v16: with a bias queue registered the input-gradient calls leave the partial rows of their fused bias gradients in the queue
+    and ONE flush sums every recorded row set (overwritten targets first, added-to targets second) - same geometry, same order, hence
+    the same bits as the per-call reduction launches.  A chain like the reverse pass: a Conv2DTranspose input gradient that OVERWRITES
+    two targets (MFMA epilogue), a Conv2D input gradient through the split-K finalize that ADDS to the second of them, a halo-kernel
+    call, then a second adder of the same target (forces the early flush); with a queue that holds everything and with one so small
+    that calls fall back to the immediate form in the middle."""
+    dt, L = BF16, lib()
+    rng = np.random.default_rng(77)
+    ws = torch.empty(32 << 18, dtype=torch.float32, device=gpu)
+    set_ws(ws)
+    B, H, W, Cin, Cout = 2, 16, 16, 128, 64
+    split = 64
+    x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+    wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+    dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+    w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+    xd, wtd, dztd, wd, dzd = dev(x, dt, gpu), dev(wt, dt, gpu), dev(dzt, dt, gpu), dev(w, dt, gpu), dev(dz, dt, gpu)
+    # a halo-kernel shape (16-multiples, 64-channel multiples): Conv2D input gradient = convT form
+    B2, H2, W2, C2in, C2out = 2, 32, 32, 64, 128
+    x2 = rnd(np.maximum(rng.standard_normal((B2, H2, W2, C2in)), 0), dt)
+    w2 = rnd(rng.standard_normal((4, 4, C2in, C2out)) * 0.1, dt)
+    dz2 = rnd(rng.standard_normal((B2, H2 // 2, W2 // 2, C2out)), dt)
+    x2d, w2d, dz2d = dev(x2, dt, gpu), dev(w2, dt, gpu), dev(dz2, dt, gpu)
+
+    def chain(queue):
+        if queue is not None:
+            L.call("gct2_ctx_set_bias_queue", ctx(), queue.data_ptr(), queue.numel() * 4)
+        dba = torch.full((split,), float("nan"), device=gpu); dbb = torch.full((Cin - split,), float("nan"), device=gpu)
+        dbc = torch.full((C2in,), 7.0, device=gpu)
+        dx = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
+        dx2 = torch.zeros(B2, H2, W2, C2in, dtype=TDT[dt], device=gpu)
+        try:
+            L.call("gct2_convT4s2_dgrad", ctx(), dt, dztd.data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dx.data_ptr(), Cin,
+                   B, H, W, Cin, Cout, 0, dba.data_ptr(), split, dbb.data_ptr(), 0, stream())
+            L.call("gct2_conv4s2_dgrad", ctx(), dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dx.data_ptr(), Cin,
+                   B, H, W, Cin, Cout, 1, None, split, dbb.data_ptr(), 2, stream())
+            L.call("gct2_conv4s2_dgrad", ctx(), dt, dz2d.data_ptr(), C2out, w2d.data_ptr(), x2d.data_ptr(), C2in, dx2.data_ptr(), C2in,
+                   B2, H2, W2, C2in, C2out, 0, dbc.data_ptr(), C2in, None, 1, stream())
+            L.call("gct2_conv4s2_dgrad", ctx(), dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dx.data_ptr(), Cin,
+                   B, H, W, Cin, Cout, 1, None, split, dbb.data_ptr(), 2, stream())
+            if queue is not None:
+                L.call("gct2_bias_queue_flush", ctx(), stream())
+            torch.cuda.synchronize()
+        finally:
+            if queue is not None:
+                L.call("gct2_ctx_set_bias_queue", ctx(), None, 0)
+        return dba, dbb, dbc, dx, dx2
+
+    try:
+        ref = chain(None)
+        got = chain(torch.empty(queue_floats, dtype=torch.float32, device=gpu))
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+        assert bool(torch.isfinite(ref[0]).all()) and bool(torch.isfinite(ref[1]).all())
+        # ... and against the oracle: the first target holds the first call's sums, the second one three contributions
+        c_t = O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)
+        c_c = O.conv4s2_bwd(x, w, dz)[0] * (x > 0)
+        want_b = (c_t.reshape(-1, Cin).sum(0) + 2 * c_c.reshape(-1, Cin).sum(0))[split:]
+        scale = np.abs(c_t).reshape(-1, Cin).sum(0).max() + 2 * np.abs(c_c).reshape(-1, Cin).sum(0).max()
+        assert np.abs(ref[0].cpu().numpy() - c_t.reshape(-1, Cin).sum(0)[:split]).max() <= 2e-3 * scale
+        assert np.abs(ref[1].cpu().numpy() - want_b).max() <= 2e-3 * scale
+    finally:
+        set_ws(None)
+
+
 @pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("shape", [(2, 8, 8, 256, 64), (1, 16, 16, 328, 72), (8, 4, 4, 512, 256)])
 def test_big_tile_dgrad_epilogues(gpu, shape, use_ws):

@@ -470,6 +470,46 @@ def test_planned_step_equals_eager_step_bit_for_bit(gpu, mode):
         assert torch.equal(out[0][1][n], out[1][1][n]), n
 
 
+@pytest.mark.parametrize("mode", ["fused", "apply_false", "loss_scaled"])
+def test_deferred_bias_row_sums_equal_the_immediate_ones_bit_for_bit(gpu, mode):
+    """r05 / ABI v16: the eleven small launches that sum the partial rows of the fused bias gradients are replaced by ONE flush behind
+    the last input gradient (engine.defer_rowsums, the default): losses, gradients (apply_false) and every arena must EQUAL the
+    immediate form's, eager and replayed from a plan."""
+    cfg = O.OracleConfig(size=64, pixel_size=128, max_size=512, octaves=4, batch_size=4)
+    params = O.init_params(cfg, seed=3)
+    xs = [torch.tensor(O.synthetic_batch(cfg, seed=k)[0], dtype=torch.float32, device=gpu) for k in range(3)]
+    out = []
+    for defer in (False, True):
+        eng = make_engine(cfg, 2 if mode == "loss_scaled" else 1, gpu, rng_seed=5, loss_scaling=(mode == "loss_scaled"))
+        eng.defer_rowsums = defer
+        eng.set_params(params)
+        losses, grads = [], []
+        for k in range(5):
+            if mode == "apply_false":
+                losses.append(eng.train_step(xs[k % 3], apply=False).clone())
+                grads.append(eng.arena.g.clone())
+                eng.check_finite(); eng.apply_adam(); eng.finish_step()
+            else:
+                losses.append(eng.train_step(xs[k % 3]).clone())
+        torch.cuda.synchronize()
+        assert eng._bias_queue_on == defer
+        if mode == "fused":                                   # one more step with the launch log on: ONE flush holds every row set of the pass
+            eng.use_plan = False
+            eng.ctx.log_launches(True)
+            eng.train_step(xs[0])
+            torch.cuda.synchronize()
+            flushes = [t for t in eng.ctx.read_launch_log() if t.startswith("bias_queue:flush")]
+            eng.ctx.log_launches(False)
+            assert flushes == (["bias_queue:flush:sets=%d" % (2 * cfg.octaves - 1)] if defer else []), flushes
+            losses.append(eng.train_step(xs[1]).clone())
+        out.append((torch.cat(losses), grads, {n: getattr(eng.arena, n).clone() for n in ("p", "m", "v", "shadow")}))
+    assert torch.equal(out[0][0], out[1][0]), (out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert torch.equal(a, b)
+    for n in ("p", "m", "v", "shadow"):
+        assert torch.equal(out[0][2][n], out[1][2][n]), n
+
+
 def test_planned_step_with_gradient_ready_hook_runs_the_hook_between_segments(gpu):
     """a gradient-ready hook (the data-parallel wrappers) cuts the plan into segments; the replay calls it at the same points, in
     the same order, with the producing stream current - and the arenas equal the eager run's."""
