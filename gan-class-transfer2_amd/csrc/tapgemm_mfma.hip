@@ -623,8 +623,13 @@ __global__ __launch_bounds__(1024) void dbpart_reduce_multi_kernel(const DbJobs 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, size_t npix) {
   const int N = p.N;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int n = blockIdx.y * 128 + tx * 4;
+  // r05: a wave = 8 pixels x 32 channels (lane = 8 * pixel + channel quad), so the eight pixels of a column meet INSIDE a wave (three
+  // xor-shuffles) and the kernel needs no LDS: with 40 registers and no LDS its work-groups fit beside the weight-gradient tile that owns
+  // every CU's LDS on the other stream, instead of waiting for one of those work-groups to retire (the 4 KiB of the r01-r04 form made
+  // this 8-us kernel take 30-110 us in the step)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ty = lane >> 3;
+  const int n = blockIdx.y * 128 + wave * 32 + (lane & 7) * 4;
   const size_t pix0 = (size_t)blockIdx.x * 8;
   T* __restrict__ yout = reinterpret_cast<T*>(p.y);
   f32x4_t bsum = {0.f, 0.f, 0.f, 0.f};
@@ -637,12 +642,15 @@ __global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, 
         const float* base = p.ws + opix * N + n;
         const size_t sstride = npix * (size_t)N;
         int s = 0;
-        for (; s + 8 <= p.ksplit; s += 8) {
-          f32x4_t t[8];
+        // (the input-gradient form keeps TWO loads in flight and 30 registers: it has to fit into the 32 registers per lane that two
+        // 240-register weight-gradient waves leave on a SIMD; the forward form runs beside nothing of that kind: eight loads)
+        constexpr int NLD = EPI == EPI_MASK ? 2 : 8;
+        for (; s + NLD <= p.ksplit; s += NLD) {
+          f32x4_t t[NLD];
 #pragma unroll
-          for (int u = 0; u < 8; u++) t[u] = *reinterpret_cast<const f32x4_t*>(base + (size_t)(s + u) * sstride);
+          for (int u = 0; u < NLD; u++) t[u] = *reinterpret_cast<const f32x4_t*>(base + (size_t)(s + u) * sstride);
 #pragma unroll
-          for (int u = 0; u < 8; u++) v += t[u];
+          for (int u = 0; u < NLD; u++) v += t[u];
         }
         for (; s < p.ksplit; s++) v += *reinterpret_cast<const f32x4_t*>(base + (size_t)s * sstride);
       }
@@ -672,19 +680,21 @@ __global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, 
     }
   }
   if (EPI == EPI_MASK && (p.db || p.db2)) {
-    __shared__ f32x4_t red[8][32];
-    red[ty][tx] = bsum;
-    __syncthreads();
-    if (ty == 0 && n < N) {
-      f32x4_t t = red[0][tx];
+    // column sums of the work-group's 8 pixels: pixel pairs (1 apart), then 2 apart, then 4 apart - a fixed tree, every lane ends
+    // with the total; the lanes of pixel 0 store the partial row (lanes outside N hold zeros and store nothing)
 #pragma unroll
-      for (int k = 1; k < 8; k++) t += red[k][tx];
-      if (p.dbws) *reinterpret_cast<f32x4_t*>(p.dbws + (size_t)blockIdx.x * N + n) = t;   // one partial row per work-group row
+    for (int r = 0; r < 4; r++) {
+      float t = bsum[r];
+      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+      bsum[r] = t;
+    }
+    if (ty == 0 && n < N) {
+      if (p.dbws) *reinterpret_cast<f32x4_t*>(p.dbws + (size_t)blockIdx.x * N + n) = bsum;   // one partial row per work-group row
       else {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           float* q = db_target(p, n + r);
-          if (q) atomicAdd(q, t[r]);
+          if (q) atomicAdd(q, bsum[r]);
         }
       }
     }
