@@ -230,7 +230,7 @@ int gct2_bias_queue_flush(gct2_ctx* ctx, void* stream) {
 int gct2_ctx_set_tuning(gct2_ctx* ctx, int v) {
   if (!ctx) return gct2_fail(GCT2_EINVAL, "ctx_set_tuning: null ctx");
   const int tap = v & 0xff, wg = (v >> 16) & 0xff, known = 0x1ff | (0xff << 16) | (0x7f << 24);
-  if ((v & ~known) || (tap != 0 && tap != 2 && tap != 5) || (wg != 0 && wg != 2 && wg != 3 && wg != 4 && wg != 5 && wg != 7) || ((v >> 24) & 3) == 3 || ((v >> 26) & 3) == 3)
+  if ((v & ~known) || (tap != 0 && tap != 2 && tap != 5) || (wg != 0 && wg != 2 && wg != 3 && wg != 4 && wg != 5 && wg != 6 && wg != 7) || ((v >> 24) & 3) == 3 || ((v >> 26) & 3) == 3)
     return gct2_fail(GCT2_EINVAL, "ctx_set_tuning: unknown tuning word 0x%x (include/gct2.h)", v);
   ctx->tap_variant = tap;
   ctx->wgrad_variant = wg;

@@ -25,7 +25,7 @@ struct gct2_ctx {
   float* ws = nullptr; size_t ws_bytes = 0;        // split-K slabs, partial rows (forward / input-gradient / head calls)
   float* wws = nullptr; size_t wws_bytes = 0;      // weight-gradient slabs (falls back to ws)
   int tap_variant = 0;                             // forward / input-gradient tile: 0 = automatic, 2 = 128 x 128, 5 = 256 x 128
-  int wgrad_variant = 0;                           // weight-gradient tile: 0 = automatic, 2 = 256 x 256, 4 / 5 = 256 x 256 in the r03 / r04 stage order, 3 = 128 x 128, 7 = 128 x 128 with atomics
+  int wgrad_variant = 0;                           // weight-gradient tile: 0 = automatic, 2 = 256 x 256, 4 / 5 = 256 x 256 in the r03 / r04 stage order, 3 = 128 x 128, 6 = 128 x 128 with the general (r04) address code, 7 = 128 x 128 with atomics
   int halo_mode = 0;                               // 0 = automatic, 1 = never, 2 = wherever the shape allows
   int xcd_order = 0;                               // tile -> XCD order: 0 = automatic, 1 = m-tile bands, 2 = weight slices
   int wgrad_split = 0;                             // forced pixel split of the 128 x 128 weight-gradient tile: 0 = automatic, v: 2^(v-1)

@@ -34,8 +34,15 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_pie
 
 // S1: the weight gradient of a 'same' stride-1 convolution with p.ks x p.ks taps (Block's 3x3, the 1x1 projection of residual=True:
 // train.py:104-143): both tensors on ONE grid, tap (kh, kw) pairs pixel r with (h + kh - pad, w + kw - pad); everything else is shared.
-template <typename T, bool S1 = false>
+// IMGAL (r05): a 64-row step covers WHOLE images of the small grid (64 % (Hs * Ws) == 0: every 128 x 128 launch of the reference topology -
+// the 8 x 8 ... 1 x 1 grids of the bottleneck levels): a lane's position inside its image, its tap's validity and its byte offsets relative
+// to the step's first image never change - the gather addresses are "constant + step x stride" (one add per piece) and the fragment
+// addresses lane constants computed once, instead of ~90 vector instructions per step beside its 32 multiplies (decode of every row,
+// three multiply-adds per gathered piece, the fragment addresses rebuilt per read).  Same sources, same zero fill, same multiplies in the
+// same order: bit-identical to the general form.
+template <typename T, bool S1 = false, bool IMGAL = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
+  static_assert(!(S1 && IMGAL), "the image-aligned form exists for the 4x4 / stride-2 layers");
   constexpr int IMG = 64 * 256;
   const int KS = S1 ? p.ks : 4, STRIDE = S1 ? 1 : 2, PAD = S1 ? (p.ks - 1) / 2 : 1;   // compile-time constants for the 4x4 layers
   __shared__ __attribute__((aligned(16))) char lds0[2 * IMG];     // [big image | small image]
@@ -92,7 +99,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     rw[i] = r % Ws; const int t = r / Ws; rh[i] = t % Hs; rb[i] = t / Hs;
   }
 
-  auto issue = [&](int step, char* base) {
+  // ---- IMGAL: lane constants (row i of this lane sits at the same place of the same image-in-step in every step)
+  unsigned cB[4], cS[4];
+  bool vB[4];
+  int rr4[4];
+  const unsigned stepB = IMGAL ? (unsigned)((64 / (Hs * Ws)) * Hb * Wb * ldb2) : 0u, stepS = (unsigned)(64 * lds2);
+  if constexpr (IMGAL) {
+    const int hw = Hs * Ws;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int rr = row0 + 16 * i, img = rr / hw, pos = rr - img * hw, sh = pos / Ws, sw = pos - sh * Ws;
+      const int h = 2 * sh + kh - 1, w = 2 * sw + kw - 1;
+      rr4[i] = rr;
+      vB[i] = gc_ok && (unsigned)h < (unsigned)Hb && (unsigned)w < (unsigned)Wb;
+      cB[i] = (unsigned)(((img * Hb + h) * Wb + w) * ldb2 + cb * 2) + (unsigned)step_lo * stepB;
+      cS[i] = (unsigned)(rr * lds2 + (cs0 + lc * 8) * 2) + (unsigned)step_lo * stepS;
+    }
+  }
+  auto issue_al = [&](int step, char* base) {                     // steps are issued in increasing order: the offsets advance in place
+    const int rem = R - step * 64;                                 // rows of this step that exist (uniform)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bool in = rr4[i] < rem;
+      dma16(rs_b, base + (wave + 4 * i) * 1024, (vB[i] && in) ? cB[i] : OOB);
+      dma16(rs_s, base + IMG + (wave + 4 * i) * 1024, (cs_ok && in) ? cS[i] : OOB);
+      cB[i] += stepB; cS[i] += stepS;
+    }
+  };
+  auto issue_gen = [&](int step, char* base) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = step * 64 + row0 + 16 * i;
@@ -108,6 +142,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       if (rh[i] >= Hs) { rh[i] -= Hs; rb[i]++; }
     }
   };
+  auto issue = [&](int step, char* base) {
+    if constexpr (IMGAL) issue_al(step, base);
+    else issue_gen(step, base);
+  };
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -115,14 +153,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // fragment addresses: lane offsets inside a T image, computed once (IMGAL); row k0 + 4 has the swizzle of row k0
+  int bfo[2][4], sfo[2][4];
+  if constexpr (IMGAL) {
+    const int g4 = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      const int k0 = kk * 32 + 8 * g4 + q, swz = timg_swz(k0);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        bfo[kk][i] = k0 * 256 + ((((wm * 64 + i * 16) >> 4) ^ swz) << 5) + pq * 8;
+        sfo[kk][i] = IMG + k0 * 256 + ((((wn * 64 + i * 16) >> 4) ^ swz) << 5) + pq * 8;
+      }
+    }
+  }
+  auto frag_at = [&](const char* base, int off) -> u32x4_t {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + off));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base + off + 4 * 256));
+    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+    return u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+  };
   auto compute = [&](const char* base) {
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
       u32x4_t bf[4], sf[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        bf[i] = timg_frag(base, wm * 64 + i * 16, kk, lane);
-        sf[i] = timg_frag(base + IMG, wn * 64 + i * 16, kk, lane);
+        if constexpr (IMGAL) {
+          bf[i] = frag_at(base, bfo[kk][i]);
+          sf[i] = frag_at(base, sfo[kk][i]);
+        } else {
+          bf[i] = timg_frag(base, wm * 64 + i * 16, kk, lane);
+          sf[i] = timg_frag(base + IMG, wn * 64 + i * 16, kk, lane);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; i++)
@@ -733,8 +796,15 @@ int wgrad_mfma(gct2_ctx& c, int dtype, WgradParams p, hipStream_t s, WgradSlabs*
       else hipLaunchKernelGGL((wgrad256q_kernel<_Float16, false, false>), grid, dim3(512), 0, s, p);
     }
   } else {
-    if (dtype == GCT2_BF16) hipLaunchKernelGGL((wgrad_kernel<__bf16>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<_Float16>), grid, dim3(256), 0, s, p);
+    // whole images of the small grid per 64-row step (tuning 16-23 = 6 keeps the general form for the bit-identity test)
+    const bool imgal = 64 % (p.Hs * p.Ws) == 0 && variant != 6;
+    if (dtype == GCT2_BF16) {
+      if (imgal) hipLaunchKernelGGL((wgrad_kernel<__bf16, false, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((wgrad_kernel<__bf16>), grid, dim3(256), 0, s, p);
+    } else {
+      if (imgal) hipLaunchKernelGGL((wgrad_kernel<_Float16, false, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((wgrad_kernel<_Float16>), grid, dim3(256), 0, s, p);
+    }
   }
   if (p.ws && defer && !p.accumulate) *defer = WgradSlabs{p.ws, rsplit, n};     // the caller's optimizer kernel sums the slabs
   else if (p.ws) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, p.ws, p.dw, n / 4, rsplit, p.accumulate);

@@ -77,7 +77,8 @@ int gct2_bias_queue_flush(gct2_ctx* ctx, void* stream);
  * bit 8     : the forward / input-gradient GEMMs never split their reduction over work-groups (parity tests at reduced batch: the
  *             kernels of the batch-64 dispatch then run the way they do at batch 64);
  * bits 16-23: weight-gradient tile: 0 = automatic, 2 = 256x256 five-stage ring, 4 / 5 = the same in the r03 / r04 stage order
- *             (bit-identity tests of the later orders), 3 = 128x128, 7 = 128x128 with fp32 atomics instead of ordered slabs (arrival-order
+ *             (bit-identity tests of the later orders), 3 = 128x128, 6 = 128x128 with the general address code (bit-identity test of the
+ *             image-aligned form), 7 = 128x128 with fp32 atomics instead of ordered slabs (arrival-order
  *             dependent: comparison tests only);
  * bits 24-25: halo-tile kernel (Conv2DTranspose forward / Conv2D input gradient): 0 = automatic, 1 = never, 2 = wherever allowed;
  * bits 26-27: tile -> XCD order of the forward / input-gradient GEMMs: 0 = automatic, 1 = bands of output pixels per XCD,

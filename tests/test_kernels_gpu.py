@@ -289,6 +289,41 @@ def test_wgrad_turns_and_scalar_addresses_equal_r03_order_bit_for_bit(gpu, shape
         set_ws(None)
 
 
+@pytest.mark.parametrize("shape", [(8, 16, 16, 128, 64), (16, 8, 8, 64, 128), (64, 4, 4, 256, 72), (40, 2, 2, 128, 128), (3, 8, 8, 64, 64),
+                                   (5, 16, 16, 72, 136), (9, 4, 8, 64, 64)])
+def test_wgrad_image_aligned_addresses_equal_the_general_form_bit_for_bit(gpu, shape):
+    """r05: the 128x128 weight-gradient tile on grids where a 64-row step covers whole images (64 % (H/2 * W/2) == 0: the bottleneck
+    levels) takes its gather addresses as "lane constant + step x stride" and its fragment addresses as lane constants - against the
+    general address code (tuning 16-23 = 6): same sources, same zero fill, same multiplies, hence the same bits.  8x8 ... 1x1 small
+    grids, a last step with missing rows, ragged channel counts, and a grid (2x4) whose images do not divide a step into a power of
+    two of rows per image row."""
+    B, H, W, Cin, Cout = shape
+    dt, L = BF16, lib()
+    rng = np.random.default_rng(81)
+    x = rnd(rng.standard_normal((B, H, W, Cin)), dt)
+    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+    dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+    xd, dzd, dztd = dev(x, dt, gpu), dev(dz, dt, gpu), dev(dzt, dt, gpu)
+    ws = torch.empty(64 << 18, dtype=torch.float32, device=gpu)
+    set_ws(ws)
+    res = {}
+    try:
+        for variant in (3, 6):
+            set_tuning(variant << 16)
+            dw = torch.full((4, 4, Cin, Cout), float("nan"), dtype=torch.float32, device=gpu)
+            dwt = torch.full((4, 4, Cout, Cin), float("nan"), dtype=torch.float32, device=gpu)
+            L.call("gct2_conv4s2_wgrad", ctx(), dt, xd.data_ptr(), Cin, dzd.data_ptr(), Cout, dw.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
+            L.call("gct2_convT4s2_wgrad", ctx(), dt, xd.data_ptr(), Cin, dztd.data_ptr(), Cout, dwt.data_ptr(), None, B, H, W, Cin, Cout, 0, None, stream())
+            torch.cuda.synchronize()
+            res[variant] = (dw, dwt)
+        assert torch.equal(res[3][0], res[6][0]) and torch.equal(res[3][1], res[6][1])
+        assert rel_l2(res[3][0].cpu().numpy(), O.conv4s2_bwd(x, np.zeros((4, 4, Cin, Cout)), dz)[1]) <= TOL_F32OUT[dt]
+        assert rel_l2(res[3][1].cpu().numpy(), O.convT4s2_bwd(x, np.zeros((4, 4, Cout, Cin)), dzt)[1]) <= TOL_F32OUT[dt]
+    finally:
+        set_tuning(0)
+        set_ws(None)
+
+
 @pytest.mark.parametrize("variant", [2, 3])
 @pytest.mark.parametrize("shape", [(3, 40, 24, 64, 128), (5, 8, 8, 128, 64), (2, 64, 64, 64, 256), (7, 4, 12, 256, 72)])
 def test_wgrad_incremental_gather_addresses(gpu, shape, variant):
