@@ -8,9 +8,13 @@ fp32 accumulation (BASELINE.json config 3; config 4 when launched on N > 1 GPUs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant KERNEL SYMBOL by summed time (HIP events on the launching stream
-around every layer call of 4 extra single-stream steps, the kernel each call selected taken from the library's launch log; its own
-algorithmic FLOPs / its own average duration); `kernels` keeps the per-family table, `kernel_symbols` the per-symbol one;
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant KERNEL SYMBOL (form, tile AND epilogue: 1:1 with a rocprofv3 row) by
+the sum of its calls' MEDIAN durations over >= 8 extra single-stream steps.  Those steps are REPLAYED from a recorded step plan whose
+layer calls are bracketed by timed event records on the launching stream (gct2_plan_add_record_kind / gct2_plan_elapsed), each measured
+step enqueued right behind an unmeasured one: no interpreter code runs between an event and its launch and the GPU never idles in
+front of one (r05's eager leg booked host stalls as kernel time: DESIGN.md section 6).  The kernel each call selected comes from the
+library's launch log; `roofline.achieved` = the symbol's algorithmic FLOPs / that time, `min / median / max` per symbol are in
+`kernel_symbols`, `roofline.suspect` is set when the figure contradicts the step time; `kernels` keeps the per-family table;
 `roofline.step_frac` (= `step_roofline_frac`) is the whole step against the 2.5 PFLOP/s dense bf16 MFMA peak (SURVEY.md §8d:
 F_train = 32.1314 GFLOP/image at 128^2).
 `cpu_baseline` times oracle/torch_cross.py (a CPU restatement of train.py - TensorFlow is not installable here) on
@@ -82,24 +86,44 @@ def call_label(name, a):
 call_label.size = 128
 
 
+_FORM = {"conv": 0, "convT": 1, "s1": 2}
+
+
 def kernel_symbol(token):
-    """launch-log token (include/gct2.h gct2_ctx_log_launches) -> the kernel symbol rocprofv3 lists for it"""
+    """launch-log token (include/gct2.h gct2_ctx_log_launches) -> the kernel symbol, one per rocprofv3 row: form, tile and EPILOGUE
+    (r05 merged `tap:conv:256x128:bias_act` - DownShuffle_1's forward, 67 us - with `...:mask` - the UpShuffle input gradients,
+    141 us - into one "symbol" that no profiler row corresponds to)"""
     t = token.split(":")
     if t[0] == "wgrad":
         return "wgrad256q_kernel" if t[1].startswith("256") else "wgrad_kernel"
     if t[0] == "tap":
-        return f"tapgemm_kernel<{t[1]},{t[2]}>"
-    if t[0] == "deep":
-        return f"deepgemm_kernel<{t[1]}>"
+        return f"tapgemm_kernel<{t[1]},{t[2]},{t[3]}>"
     if t[0] == "halo":
-        return "halo_convT_kernel<head>" if "head" in t else "halo_convT_kernel"
+        return f"halo_convT_kernel<{'head' if 'head' in t else t[2]}>"
     if t[0] == "rgb":
         return f"rgb_{t[1]}_kernel"
     return token
 
 
+def rocprof_pattern(symbol):
+    """substring of the MANGLED kernel name (rocprofv3 --mangled-kernels) that this symbol's launches carry, dtype left out:
+    scripts/compare_bench_rocprof.py joins the bench line with a kernel_stats.csv through it"""
+    if symbol.startswith("tapgemm_kernel<"):
+        form, tile, epi = symbol[len("tapgemm_kernel<"):-1].split(",")
+        bm, bn = tile.split("x")
+        return f"tapgemm_kernelI*Li{_FORM[form]}ELi{bm}ELi{bn}ELi{0 if epi == 'bias_act' else 1}E"
+    if symbol.startswith("halo_convT_kernel<"):
+        return f"halo_convT_kernelI*Li{('bias_act', 'mask', 'head').index(symbol[len('halo_convT_kernel<'):-1])}E"
+    return symbol.split("<")[0] + "I"
+
+
 class KernelTimer:
-    """HIP events on the stream each layer call is launched on; per call: family, kernel symbol (launch log), FLOPs."""
+    """Per layer call of the step: family, kernel symbol (launch log), FLOPs and - through a recorded step plan - timed event records
+    on the stream the call is launched on.  Two phases per leg, driven by the engine's own plan machinery (a step shape is run
+    eagerly once, then recorded and replayed):
+      * the EAGER step of the leg: every layer call runs with the launch log on -> which kernel it selected (no events);
+      * the RECORDING step: `timed record, call, timed record` are appended to the plan instead of a host-side event pair, so a replay
+        is one C call per segment with nothing of the interpreter between an event and its launch."""
 
     FAMILY = {
         "gct2_conv4s2_fwd": "conv_form", "gct2_convT4s2_dgrad": "conv_form",
@@ -108,18 +132,22 @@ class KernelTimer:
     }
 
     def __init__(self):
-        self.events = []      # (family, symbol, flops, start, end) of the steps with two streams: in-situ durations
-        self.isolated = []    # the same from the serial-stream steps run after the timed region (one kernel at a time)
-        self.sink = self.events
-        self.streams = {}     # raw stream handle -> torch stream object
         self.enabled = False
-        self.split_adam = False   # isolated leg: the fused optimizer launch of a weight-gradient call is issued BEHIND the end event
+        self.split_adam = False   # isolated leg: the fused optimizer launch of a weight-gradient call is issued BEHIND the end record
         self.ctxs = {}            # ctx handle -> _lib.Context (launch logs)
+        self.names = []           # eager step: (family, symbol, flops, (layer, direction)) per layer call, in call order
+        self.pairs = []           # recording step: (start record, end record, (layer, direction)) per layer call, in call order
+        self.plan = None          # the _lib.Plan the pairs belong to
+        self.lib = None
+        self.context_source = None
+
+    def reset(self):
+        self.names, self.pairs, self.plan = [], [], None
 
     def install(self, engine_module, lib_module, contexts):
-        import ctypes
         orig = lib_module.call
         timer = self
+        timer.lib = lib_module
         for c in contexts:
             self.ctxs[c.handle] = c
 
@@ -127,51 +155,82 @@ class KernelTimer:
             fam = timer.FAMILY.get(name) if timer.enabled else None
             if fam is None:
                 return orig(name, *args)
-            # events go on the stream the kernel is launched on (the last argument): the weight gradients run on the engine's
-            # side stream, concurrently with the dgrad chain - their durations are the in-situ ones, like rocprofv3's
+            label = call_label(name, args)
+            P = lib_module._recording
+            if P is None:
+                # eager step: the kernel this call selects, from its context's launch log
+                ctx = timer.ctxs.get(args[0])
+                if ctx is None and timer.context_source is not None:      # (contexts the engine created since: the deferred layers')
+                    timer.ctxs.update({c.handle: c for c in timer.context_source()})
+                    ctx = timer.ctxs.get(args[0])
+                if ctx is None:
+                    raise RuntimeError(f"bench.py: {name} was called with a context the timer does not know")
+                ctx.log_launches(True)
+                orig(name, *args)
+                toks = [t for t in ctx.read_launch_log() if not t.startswith(("relu_bits", "bias_queue"))]
+                ctx.log_launches(False)
+                sym = kernel_symbol(toks[0]) if toks else name
+                timer.names.append(("other" if sym.startswith("rgb") else fam, sym, call_flops(name, args), label))
+                return None
+            # recording step: events go on the stream the kernel is launched on (the last argument) - the weight gradients run on the
+            # engine's side stream in the two-stream leg, where their durations are the in-situ ones, like rocprofv3's
+            if timer.plan is None:
+                timer.plan = P
             h = int(args[-1] or 0)
-            st = timer.streams.get(h)
-            if st is None:
-                st = timer.streams[h] = torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream()
-            ctx = timer.ctxs.get(args[0])
             adam = None
             if timer.split_adam and fam == "wgrad" and args[-2]:
-                # the engine's deferral mechanism (gct2_adam_args.defer + gct2_adam_apply: the same launch, the same bits), used here so
-                # that the events bracket the weight-gradient kernel alone
+                # the engine's deferral mechanism (gct2_adam_args.defer + gct2_adam_apply: the same launch, the same bits): the struct is
+                # read when the call is MADE, i.e. at every replay - `defer` stays set (the engine records the struct's inputs after the
+                # recording step and restores them in front of every replayed reverse pass), the optimizer launch follows the end record
                 adam = lib_module.AdamArgs.from_address(int(args[-2]))
                 if adam.defer:
                     adam = None                      # (already deferred by the engine)
                 else:
                     adam.defer = 1
-            if ctx is not None:
-                ctx.log_launches(True)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record(st)
+            e0 = P.record(h, lib_module.EVENT_TIMED)
             orig(name, *args)
-            e.record(st)
+            e1 = P.record(h, lib_module.EVENT_TIMED)
             if adam is not None:
-                adam.defer = 0
                 orig("gct2_adam_apply", int(args[-2]), args[6], 16 * args[11] * args[12], args[-1])
-            toks = [t for t in (ctx.read_launch_log() if ctx is not None else []) if not t.startswith("relu_bits")]
-            if ctx is not None:
-                ctx.log_launches(False)
-            sym = kernel_symbol(toks[0]) if toks else name
-            timer.sink.append(("other" if sym.startswith("rgb") else fam, sym, call_flops(name, args), s, e, call_label(name, args)))
+            timer.pairs.append((e0, e1, label))
+            return None
 
         engine_module.call = timed_call
 
-    @staticmethod
-    def table(events, nsteps, key):
-        tot, cnt, fl = {}, {}, {}
-        for ev in events:
-            k = ev[key]
-            tot[k] = tot.get(k, 0.0) + ev[3].elapsed_time(ev[4]) * 1e-3
-            cnt[k] = cnt.get(k, 0) + 1
-            fl[k] = fl.get(k, 0.0) + ev[2]
-        rows = {k: {"launches_per_step": cnt[k] // nsteps, "ms_per_step": round(tot[k] / nsteps * 1e3, 4),
-                    "gflop_per_launch": round(fl[k] / cnt[k] / 1e9, 3), "avg_launch_us": round(tot[k] / cnt[k] * 1e6, 2),
-                    "tflops": round(fl[k] / tot[k] / 1e12, 2)} for k in tot}
-        return tot, cnt, fl, rows
+    def read(self):
+        """milliseconds of every bracketed call of the LAST replay (the caller synchronised)"""
+        return [self.plan.elapsed_ms(e0, e1) for e0, e1, _ in self.pairs]
+
+
+def median(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def symbol_table(names, samples, key):
+    """names: (family, symbol, flops, label) per call; samples[i] = the call's durations in ms over the measured steps.
+    Per key (0 family, 1 symbol): launches per step, the SUM OF THE CALLS' MEDIANS (robust against a stalled sample), FLOPs,
+    and min / median / max over every sample of every call of the key"""
+    rows = {}
+    for (nm, ms) in zip(names, samples):
+        r = rows.setdefault(nm[key], {"n": 0, "sum_median_ms": 0.0, "flops": 0.0, "all": [], "layers": []})
+        r["n"] += 1
+        r["sum_median_ms"] += median(ms)
+        r["flops"] += nm[2]
+        r["all"] += list(ms)
+        r["layers"].append(f"{nm[3][0]}.{nm[3][1]}")
+    out = {}
+    for k, r in rows.items():
+        t = r["sum_median_ms"] * 1e-3
+        out[k] = {"launches_per_step": r["n"], "ms_per_step": round(r["sum_median_ms"], 4), "gflop_per_launch": round(r["flops"] / r["n"] / 1e9, 3),
+                  "avg_launch_us": round(r["sum_median_ms"] / r["n"] * 1e3, 2), "min_us": round(min(r["all"]) * 1e3, 2),
+                  "median_us": round(median(r["all"]) * 1e3, 2), "max_us": round(max(r["all"]) * 1e3, 2),
+                  "tflops": round(r["flops"] / t / 1e12, 2) if t > 0 else None}
+        if key == 1:
+            out[k]["layers"] = sorted(r["layers"])
+            out[k]["rocprof_mangled"] = rocprof_pattern(k)
+    return rows, out
 
 
 def pmc_evidence(layers, default_config):
@@ -306,6 +365,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--event-steps", type=int, default=8, help="measured steps of the per-kernel (roofline) leg; per call the median is reported")
     ap.add_argument("--variant", type=int, default=0, help="tapgemm tile variant hook (0 auto, 2, 3): A/B timing only")
     ap.add_argument("--no-plan", action="store_true", help="run every step through the interpreter (no recorded step plan): A/B of the host side")
     ap.add_argument("--serial-streams", action="store_true",
@@ -364,6 +424,7 @@ def main():
     timer = KernelTimer()
     if not args.no_kernel_events:
         timer.install(engine_mod, _lib, [eng.ctx, eng.ctx_tail])
+        timer.context_source = lambda: [eng.ctx, eng.ctx_tail, *eng._defer_ctxs.values()]
 
     def barrier():
         if world > 1:
@@ -382,31 +443,61 @@ def main():
     host_dt = time.perf_counter() - t0                 # host time to enqueue the K steps (the GPU is still running)
     barrier()
     dt = time.perf_counter() - t0
-    # in-situ leg: the step as timed (two streams), with events: what a launch takes while it shares the chip with the other stream
-    ev_steps = 0
-    plan0, eng.use_plan = eng.use_plan, False       # the event legs intercept every C-ABI call: they run the step eagerly (same calls)
-    if not args.no_kernel_events:
-        timer.enabled = True
-        for _ in range(4):
-            dp.train_step(x)
-            ev_steps += 1
+    # ---- per-kernel legs: extra steps AFTER the timed region, replayed from step plans that carry timed event records ---------------
+    def event_leg(overlap, split_adam, nsamples):
+        """one eager step (which kernel every layer call selects), one recording step, then `nsamples` x (an unmeasured replay + a
+        measured replay enqueued right behind it, one synchronisation, the measured replay's event pairs read back).  Returns
+        (names, samples) with samples[i] = the durations of call i in ms."""
+        import gc
+        overlap0, plan0 = eng.overlap, eng.use_plan
         barrier()
-        timer.enabled = False
-    # roofline leg: the same step with ONE stream, so that every MFMA launch has the chip to itself and its HIP-event duration
-    # is the kernel's own (with two streams a launch shares the CUs with whatever the other stream is running)
-    iso_steps = 0
+        eng._plans.clear(); eng._plan_seen.clear()           # the timed region's plan has no timed records: record this leg's own
+        eng.overlap, eng.use_plan = overlap, True
+        timer.reset()
+        timer.enabled, timer.split_adam = True, split_adam
+        gc.collect(); gc.disable()
+        try:
+            # eager steps (each names its layer calls afresh) until the engine records one: a step shape is recorded the
+            # `plan_after`-th time it is seen, and the two-stream step changes shape once (its first step starts without deferred
+            # optimizer launches); the recording step appends the timed records and is replayed at once
+            for _ in range(2 * eng.plan_after + 2):
+                if timer.plan is not None:
+                    break
+                keep = timer.names
+                timer.names = []
+                dp.train_step(x)
+                if timer.plan is not None:
+                    timer.names = keep                        # (the recording step names nothing)
+            if timer.plan is None or [n[3] for n in timer.names] != [p_[2] for p_ in timer.pairs]:
+                raise RuntimeError("bench.py: the recorded step's layer calls do not match the eager step's "
+                                   f"({len(timer.names)} named, {len(timer.pairs)} bracketed)")
+            barrier()
+            samples = [[] for _ in timer.pairs]
+            for _ in range(nsamples):
+                dp.train_step(x)                              # keeps the GPU busy while the host enqueues the measured step
+                dp.train_step(x)
+                barrier()
+                for i, ms in enumerate(timer.read()):
+                    samples[i].append(ms)
+        finally:
+            gc.enable()
+            timer.enabled, timer.split_adam = False, False
+            eng.flush_deferred()
+            barrier()
+            eng._plans.clear(); eng._plan_seen.clear()       # (these plans bake the leg's deferral of the optimizer launches)
+            eng.overlap, eng.use_plan = overlap0, plan0
+        return list(timer.names), samples
+
+    situ = iso = None
     if not args.no_kernel_events:
-        overlap0, eng.overlap = eng.overlap, False
-        # the fused optimizer launch of every weight-gradient call is issued behind the call's end event (KernelTimer.split_adam): the
-        # events bracket the GEMM kernel (+ its helper launches where the call has any), never the optimizer
-        timer.sink, timer.enabled, timer.split_adam = timer.isolated, True, True
-        for _ in range(4):
-            dp.train_step(x)
-            iso_steps += 1
-        eng.flush_deferred()
-        barrier()
-        timer.enabled, timer.split_adam, eng.overlap = False, False, overlap0
-    eng.use_plan = plan0
+        # in-situ leg: the step as timed (two streams): what a call takes while it shares the chip with the other stream's kernels (a
+        # weight-gradient call includes its fused optimizer launch)
+        if eng.overlap:
+            situ = event_leg(True, False, 4)
+        # roofline leg: the same step on ONE stream, so that every launch has the chip to itself and its event-pair duration is the
+        # kernel's own (+ the helper launches of calls that have any: split-K finalize); the fused optimizer launch of every
+        # weight-gradient call is issued behind the call's end record (KernelTimer.split_adam)
+        iso = event_leg(False, True, args.event_steps)
     comm = None
     if world > 1:
         # evidence of what RCCL ran (rank 0): ranks it saw, the buckets of one extra step and the HIP-event time of every collective
@@ -449,28 +540,40 @@ def main():
             "step_roofline_frac": round(imgs / world * f_img / MFMA_PEAK, 5),
         }
         out["roofline"] = {"bound": "mfma", "step_frac": out["step_roofline_frac"], "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s"}
-        if timer.isolated:
-            _, _, _, fams = timer.table(timer.isolated, iso_steps, 0)
-            tot, cnt, fl, syms = timer.table(timer.isolated, iso_steps, 1)
-            dom = max(tot, key=tot.get)                       # the kernel symbol with the largest summed time
-            achieved = fl[dom] / tot[dom] / 1e12              # its own algorithmic FLOPs / its own summed HIP-event time
+        if iso is not None:
+            names, samples = iso
+            _, fams = symbol_table(names, samples, 0)
+            rows, syms = symbol_table(names, samples, 1)
+            dom = max(rows, key=lambda k: rows[k]["sum_median_ms"])        # the kernel symbol with the largest sum of per-call medians
+            r = rows[dom]
+            achieved = r["flops"] / (r["sum_median_ms"] * 1e-3) / 1e12        # its algorithmic FLOPs / its time, per step
             # traffic / mfma_util are NOT measured in this run: they come from the committed rocprofv3 --pmc passes over the ENGINE'S
             # OWN launches (scripts/engine_layers.py --pmc, scripts/collect_engine_pmc.py, scripts/profile_round.sh), default config
             # only, summed over the layers whose calls selected the dominant kernel; the *_source fields say so.
-            dom_layers = sorted({ev[5] for ev in timer.isolated if ev[1] == dom})
+            dom_layers = sorted({nm[3] for nm in names if nm[1] == dom})
             traffic, traffic_source, mfma_util, mfma_source = pmc_evidence(set(dom_layers), (S, B, args.dtype, world) == (128, 64, "bf16", 1))
+            # cross-checks: no kernel can take more of the one-stream step than the step (the timed two-stream step is at most ~10 %
+            # shorter than the one-stream one); a sample far from its call's median is reported, never averaged in
+            step_ms = dt / args.steps * 1e3
+            outliers = [{"call": f"{nm[3][0]}.{nm[3][1]}", "symbol": nm[1], "median_us": round(median(ms) * 1e3, 2), "sample_us": round(max(ms) * 1e3, 2)}
+                        for nm, ms in zip(names, samples) if max(ms) > 1.5 * median(ms) + 0.01]
+            suspect = r["sum_median_ms"] > 1.2 * step_ms or sum(v["sum_median_ms"] for v in rows.values()) > 1.5 * step_ms
             out["roofline"].update({
                 "kernel": dom, "kernel_layers": [f"{l}.{d}" for l, d in dom_layers], "achieved": round(achieved, 2), "frac": round(achieved * 1e12 / MFMA_PEAK, 5),
                 "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_source,
                 "mfma_util": None if mfma_util is None else round(mfma_util, 4), "mfma_util_source": mfma_source,
-                "flops_per_launch": fl[dom] / cnt[dom], "launches_per_step": cnt[dom] // iso_steps, "event_steps": iso_steps,
-                "avg_launch_us": round(tot[dom] / cnt[dom] * 1e6, 2),
-                "mode": "one stream (4 extra steps after the timed region): isolated launch durations, HIP events on the launching stream; "
-                        "the kernel of every call from the library's launch log; weight-gradient calls without their optimizer launch"})
+                "flops_per_launch": r["flops"] / r["n"], "launches_per_step": r["n"], "event_steps": len(samples[0]),
+                "avg_launch_us": round(r["sum_median_ms"] / r["n"] * 1e3, 2), "min_us": syms[dom]["min_us"], "median_us": syms[dom]["median_us"],
+                "max_us": syms[dom]["max_us"], "kernel_ms_per_step": round(r["sum_median_ms"], 4), "rocprof_mangled": rocprof_pattern(dom),
+                "suspect": bool(suspect), "outlier_samples": outliers[:8],
+                "mode": f"one stream, {len(samples[0])} extra steps after the timed region, each REPLAYED from a recorded step plan right behind an unmeasured "
+                        "replay (the GPU never waits for the host); timed event records on the launching stream around every layer call; per call the "
+                        "MEDIAN over the steps, per symbol the sum of its calls' medians; the kernel of every call from the library's launch log; "
+                        "weight-gradient calls without their optimizer launch"})
             out["kernel_symbols"] = syms
             out["kernels"] = fams
-            if timer.events:   # the same calls inside the two-stream step: a launch shares the chip with the other stream's, and each
-                out["kernels_two_streams"] = timer.table(timer.events, ev_steps, 0)[3]      # wgrad call carries its fused Adam launch
+            if situ is not None:   # the same calls inside the two-stream step: a launch shares the chip with the other stream's, and each
+                out["kernels_two_streams"] = symbol_table(situ[0], situ[1], 0)[1]      # wgrad call carries its fused Adam launch
         if world == 1 and not args.no_cpu_baseline:
             kw = dict(pixel_size=128, max_size=512)
             v3, s3, n3 = cpu_baseline(dict(octaves=6, **kw), S, 4, 100, 1, budget_s=12.0)   # ~12 s of CPU work

@@ -11,7 +11,7 @@ import struct
 
 F32, BF16, F16 = 0, 1, 2
 DTYPE_NAMES = {F32: "f32", BF16: "bf16", F16: "f16"}
-ABI_VERSION = 16
+ABI_VERSION = 17
 # gct2_diffusion_update modes (include/gct2.h; the sampler's objective switches, train.py:29-32)
 SAMPLE_X, SAMPLE_EPS, SAMPLE_SCALED_EPS, SAMPLE_ODE = 0, 1, 2, 3
 BUILD_STAMP = 1
@@ -94,6 +94,8 @@ SIGNATURES = {
     "gct2_plan_add_call": [_vp, C.c_char_p, C.POINTER(C.c_uint64), _i, C.POINTER(C.c_int)],
     "gct2_plan_add_record": [_vp, _vp, C.POINTER(C.c_int)],
     "gct2_plan_add_wait": [_vp, _vp, _i],
+    "gct2_plan_add_record_kind": [_vp, _vp, _i, C.POINTER(C.c_int)],
+    "gct2_plan_elapsed": [_vp, _i, _i, C.POINTER(C.c_float)],
     "gct2_plan_size": [_vp, C.POINTER(C.c_int)],
     "gct2_plan_set_arg": [_vp, _i, _i, _u64],
     "gct2_plan_run": [_vp, _i, _i, C.POINTER(C.c_int)],
@@ -181,6 +183,9 @@ def _slot_bits(ctype, v) -> int:
     return int(v) & 0xFFFFFFFFFFFFFFFF
 
 
+EVENT_DEVICE, EVENT_SYSTEM, EVENT_TIMED = 0, 1, 2        # include/gct2.h GCT2_EVENT_*
+
+
 class Plan:
     """gct2_plan (include/gct2.h): a recorded list of entry-point calls, event records and stream waits that one C call replays.
 
@@ -234,11 +239,19 @@ class Plan:
         check(load().gct2_plan_add_call(self.handle, name.encode(), arr, len(args), C.byref(idx)), "gct2_plan_add_call")
         self.n = idx.value + 1
 
-    def record(self, stream: int) -> int:
+    def record(self, stream: int, kind: int = EVENT_DEVICE) -> int:
+        """appends "record a new event on `stream`"; kind: EVENT_DEVICE (ordering inside the device), EVENT_SYSTEM (the waiter hands the
+        data to another device: the communication stream of the data-parallel exchange), EVENT_TIMED (elapsed_ms)"""
         ev = C.c_int(-1)
-        check(load().gct2_plan_add_record(self.handle, stream, C.byref(ev)), "gct2_plan_add_record")
+        check(load().gct2_plan_add_record_kind(self.handle, stream, kind, C.byref(ev)), "gct2_plan_add_record_kind")
         self.n += 1
         return ev.value
+
+    def elapsed_ms(self, start: int, end: int) -> float:
+        """milliseconds between two EVENT_TIMED records of the last run (both completed: synchronise first)"""
+        ms = C.c_float(0.0)
+        check(load().gct2_plan_elapsed(self.handle, start, end, C.byref(ms)), "gct2_plan_elapsed")
+        return ms.value
 
     def wait(self, stream: int, event: int) -> None:
         check(load().gct2_plan_add_wait(self.handle, stream, event), "gct2_plan_add_wait")

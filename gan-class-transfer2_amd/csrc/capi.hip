@@ -136,7 +136,10 @@ int run_dgrad(gct2_ctx& c, int dtype, int form, TapGemmParams p, size_t out_pixe
   p.db = db; p.db_split = split; p.db2 = db2; p.db_acc = db_acc;
   if (!c.force_direct && tapgemm_mfma_supported(dtype, p)) return tapgemm_mfma(c, dtype, form, EPI_MASK, p, S(stream));
   gct2_log(c, "direct:tap");
-  zero_overwritten_db(p, S(stream));        // the column-sum kernels below add with atomics
+  // the column-sum kernels below add with atomics, at once: row sets queued for the same targets are reduced first (a queued
+  // overwrite would otherwise run behind this call's add and erase it)
+  if (int e = tapgemm_dbq_flush_for(c, db, split, db2, p.N - split, S(stream))) return e;
+  zero_overwritten_db(p, S(stream));
   const size_t es = esize(dtype);
   auto sums = [&](float sign) -> int {
     if (db && split > 0) if (int e = pw_colsum(dtype, p.y, p.ldy, db, out_pixels, split, sign, S(stream))) return e;
@@ -155,7 +158,8 @@ int run_wgrad(gct2_ctx& c, int dtype, const WgradParams& p, void* stream, WgradS
   return wgrad_direct(dtype, p, S(stream));
 }
 // bias gradient of a weight-gradient call: db (+)= column sums of dz (atomics: an overwritten target starts from zero)
-int wgrad_db(int dtype, const void* dz, int lddz, float* db, size_t pixels, int Cout, int accumulate, void* stream) {
+int wgrad_db(gct2_ctx& c, int dtype, const void* dz, int lddz, float* db, size_t pixels, int Cout, int accumulate, void* stream) {
+  if (int e = tapgemm_dbq_flush_for(c, db, Cout, nullptr, 0, S(stream))) return e;      // (an immediate writer: queued row sets of db go first)
   if (!accumulate) (void)hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), S(stream));
   return pw_colsum(dtype, dz, lddz, db, pixels, Cout, 1.f, S(stream));
 }
@@ -181,7 +185,7 @@ int adam_after_wgrad(gct2_adam_args* a, float* dw, size_t nw, const WgradSlabs& 
 
 extern "C" {
 
-int gct2_abi_version(void) { return 16; }
+int gct2_abi_version(void) { return 17; }
 int gct2_build_flags(void) {
 #ifdef GCT2_STAMP
   return GCT2_BUILD_STAMP;
@@ -343,7 +347,7 @@ int gct2_conv4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const v
     if (int e = rgb_wgrad(c, dtype, p, S(stream), adam ? &sl : nullptr)) return e;
   } else if (int e = run_wgrad(c, dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)
-    if (int e = wgrad_db(dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, accumulate, stream)) return e;
+    if (int e = wgrad_db(c, dtype, dz, lddz, db, (size_t)B * (H / 2) * (W / 2), Cout, accumulate, stream)) return e;
   if (adam) return adam_after_wgrad(adam, dw, (size_t)16 * Cin * Cout, sl, stream);
   return GCT2_OK;
 }
@@ -406,7 +410,7 @@ int gct2_convT4s2_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const 
   if (adam) if (int e = check_adam_args(adam, dw, (size_t)16 * Cin * Cout)) return e;
   if (int e = run_wgrad(c, dtype, p, stream, adam ? &sl : nullptr)) return e;
   if (db)
-    if (int e = wgrad_db(dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, accumulate, stream)) return e;
+    if (int e = wgrad_db(c, dtype, dz, lddz, db, (size_t)B * (2 * H) * (2 * W), Cout, accumulate, stream)) return e;
   if (adam) return adam_after_wgrad(adam, dw, (size_t)16 * Cin * Cout, sl, stream);
   return GCT2_OK;
 }
@@ -455,7 +459,7 @@ int gct2_conv2d_s1_wgrad(gct2_ctx* ctx, int dtype, const void* x, int ldx, const
   if (!c.force_direct && wgrad_mfma_supported(dtype, p)) {
     if (int e = wgrad_mfma(c, dtype, p, S(stream), nullptr)) return e;
   } else if (int e = conv_s1_wgrad_direct(dtype, x, ldx, dz, lddz, dw, B, H, W, Cin, Cout, KS, accumulate, S(stream))) return e;
-  if (db) return wgrad_db(dtype, dz, lddz, db, (size_t)B * H * W, Cout, accumulate, stream);
+  if (db) return wgrad_db(c, dtype, dz, lddz, db, (size_t)B * H * W, Cout, accumulate, stream);
   return GCT2_OK;
 }
 int gct2_relu_mask(int dtype, const void* act, int ldact, void* d, int ldd, size_t npix, int C, void* stream) {

@@ -336,6 +336,7 @@ __device__ __forceinline__ bool xcd_tile(int id, int m_tiles, int inner, int chu
 // bias queue of a call context (tapgemm_mfma.hip): record the partial rows a launch left in the queue buffer / reduce everything recorded
 int tapgemm_dbq_push(gct2_ctx& c, const float* part, int rows, const TapGemmParams& p, hipStream_t s);
 int tapgemm_dbq_flush(gct2_ctx& c, hipStream_t s);
+int tapgemm_dbq_flush_for(gct2_ctx& c, const float* db, int n0, const float* db2, int n1, hipStream_t s);   // in front of an immediate writer
 inline void zero_overwritten_db(const TapGemmParams& p, hipStream_t s) {
   if (p.db && !(p.db_acc & 1) && p.db_split > 0) (void)hipMemsetAsync(p.db, 0, (size_t)p.db_split * sizeof(float), s);
   if (p.db2 && !(p.db_acc & 2) && p.N > p.db_split) (void)hipMemsetAsync(p.db2, 0, (size_t)(p.N - p.db_split) * sizeof(float), s);

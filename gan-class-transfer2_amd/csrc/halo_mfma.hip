@@ -682,7 +682,10 @@ int halo_convT(gct2_ctx& c, int dtype, int epi, TapGemmParams p, hipStream_t s) 
       if (queued) p.dbws = queued;
       else if (int e = tapgemm_dbq_flush(c, s)) return e;
     }
-    if (!p.dbws) zero_overwritten_db(p, s);
+    if (!p.dbws) {                                 // atomics, at once: queued row sets of these targets go first
+      if (int e = tapgemm_dbq_flush_for(c, p.db, p.db_split, p.db2, p.N - p.db_split, s)) return e;
+      zero_overwritten_db(p, s);
+    }
   }
 #ifdef GCT2_STAMP
   p.stamps = c.stamps;

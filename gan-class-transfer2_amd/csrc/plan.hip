@@ -56,6 +56,7 @@ struct Op {
 struct gct2_plan {
   std::vector<Op> ops;
   std::vector<hipEvent_t> events;
+  std::vector<char> timed;       // per event: created with timing (GCT2_EVENT_TIMED)
 };
 
 extern "C" {
@@ -90,21 +91,41 @@ int gct2_plan_add_call(gct2_plan* plan, const char* name, const uint64_t* args, 
   return gct2_fail(GCT2_EINVAL, "plan_add_call: %s is not an entry point a plan can hold", name);
 }
 
-int gct2_plan_add_record(gct2_plan* plan, void* stream, int* event) {
+int gct2_plan_add_record_kind(gct2_plan* plan, void* stream, int kind, int* event) {
   if (!plan || !event) return gct2_fail(GCT2_EINVAL, "plan_add_record: null pointer");
+  if (kind < GCT2_EVENT_DEVICE || kind > GCT2_EVENT_TIMED) return gct2_fail(GCT2_EINVAL, "plan_add_record: unknown event kind %d", kind);
   hipEvent_t ev;
-  // ordering inside one device only: no timing, device-scope release (the default is a system-scope fence per record)
-  unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
-  if (const char* e = getenv("GCT2_PLAN_EVENT_FLAGS")) flags = (unsigned)strtoul(e, nullptr, 0);      // diagnostics: A/B of the release scope
+  // GCT2_EVENT_DEVICE: ordering inside one device only - no timing, device-scope release (the default is a system-scope fence per
+  // record); GCT2_EVENT_SYSTEM: no timing, the runtime's default (system-scope) release - for a record whose waiter hands the data to
+  // another device (the stream an RCCL collective is issued on); GCT2_EVENT_TIMED: a timing event (gct2_plan_elapsed)
+  unsigned flags = kind == GCT2_EVENT_DEVICE ? (hipEventDisableTiming | hipEventReleaseToDevice) : kind == GCT2_EVENT_SYSTEM ? hipEventDisableTiming : hipEventDefault;
+  if (kind == GCT2_EVENT_DEVICE)
+    if (const char* e = getenv("GCT2_PLAN_EVENT_FLAGS")) flags = (unsigned)strtoul(e, nullptr, 0);      // diagnostics: A/B of the release scope
   if (hipEventCreateWithFlags(&ev, flags) != hipSuccess) {
     (void)hipGetLastError();
     return gct2_fail(GCT2_ELAUNCH, "plan_add_record: hipEventCreateWithFlags failed");
   }
   plan->events.push_back(ev);
+  plan->timed.push_back(kind == GCT2_EVENT_TIMED);
   Op op{};
   op.kind = OP_RECORD; op.entry = -1; op.nargs = 0; op.event = (int)plan->events.size() - 1; op.stream = reinterpret_cast<hipStream_t>(stream);
   plan->ops.push_back(op);
   *event = op.event;
+  return GCT2_OK;
+}
+
+int gct2_plan_add_record(gct2_plan* plan, void* stream, int* event) { return gct2_plan_add_record_kind(plan, stream, GCT2_EVENT_DEVICE, event); }
+
+int gct2_plan_elapsed(gct2_plan* plan, int start, int end, float* ms) {
+  if (!plan || !ms) return gct2_fail(GCT2_EINVAL, "plan_elapsed: null pointer");
+  const int n = (int)plan->events.size();
+  if (start < 0 || start >= n || end < 0 || end >= n || !plan->timed[start] || !plan->timed[end])
+    return gct2_fail(GCT2_EINVAL, "plan_elapsed: events %d / %d are not timed records of this plan", start, end);
+  // both events must have completed (the caller synchronised the device or the streams behind the run)
+  if (hipEventElapsedTime(ms, plan->events[start], plan->events[end]) != hipSuccess) {
+    (void)hipGetLastError();
+    return gct2_fail(GCT2_ELAUNCH, "plan_elapsed: hipEventElapsedTime failed (events not recorded yet, or still pending)");
+  }
   return GCT2_OK;
 }
 

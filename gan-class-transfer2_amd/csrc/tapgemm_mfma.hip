@@ -619,7 +619,7 @@ __global__ __launch_bounds__(1024) void dbpart_reduce_multi_kernel(const DbJobs 
 
 // sums the split-K slabs and applies the epilogue the GEMM kernel skipped.  Work-group = 8 pixels x 128 channels,
 // thread = 4 channels of one pixel (split-K layers have few pixels: keep the grid wide), and the bias-gradient
-// column sums of the 8 pixels are reduced in LDS into one partial row for dbpart_reduce_kernel.
+// column sums of the 8 pixels meet inside a wave (three xor-shuffles, no LDS) as one partial row for dbpart_reduce_kernel / the bias queue.
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void tapgemm_finalize_kernel(TapGemmParams p, size_t npix) {
   const int N = p.N;
@@ -757,7 +757,10 @@ int launch(gct2_ctx& c, TapGemmParams p, hipStream_t s) {
   float* queued = (db_rows && c.dbq) ? c.dbq_alloc((p.ksplit > 1 ? fin_rows : (size_t)p.m_tiles * PH) * p.N) : nullptr;   // (the rows this launch really leaves)
   if (queued) p.dbws = queued;
   else if (db_rows && c.dbq) { if (int e = tapgemm_dbq_flush(c, s)) return e; }
-  if (want_db && !p.dbws) zero_overwritten_db(p, s);
+  if (want_db && !p.dbws) {                  // the epilogue adds with atomics, at once: queued row sets of these targets go first
+    if (int e = tapgemm_dbq_flush_for(c, p.db, p.db_split, p.db2, p.N - p.db_split, s)) return e;
+    zero_overwritten_db(p, s);
+  }
   gct2_log(c, "tap:%s:%dx%d:%s:ksplit=%d%s%s", FORM == FORM_CONV ? "conv" : FORM == FORM_CONVT ? "convT" : "s1", BM, BN,
            EPI == EPI_BIAS_ACT ? "bias_act" : "mask", p.ksplit, p.wstat ? ":wstat" : "", (p.bits && p.wide && p.ksplit == 1) ? ":bits" : "");
   hipLaunchKernelGGL(kern, grid, dim3((BM / 64) * (BN / 64) * 64), 0, s, p);
@@ -847,24 +850,43 @@ int tapgemm_dbq_flush(gct2_ctx& c, hipStream_t s) {
   }
   return gct2_check_launch("bias_queue_flush");
 }
-int tapgemm_dbq_push(gct2_ctx& c, const float* part, int rows, const TapGemmParams& p, hipStream_t s) {
-  // two jobs that ADD to one target would race inside the second launch: reduce what is queued before recording the second of them
+namespace {
+inline bool dbq_overlap(const float* x, int nx, const float* y, int ny) { return x && y && nx > 0 && ny > 0 && x < y + ny && y < x + nx; }
+}
+// An IMMEDIATE writer of bias gradients (direct kernels, the atomics epilogues taken without room for partial rows, a weight-gradient
+// call's db) is about to touch [db, db + n0) / [db2, db2 + n1): row sets queued for the same targets are reduced first, in program
+// order - otherwise a queued OVERWRITE would run behind this call's add and erase it.  No overlap: nothing happens.
+int tapgemm_dbq_flush_for(gct2_ctx& c, const float* db, int n0, const float* db2, int n1, hipStream_t s) {
   for (const gct2_ctx::DbJob& j : c.dbq_jobs) {
-    const bool a0 = (p.db_acc & 1) && p.db && p.db_split > 0, a1 = (p.db_acc & 2) && p.db2 && p.db_split < p.N;
-    const bool b0 = (j.db_acc & 1) && j.db && j.db_split > 0, b1 = (j.db_acc & 2) && j.db2 && j.db_split < j.N;
-    auto overlap = [](const float* x, int nx, const float* y, int ny) { return x < y + ny && y < x + nx; };
-    bool clash = false;
-    if (a0 && b0) clash |= overlap(p.db, p.db_split, j.db, j.db_split);
-    if (a0 && b1) clash |= overlap(p.db, p.db_split, j.db2, j.N - j.db_split);
-    if (a1 && b0) clash |= overlap(p.db2, p.N - p.db_split, j.db, j.db_split);
-    if (a1 && b1) clash |= overlap(p.db2, p.N - p.db_split, j.db2, j.N - j.db_split);
-    if (clash) {
-      // (the rows of THIS job are already in the queue buffer: keep them valid across the flush by flushing the jobs only)
-      const size_t used = c.dbq_used;
-      if (int e = tapgemm_dbq_flush(c, s)) return e;
-      c.dbq_used = used;
-      break;
-    }
+    const float* jt[2] = {j.db_split > 0 ? j.db : nullptr, j.db_split < j.N ? j.db2 : nullptr};
+    const int jn[2] = {j.db_split, j.N - j.db_split};
+    for (int k = 0; k < 2; k++)
+      if (dbq_overlap(db, n0, jt[k], jn[k]) || dbq_overlap(db2, n1, jt[k], jn[k])) return tapgemm_dbq_flush(c, s);
+  }
+  return GCT2_OK;
+}
+int tapgemm_dbq_push(gct2_ctx& c, const float* part, int rows, const TapGemmParams& p, hipStream_t s) {
+  // The flush runs every overwriting target first and every adding target second, so per target only the order "one queued
+  // OVERWRITE, then one ADD" survives being queued together.  Everything else that meets a queued job on the same target - a second
+  // add (two adders would race inside the second launch), a second overwrite (a race inside the first), an overwrite behind a queued
+  // add (would be reordered in front of it) - reduces what is queued before this job is recorded.
+  const float* pt[2] = {p.db_split > 0 ? p.db : nullptr, p.db_split < p.N ? p.db2 : nullptr};
+  const int pn[2] = {p.db_split, p.N - p.db_split};
+  const bool padd[2] = {(p.db_acc & 1) != 0, (p.db_acc & 2) != 0};
+  bool clash = false;
+  for (const gct2_ctx::DbJob& j : c.dbq_jobs) {
+    const float* jt[2] = {j.db_split > 0 ? j.db : nullptr, j.db_split < j.N ? j.db2 : nullptr};
+    const int jn[2] = {j.db_split, j.N - j.db_split};
+    const bool jadd[2] = {(j.db_acc & 1) != 0, (j.db_acc & 2) != 0};
+    for (int a = 0; a < 2; a++)
+      for (int b = 0; b < 2; b++)
+        if (dbq_overlap(pt[a], pn[a], jt[b], jn[b]) && !(padd[a] && !jadd[b])) clash = true;
+  }
+  if (clash) {
+    // (the rows of THIS job are already in the queue buffer: keep them valid across the flush by flushing the jobs only)
+    const size_t used = c.dbq_used;
+    if (int e = tapgemm_dbq_flush(c, s)) return e;
+    c.dbq_used = used;
   }
   c.dbq_jobs.push_back(gct2_ctx::DbJob{part, rows, p.N, p.db, p.db_split, p.db2, p.db_acc});
   return GCT2_OK;

@@ -33,10 +33,12 @@ class _Plumbing:
     def __init__(self, engine=None):
         self.engine = engine
 
-    def stream_waits(self, waiter, other) -> None:
+    def stream_waits(self, waiter, other, to_comm: bool = False) -> None:
+        """to_comm: `waiter` is the communication stream - what it waits for is read by a collective and leaves the device, so a
+        recorded event releases at system scope (the step's own stream-to-stream waits keep device scope)"""
         f = getattr(self.engine, "_wait_stream", None)
         if f is not None:
-            f(waiter, other)
+            f(waiter, other, to_comm)
         else:
             ev = torch.cuda.Event()
             ev.record(other)
@@ -94,16 +96,18 @@ class BucketedAllReducer:
             # the communication stream waits for the gradients, then carries the collective: a stream-synchronous call (the
             # communication stream is blocked until the sum is there, the host is not), so whatever is enqueued on that stream behind
             # it - the bucket's optimizer step - is ordered without a work handle
-            self.pl.stream_waits(self.comm_stream, torch.cuda.current_stream(self.flat.device))
+            self.pl.stream_waits(self.comm_stream, torch.cuda.current_stream(self.flat.device), to_comm=True)
             self.pl.host_call(lambda idx=idx: self._issue(idx))
         else:
             self.works[idx] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.launched += 1
+            self.launched += 1
 
     def _issue(self, idx: int) -> None:
+        """(runs at every step, recorded or replayed: `launched` counts the collectives really issued)"""
         lo, hi = self.buckets[idx]
         with torch.cuda.stream(self.comm_stream):
             dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        self.launched += 1
 
     def wait_bucket(self, idx: int) -> Tuple[int, int]:
         """block the CURRENT stream (not the host, on a GPU) until bucket idx holds the global sum."""
@@ -146,6 +150,7 @@ class DataParallelStep:
         engine.grad_ready_hook = self._grad_ready
         engine.hook_plan_aware = True          # the hook below does its plumbing through the engine: recorded with the step
         engine.post_backward = self._tail
+        engine.post_replay = self._after_replay
         self.world = self.reducer.world
         self._adam_next = 0            # first bucket whose update has not been enqueued in this step
         _one_stream_less(engine, self.reducer.exchange)
@@ -183,11 +188,18 @@ class DataParallelStep:
             self._tail()                                         # (an engine without the post_backward hook: the tests' CPU stand-in)
         return loss
 
+    def _after_replay(self) -> None:
+        """UNetEngine.post_replay: the hooks and _tail only run while a step is RECORDED; a replayed step ran the same launches, so
+        the wrapper's counters go where a full step leaves them (reducer.launched is counted by _issue itself)"""
+        self._adam_next = len(self.reducer.buckets) if self.engine.ls_state is None and self.reducer.on_cuda else 0
+        self._tail_done = True
+
     def _tail(self) -> None:
         """what follows the reverse pass: the updates of the buckets still open, the caller's stream joins the communication stream,
         the step counter - part of the step body (UNetEngine.post_backward), so a step plan records it"""
         eng, red = self.engine, self.reducer
         self._tail_done = True
+        assert not red.exchange or not red.on_cuda or _recording_plan() or red.launched == len(red.buckets), (red.launched, len(red.buckets))
         if eng.ls_state is not None:
             # fp16 + dynamic loss scale (train.py:82-83): an inf/nan on ANY rank survives the SUM all-reduce, so the
             # finite check of the reduced arena gives every rank the same skip decision without a second collective
@@ -260,6 +272,7 @@ class ShardedDataParallelStep:
         engine.grad_ready_hook = self._grad_ready
         engine.hook_plan_aware = True          # the hook does its plumbing through the engine: recorded with the step
         engine.post_backward = self._tail
+        engine.post_replay = self._after_replay
         _one_stream_less(engine, self.exchange)
         self.events: List[Tuple[int, object, object]] = []      # (bucket, start, end) of the collectives when timing is on
         self.time_collectives = False
@@ -292,7 +305,7 @@ class ShardedDataParallelStep:
 
     def _comm_waits_current(self) -> None:
         if self.on_cuda:
-            self.pl.stream_waits(self.comm_stream, torch.cuda.current_stream(self.engine.device))
+            self.pl.stream_waits(self.comm_stream, torch.cuda.current_stream(self.engine.device), to_comm=True)
 
     def _timed(self, k: int, fn) -> None:
         if self.time_collectives and self.on_cuda:
@@ -306,10 +319,11 @@ class ShardedDataParallelStep:
 
     def _reduce_scatter(self, k: int) -> None:
         self.pl.host_call(lambda k=k: self._issue_reduce(k))
-        self.launched += 1
 
     def _issue_reduce(self, k: int) -> None:
-        """the bucket's gradient exchange on the communication stream (stream-synchronous: what is enqueued there behind it is ordered)"""
+        """the bucket's gradient exchange on the communication stream (stream-synchronous: what is enqueued there behind it is ordered).
+        Runs at every step, recorded or replayed: `launched` counts the exchanges really issued."""
+        self.launched += 1
         g = self.engine.arena.g
         lo, hi = self.buckets[k]
         slo, shi = self.shard(k)
@@ -375,6 +389,13 @@ class ShardedDataParallelStep:
         eng._masters_sharded = True
         return loss
 
+    def _after_replay(self) -> None:
+        """UNetEngine.post_replay: the hooks and _tail only run while a step is RECORDED; a replayed step issued the same exchanges
+        (counted by _issue_reduce), so the bucket cursors go where a full step leaves them"""
+        self.next_rs = self.next_opt = len(self.buckets)
+        self._tail_done = True
+        assert self.launched == len(self.buckets), (self.launched, len(self.buckets))
+
     def _tail(self) -> None:
         """what follows the reverse pass - part of the step body (UNetEngine.post_backward), so a step plan records it"""
         eng = self.engine
@@ -429,6 +450,15 @@ class ShardedDataParallelStep:
 
     def collective_times_ms(self) -> List[Tuple[int, float]]:
         return [(k, s.elapsed_time(e)) for k, s, e in self.events]
+
+
+def _recording_plan() -> bool:
+    """True while a step plan is being recorded (the collectives of that step are issued by the replay that follows)"""
+    try:
+        from . import _lib
+    except ImportError:            # (the CPU tests import this module on its own)
+        return False
+    return _lib._recording is not None
 
 
 class _NullCtx:

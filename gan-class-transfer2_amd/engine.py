@@ -324,6 +324,9 @@ class UNetEngine:
         # (remaining bucket updates, joining the communication stream, finish_step)
         self.post_backward: Optional[Callable[[], None]] = None
         self.post_backward_ran = False
+        # called at the end of every REPLAYED step: a plan-aware wrapper's Python state (bucket counters) is advanced by its hooks, which
+        # only run while a step is being recorded - it puts that state where a full step leaves it (distributed.py)
+        self.post_replay: Optional[Callable[[], None]] = None
         self._grads_in_arena = True    # False after a step whose fused optimizer consumed weight-gradient slabs in place
 
     # ------------------------------------------------------------------------------------------
@@ -358,11 +361,13 @@ class UNetEngine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     # ---- stream plumbing: torch events when the step runs eagerly, plan records while a step plan is being recorded ---------------
-    def _mark(self, stream: "torch.cuda.Stream"):
-        """a point on `stream` that another stream can wait for"""
+    def _mark(self, stream: "torch.cuda.Stream", system_scope: bool = False):
+        """a point on `stream` that another stream can wait for.  system_scope: the waiter hands the data to another device (the
+        communication stream in front of a collective) - a recorded event then releases at system scope (torch's events always do);
+        the waits between the step's own streams keep the cheaper device-scope release they were measured with"""
         P = _lib._recording
         if P is not None:
-            return P.record(stream.cuda_stream)
+            return P.record(stream.cuda_stream, _lib.EVENT_SYSTEM if system_scope else _lib.EVENT_DEVICE)
         ev = torch.cuda.Event()
         ev.record(stream)
         return ev
@@ -374,8 +379,8 @@ class UNetEngine:
         else:
             stream.wait_event(token)
 
-    def _wait_stream(self, waiter: "torch.cuda.Stream", other: "torch.cuda.Stream") -> None:
-        self._wait(waiter, self._mark(other))
+    def _wait_stream(self, waiter: "torch.cuda.Stream", other: "torch.cuda.Stream", system_scope: bool = False) -> None:
+        self._wait(waiter, self._mark(other, system_scope))
 
     # ---- deferred optimizer steps ------------------------------------------------------------------------------------------
     def _defer_ctx(self, layer: str) -> "_lib.Context":
@@ -990,7 +995,11 @@ class UNetEngine:
                 tuple(sorted((k, c.version) for k, c in self._defer_ctxs.items())), tuple(l for _, l, _ in self._pending),
                 id(self.grad_ready_hook), self.hook_plan_aware, id(self.post_backward), self.overlap, self.chain_priority, self.fuse_adam, self.defer_adam, tuple(self.defer_layers),
                 self.defer_window_at, self.defer_rowsums, self.tail_on_chain, self.use_fused_head, self.fuse_u0_head, self.keep_pred, self.relu_bits,
-                self.ls_state is not None, self.workspace is not None, self.wgrad_workspace is not None, self.steps, self.rng_seed)
+                self.ls_state is not None, self.workspace is not None, self.wgrad_workspace is not None, self.steps, self.rng_seed,
+                # baked into recorded arguments (gct2_adam_keras_multi, gct2_loss_scale_begin) or restored into the per-layer
+                # gct2_adam_args by every replay: Trainer.compile() may legally rewrite them between steps
+                self.dtype, float(self.beta_1), float(self.beta_2), float(self.epsilon), float(self.base_lr), int(self.warm_up),
+                id(self.post_replay))
 
     def _planned_step(self, b: _Buffers, x: torch.Tensor, apply: bool, inline: bool, cur: "torch.cuda.Stream") -> torch.Tensor:
         key = self._plan_key(b, apply, inline, cur)
@@ -1007,12 +1016,27 @@ class UNetEngine:
             # recording fills the per-layer gct2_adam_args structs for THIS step, but the deferred launches of the previous step (which
             # the replay below enqueues first) read theirs when they are made: put those back before replaying
             held = {l: bytes(a) for _, l, a in self._pending}
+            # recording runs the step body with nothing enqueued: if it (or a hook) raises, every piece of host state it advanced goes
+            # back to where it was, the half-built plan is dropped, and the caller sees the exception with the engine as before the
+            # call (offsets and counters stayed advanced, _pending named launches whose slabs were never produced)
+            before = dict(pending=list(self._pending), pending_names=set(self._pending_names), pending_event=self._pending_event,
+                          bits_valid=b.bits_valid, grads_in_arena=self._grads_in_arena, post_backward_ran=self.post_backward_ran,
+                          structs={l: bytes(a) for l, a in self._adam_args.items()})
             sp = _StepPlan(b)
             sp.plan.begin(execute=False)
             try:
                 sp.loss = self._step_body(b, x, None, None, apply, inline)
-            finally:
+            except BaseException:
                 sp.plan.end()
+                self.rng_offset_t, self.rng_offset_eps, self._iterations = off_t, off_eps, its
+                self._pending, self._pending_names = before["pending"], before["pending_names"]
+                self._pending_event, b.bits_valid = before["pending_event"], before["bits_valid"]
+                self._grads_in_arena, self.post_backward_ran = before["grads_in_arena"], before["post_backward_ran"]
+                for l, raw in before["structs"].items():
+                    ctypes.memmove(ctypes.addressof(self._adam_args[l]), raw, len(raw))
+                self._plan_seen[key] = self.plan_after - 1     # (the next step of this shape tries again)
+                raise
+            sp.plan.end()
             sp.after = dict(pending=list(self._pending), pending_names=set(self._pending_names), bits_valid=b.bits_valid,
                             grads_in_arena=self._grads_in_arena, fused_layers=list(getattr(self, "_fused_layers", [])))
             # the per-layer gct2_adam_args structs are shared with eager steps (which may fill them differently: another deferral
@@ -1061,6 +1085,8 @@ class UNetEngine:
         self._iterations += sp.d_its
         self._pending, self._pending_names, self._pending_event = list(a["pending"]), set(a["pending_names"]), None
         sp.b.bits_valid, self._grads_in_arena = a["bits_valid"], a["grads_in_arena"]
+        if self.post_replay is not None:
+            self.post_replay()
         return sp.loss
 
     def predict(self, noised: torch.Tensor) -> torch.Tensor:

@@ -37,7 +37,7 @@ enum {
 };
 
 /* library / device identification ------------------------------------------------------------ */
-int gct2_abi_version(void);                 /* bumps when a signature below changes (v13: ReLU bit planes; v14: pruned tuning word, launch log, no deferred row sums; v15: launch-log read reports the size it needs, step plans; v16: bias queue) */
+int gct2_abi_version(void);                 /* bumps when a signature below changes (v13: ReLU bit planes; v14: pruned tuning word, launch log, no deferred row sums; v15: launch-log read reports the size it needs, step plans; v16: bias queue; v17: plan event kinds - system-scope and timed records, gct2_plan_elapsed) */
 /* how the library was built: 0 for the product build; bit 0 (GCT2_BUILD_STAMP) = diagnostic build with in-kernel phase stamps
  * (make EXTRA=-DGCT2_STAMP).  Product hosts (the Python binding, bench.py, the tests) refuse a library whose flags are not 0. */
 enum { GCT2_BUILD_STAMP = 1 };
@@ -68,7 +68,10 @@ int gct2_ctx_set_wgrad_workspace(gct2_ctx* ctx, void* ws, size_t bytes);
  * same geometry, same order of additions, same "first writer overwrites, second adds" as the immediate launches, hence the same bits -
  * in two launches on `stream`.  All calls that fill one queue and its flush must be enqueued on ONE stream; a call whose rows do not fit
  * (or a 17th row set) first flushes what is queued and then reduces its own rows at once; buf = NULL returns to the immediate form and
- * drops row sets that were recorded and not flushed. */
+ * drops row sets that were recorded and not flushed.  Program order per target is kept whoever writes it (v17): a call that writes a
+ * bias gradient AT ONCE - direct kernels, an atomics epilogue taken for lack of row space, the db of a weight-gradient call - first
+ * flushes the queue if a queued row set names the same target, and of the combinations that can meet in the queue only "queued
+ * overwrite, then ONE add" is recorded together; a second add, a second overwrite or an overwrite behind a queued add flush first. */
 int gct2_ctx_set_bias_queue(gct2_ctx* ctx, void* buf, size_t bytes);
 int gct2_bias_queue_flush(gct2_ctx* ctx, void* stream);
 /* tuning: forces a tile / order instead of the automatic per-layer choice (same results for every value within the stated
@@ -377,6 +380,14 @@ int gct2_plan_add_call(gct2_plan* plan, const char* name, const uint64_t* args, 
 /* appends "record a new event on `stream`" / "make `stream` wait for event `event`" (an earlier add_record of this plan) */
 int gct2_plan_add_record(gct2_plan* plan, void* stream, int* event);
 int gct2_plan_add_wait(gct2_plan* plan, void* stream, int event);
+/* ABI v17: the same record with a chosen event kind.  GCT2_EVENT_DEVICE = gct2_plan_add_record (no timing, device-scope release:
+ * ordering between streams of one device); GCT2_EVENT_SYSTEM: no timing, system-scope release - for a record whose waiter hands
+ * the data to ANOTHER device (the stream a collective of the data-parallel exchange is issued on); GCT2_EVENT_TIMED: a timing
+ * event.  gct2_plan_elapsed: milliseconds between two TIMED records of the last run, both completed (the caller synchronised) -
+ * how bench.py brackets every layer call of a replayed step without a host round trip between the event and the launch. */
+enum { GCT2_EVENT_DEVICE = 0, GCT2_EVENT_SYSTEM = 1, GCT2_EVENT_TIMED = 2 };
+int gct2_plan_add_record_kind(gct2_plan* plan, void* stream, int kind, int* event);
+int gct2_plan_elapsed(gct2_plan* plan, int start_event, int end_event, float* ms);
 int gct2_plan_size(const gct2_plan* plan, int* records);
 int gct2_plan_set_arg(gct2_plan* plan, int index, int arg, uint64_t value);
 /* executes records [first, first + count) in order; stops at the first record that fails, returns its status (message:

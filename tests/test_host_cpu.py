@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gct2.h but not exported"
     # and the ctypes table binds exactly the declared entry points (minus last_error, bound separately)
     assert sorted(set(g._lib.SIGNATURES) | {"gct2_last_error"}) == names
-    assert g._lib.load().gct2_abi_version() == g._lib.ABI_VERSION == 16
+    assert g._lib.load().gct2_abi_version() == g._lib.ABI_VERSION == 17
     # the shipped library is the PRODUCT build: no in-kernel stamps, and the diagnostic hook refuses
     assert g._lib.build_flags() == 0
     c = g._lib.Context()
@@ -268,8 +268,25 @@ def test_bench_kernel_symbol_and_labels():
     import bench
     assert bench.kernel_symbol("wgrad:256q:rsplit=64:slabs") == "wgrad256q_kernel"
     assert bench.kernel_symbol("wgrad:128:rsplit=1:owner") == "wgrad_kernel"
-    assert bench.kernel_symbol("tap:conv:256x128:mask:ksplit=1:bits") == "tapgemm_kernel<conv,256x128>"
+    # one symbol per profiler row: the epilogue is part of it (r05 merged DownShuffle_1's forward with the UpShuffle input gradients)
+    assert bench.kernel_symbol("tap:conv:256x128:mask:ksplit=1:bits") == "tapgemm_kernel<conv,256x128,mask>"
+    assert bench.kernel_symbol("tap:conv:256x128:bias_act:ksplit=1:bits") == "tapgemm_kernel<conv,256x128,bias_act>"
+    assert bench.kernel_symbol("tap:convT:128x128:mask:ksplit=2:wstat") == "tapgemm_kernel<convT,128x128,mask>"
     assert bench.kernel_symbol("halo:convT:head") == "halo_convT_kernel<head>"
+    assert bench.kernel_symbol("halo:convT:mask:bits") == "halo_convT_kernel<mask>" != bench.kernel_symbol("halo:convT:bias_act:bits")
+    # ... and the mangled-name pattern that joins a symbol with a rocprofv3 --mangled-kernels row (scripts/compare_bench_rocprof.py)
+    assert bench.rocprof_pattern("tapgemm_kernel<conv,256x128,mask>") == "tapgemm_kernelI*Li0ELi256ELi128ELi1E"
+    assert bench.rocprof_pattern("halo_convT_kernel<head>") == "halo_convT_kernelI*Li2E"
+    assert bench.rocprof_pattern("wgrad256q_kernel") == "wgrad256q_kernelI"
+    # per call the MEDIAN over the measured steps, per symbol the sum of its calls' medians: one stalled sample changes nothing
+    names = [("wgrad", "wgrad256q_kernel", 1e11, ("U0", "wgrad")), ("wgrad", "wgrad256q_kernel", 1e11, ("U1", "wgrad")),
+             ("conv_form", "tapgemm_kernel<conv,256x128,mask>", 1e11, ("U0", "dgrad"))]
+    samples = [[0.10, 0.11, 0.10, 0.10, 0.12], [0.08, 0.08, 0.08, 0.09, 0.08], [0.14, 0.14, 33.0, 0.14, 0.15]]
+    rows, syms = bench.symbol_table(names, samples, 1)
+    assert abs(rows["wgrad256q_kernel"]["sum_median_ms"] - 0.18) < 1e-9 and syms["wgrad256q_kernel"]["launches_per_step"] == 2
+    t = syms["tapgemm_kernel<conv,256x128,mask>"]
+    assert t["avg_launch_us"] == 140.0 and t["max_us"] == 33000.0 and t["min_us"] == 140.0 and t["layers"] == ["U0.dgrad"]
+    assert max(rows, key=lambda k: rows[k]["sum_median_ms"]) == "wgrad256q_kernel"
     bench.call_label.size = 128
     # gct2_convT4s2_wgrad(ctx, dtype, x, ldx, dz, lddz, dw, db, B, H, W, Cin, Cout, acc, adam, stream) for UpShuffle_0 at config 3
     a = (0, 1, 0, 256, 0, 64, 0, None, 64, 64, 64, 256, 64, 0, None, None)

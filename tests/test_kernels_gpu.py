@@ -578,6 +578,80 @@ def test_bias_queue_flush_equals_the_immediate_row_sums(gpu, queue_floats):
         set_ws(None)
 
 
+@pytest.mark.parametrize("second", ["direct", "no_row_space", "overwrite_after_add", "two_overwrites"])
+def test_bias_queue_keeps_program_order_with_immediate_writers(gpu, second):
+    """a bias-gradient target keeps its program order whoever writes it.  First call: a Conv2DTranspose input gradient on
+    the MFMA path whose OVERWRITE of two targets is queued.  Second call on the same targets:
+      direct              - the direct kernels (force_direct) ADD at once: the queued overwrite must be reduced first, not behind it;
+      no_row_space        - the MFMA launch has no room for partial rows (workspace withdrawn) and adds with atomics at once: same;
+      overwrite_after_add - queued [overwrite, add], then an OVERWRITE: must not be reordered in front of the add;
+      two_overwrites      - a second OVERWRITE of the same target: last writer wins, no race inside the first flush launch.
+    Reference: the same chain without a queue (every reduction immediate)."""
+    dt, L = BF16, lib()
+    rng = np.random.default_rng(78)
+    ws = torch.empty(32 << 18, dtype=torch.float32, device=gpu)
+    B, H, W, Cin, Cout, split = 2, 16, 16, 128, 64, 64
+    x = rnd(np.maximum(rng.standard_normal((B, H, W, Cin)), 0), dt)
+    wt = rnd(rng.standard_normal((4, 4, Cout, Cin)) * 0.1, dt)
+    dzt = rnd(rng.standard_normal((B, 2 * H, 2 * W, Cout)), dt)
+    w = rnd(rng.standard_normal((4, 4, Cin, Cout)) * 0.1, dt)
+    dz = rnd(rng.standard_normal((B, H // 2, W // 2, Cout)), dt)
+    xd, wtd, dztd, wd, dzd = dev(x, dt, gpu), dev(wt, dt, gpu), dev(dzt, dt, gpu), dev(w, dt, gpu), dev(dz, dt, gpu)
+
+    def up(dx, dba, dbb, acc):          # Conv2DTranspose input gradient: channels [0, split) -> dba, the rest -> dbb
+        L.call("gct2_convT4s2_dgrad", ctx(), dt, dztd.data_ptr(), Cout, wtd.data_ptr(), xd.data_ptr(), Cin, dx.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 0, dba.data_ptr(), split, dbb.data_ptr(), acc, stream())
+
+    def down(dx, dbb, acc):             # Conv2D input gradient accumulated into dx: its skip channels -> dbb
+        L.call("gct2_conv4s2_dgrad", ctx(), dt, dzd.data_ptr(), Cout, wd.data_ptr(), xd.data_ptr(), Cin, dx.data_ptr(), Cin,
+               B, H, W, Cin, Cout, 1, None, split, dbb.data_ptr(), acc, stream())
+
+    def chain(queue):
+        set_ws(ws)
+        if queue is not None:
+            L.call("gct2_ctx_set_bias_queue", ctx(), queue.data_ptr(), queue.numel() * 4)
+        dba = torch.full((split,), float("nan"), device=gpu); dbb = torch.full((Cin - split,), float("nan"), device=gpu)
+        dx = torch.zeros(B, H, W, Cin, dtype=TDT[dt], device=gpu)
+        try:
+            up(dx, dba, dbb, 0)                                # queued: overwrite dba, overwrite dbb
+            if second == "direct":
+                ctx_obj().force_direct(True)
+                down(dx, dbb, 2)                               # immediate add (direct kernels, atomics)
+                ctx_obj().force_direct(False)
+            elif second == "no_row_space":
+                set_ws(None)
+                down(dx, dbb, 2)                               # immediate add (atomics in the MFMA epilogue)
+                set_ws(ws)
+            elif second == "overwrite_after_add":
+                down(dx, dbb, 2)                               # queued: add to dbb
+                up(dx, dba, dbb, 0)                            # overwrite both again: behind the add, not in front of it
+            else:
+                up(dx, dba, dbb, 0)                            # second overwrite of both targets
+            if queue is not None:
+                L.call("gct2_bias_queue_flush", ctx(), stream())
+            torch.cuda.synchronize()
+        finally:
+            ctx_obj().force_direct(False)
+            if queue is not None:
+                L.call("gct2_ctx_set_bias_queue", ctx(), None, 0)
+            set_ws(None)
+        return dba, dbb
+
+    ref = chain(None)
+    got = chain(torch.empty(1 << 20, dtype=torch.float32, device=gpu))
+    assert bool(torch.isfinite(ref[0]).all()) and bool(torch.isfinite(ref[1]).all())
+    tol = 0.0 if second in ("overwrite_after_add", "two_overwrites") else 2e-6        # (atomics: the order of the adds is not fixed)
+    for a, b in zip(ref, got):
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max()), second
+    # ... and against the oracle (the second call's contribution must be there / the last overwrite must have won)
+    c_t = (O.convT4s2_bwd(x, wt, dzt)[0] * (x > 0)).reshape(-1, Cin).sum(0)
+    c_c = (O.conv4s2_bwd(x, w, dz)[0] * (x > 0)).reshape(-1, Cin).sum(0)
+    want_b = c_t[split:] + (c_c[split:] if second in ("direct", "no_row_space") else 0.0)
+    scale = np.abs(c_t).max() + np.abs(c_c).max()
+    assert np.abs(got[0].cpu().numpy() - c_t[:split]).max() <= 4e-3 * scale
+    assert np.abs(got[1].cpu().numpy() - want_b).max() <= 4e-3 * scale
+
+
 @pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("shape", [(2, 8, 8, 256, 64), (1, 16, 16, 328, 72), (8, 4, 4, 512, 256)])
 def test_big_tile_dgrad_epilogues(gpu, shape, use_ws):

@@ -470,6 +470,74 @@ def test_planned_step_equals_eager_step_bit_for_bit(gpu, mode):
         assert torch.equal(out[0][1][n], out[1][1][n]), n
 
 
+@pytest.mark.parametrize("mode", ["fused", "loss_scaled"])
+def test_recompiled_hyperparameters_reach_replayed_steps(gpu, mode):
+    """Trainer.compile() may rewrite beta_1 / beta_2 / epsilon / base_lr / warm_up between steps (model.py); they are baked
+    into recorded arguments (gct2_adam_keras_multi, gct2_loss_scale_begin) and restored into the per-layer gct2_adam_args by every
+    replay, so they are part of a plan's key: after the change the planned engine must train exactly like the eager one."""
+    cfg = O.OracleConfig(size=64, pixel_size=128, max_size=512, octaves=4, batch_size=4)
+    params = O.init_params(cfg, seed=3)
+    xs = [torch.tensor(O.synthetic_batch(cfg, seed=k)[0], dtype=torch.float32, device=gpu) for k in range(3)]
+    out = []
+    for use_plan in (False, True):
+        eng = make_engine(cfg, 2 if mode == "loss_scaled" else 1, gpu, rng_seed=5, loss_scaling=(mode == "loss_scaled"))
+        eng.use_plan = use_plan
+        eng.set_params(params)
+        losses = []
+        for k in range(8):
+            if k == 4:                                        # what a second compile() does (model.py Trainer.compile)
+                eng.beta_1, eng.beta_2, eng.epsilon, eng.base_lr, eng.warm_up = 0.8, 0.99, 1e-5, 3e-4, 3
+            losses.append(eng.train_step(xs[k % 3]).clone())
+        torch.cuda.synchronize()
+        if use_plan:
+            assert len(eng._plans) >= 2                       # one plan per hyper-parameter set
+        out.append((torch.cat(losses), {n: getattr(eng.arena, n).clone() for n in ("p", "m", "v", "shadow")}))
+    assert torch.equal(out[0][0], out[1][0]), (out[0][0], out[1][0])
+    for n in ("p", "m", "v", "shadow"):
+        assert torch.equal(out[0][1][n], out[1][1][n]), n
+
+
+def test_failed_recording_leaves_the_engine_as_it_was(gpu):
+    """recording a step plan runs the step body with nothing enqueued; when it raises (a hook, a rejected argument) the
+    RNG offsets, the counters, the deferred-optimizer bookkeeping and the per-layer gct2_adam_args go back to where they were, the
+    half-built plan is dropped, and training continues bit for bit like an engine that never saw the failure."""
+    cfg = O.OracleConfig(size=64, pixel_size=128, max_size=512, octaves=4, batch_size=4)
+    params = O.init_params(cfg, seed=3)
+    xs = [torch.tensor(O.synthetic_batch(cfg, seed=k)[0], dtype=torch.float32, device=gpu) for k in range(3)]
+    out = []
+    for fail in (False, True):
+        eng = make_engine(cfg, 1, gpu, rng_seed=5)
+        eng.set_params(params)
+        losses = []
+        for k in range(6):
+            if fail and k == eng.plan_after - 1:              # the step that records: its reverse pass raises half-way
+                orig = eng._ready
+                seen = []
+
+                def boom(layer, stream=None):
+                    seen.append(layer)
+                    if layer == "U2":
+                        raise RuntimeError("hook failed while recording")
+                    return orig(layer, stream)
+                eng._ready = boom
+                state = (eng.rng_offset_t, eng.rng_offset_eps, eng.iterations, list(eng._pending), set(eng._pending_names))
+                with pytest.raises(RuntimeError, match="while recording"):
+                    eng.train_step(xs[k % 3])
+                eng._ready = orig
+                assert "U2" in seen and not eng._plans
+                assert state == (eng.rng_offset_t, eng.rng_offset_eps, eng.iterations, list(eng._pending), set(eng._pending_names))
+                import gan_class_transfer2_amd as g
+                assert g._lib._recording is None
+            losses.append(eng.train_step(xs[k % 3]).clone())
+        torch.cuda.synchronize()
+        assert len(eng._plans) >= 1
+        out.append((torch.cat(losses), {n: getattr(eng.arena, n).clone() for n in ("p", "m", "v", "shadow")},
+                    (eng.iterations, eng.rng_offset_t, eng.rng_offset_eps)))
+    assert torch.equal(out[0][0], out[1][0]) and out[0][2] == out[1][2]
+    for n in ("p", "m", "v", "shadow"):
+        assert torch.equal(out[0][1][n], out[1][1][n]), n
+
+
 @pytest.mark.parametrize("mode", ["fused", "apply_false", "loss_scaled"])
 def test_deferred_bias_row_sums_equal_the_immediate_ones_bit_for_bit(gpu, mode):
     """r05 / ABI v16: the eleven small launches that sum the partial rows of the fused bias gradients are replaced by ONE flush behind
