@@ -297,19 +297,31 @@ def noise_image_f16(x, t_int, eps, steps=200):
     return (x16 * sa).astype(h) + (e16 * sb).astype(h)
 
 
-def unet_forward(params, x0, cfg: OracleConfig, operand_round: Optional[str] = None):
+def unet_forward(params, x0, cfg: OracleConfig, operand_round: Optional[str] = None, keras_strict: bool = False):
     """Denoiser.call (train.py:206-215): `t` is ignored; returns (prediction, cache).
 
     operand_round in {None,'bf16','f16'} models the low-precision HIP path: weights and every
     stored activation are rounded to that type, accumulation stays in the array dtype.
-    The Dense head output is kept unrounded (the HIP path writes it as fp32)."""
+    The Dense head output is kept unrounded (the HIP path writes it as fp32).
+
+    keras_strict (with operand_round, r06): the two rounding points of Keras' mixed-precision policy (train.py:43-45) that the HIP
+    path - and therefore the default rounding model - leaves out, both in the direction of MORE precision: under `mixed_float16` a
+    layer's variables are cast to the compute dtype, its convolution / matmul returns a compute-dtype tensor, and the bias is
+    added to THAT in the compute dtype [TF] - z = rnd(rnd(conv) + rnd(b)) - where the HIP kernels add the fp32 bias to the fp32
+    accumulator and round once; the Dense(3) kernel and bias are cast as well.  (The second point - variable gradients are
+    compute-dtype tensors - is in unet_backward.)  Used to MEASURE the documented deviation (tests log it), never as the parity
+    target of the HIP path."""
     rnd = _rounder(operand_round)
     n = cfg.octaves
     # conv / transposed-conv kernels are consumed as rounded operands; the 67x3 Dense kernel stays fp32
-    wq = {k: (rnd(v) if k.endswith(".w") and k != "dense.w" else v) for k, v in params.items()}
+    wq = {k: (rnd(v) if k.endswith(".w") and (k != "dense.w" or keras_strict) else v) for k, v in params.items()}
+
+    def with_bias(z_nobias, b):         # the layer's pre-activation
+        return rnd(rnd(z_nobias) + rnd(b)) if keras_strict else z_nobias + b
+    zero = lambda b: np.zeros_like(b)
     xs = [rnd(x0)]                      # x_i : input of level i
     for i in range(n):
-        z = conv4s2_fwd(xs[i], wq[f"D{i}.w"], params[f"D{i}.b"])
+        z = with_bias(conv4s2_fwd(xs[i], wq[f"D{i}.w"], zero(params[f"D{i}.b"])), params[f"D{i}.b"])
         xs.append(rnd(np.maximum(z, 0)))
     # inner_{n-1} is Block(...) = identity (train.py:179, block_depth = 0)
     r = xs[n]                           # what UpShuffle_{n-1} consumes
@@ -317,17 +329,22 @@ def unet_forward(params, x0, cfg: OracleConfig, operand_round: Optional[str] = N
     uin = [None] * n
     for i in reversed(range(n)):
         uin[i] = r
-        z = convT4s2_fwd(r, wq[f"U{i}.w"], params[f"U{i}.b"])
+        z = with_bias(convT4s2_fwd(r, wq[f"U{i}.w"], zero(params[f"U{i}.b"])), params[f"U{i}.b"])
         u = rnd(np.maximum(z, 0))
         r = np.concatenate([u, xs[i]], axis=-1)
         rs[i] = r
-    pred = rs[0] @ wq["dense.w"] + params["dense.b"]       # Dense(3), linear (train.py:198-202)
+    pred = with_bias(rs[0] @ wq["dense.w"], params["dense.b"])       # Dense(3), linear (train.py:198-202)
     return pred, dict(xs=xs, rs=rs, uin=uin, wq=wq)
 
 
-def unet_backward(params, cache, dpred, cfg: OracleConfig, operand_round: Optional[str] = None):
+def unet_backward(params, cache, dpred, cfg: OracleConfig, operand_round: Optional[str] = None, keras_strict: bool = False):
     """hand-derived reverse pass; returns gradients for every parameter.
-    Stored activation gradients are rounded like the HIP path stores them."""
+    Stored activation gradients are rounded like the HIP path stores them.
+
+    keras_strict: every variable gradient is a COMPUTE-DTYPE tensor, as under Keras' mixed-precision policy [TF] (the gradient of
+    the variable's fp32 -> fp16 cast is the cast back of an fp16 tensor): rounded to `operand_round` on the way out, overflowing to
+    inf beyond the type's range (fp16: 65504 - which makes the reference's LossScaleOptimizer skip steps that the HIP path, with
+    its fp32 weight and bias gradients, applies)."""
     rnd = _rounder(operand_round)
     n = cfg.octaves
     xs, rs, uin, wq = cache["xs"], cache["rs"], cache["uin"], cache["wq"]
@@ -354,6 +371,9 @@ def unet_backward(params, cache, dpred, cfg: OracleConfig, operand_round: Option
         return dx + dR_i[..., fu:]
 
     down_pass(0, dR)
+    if keras_strict:
+        with np.errstate(over="ignore"):
+            g = {k: rnd(v) for k, v in g.items()}
     return g
 
 
@@ -383,7 +403,7 @@ def objective_terms(x, t_int, eps, steps: int = 200, predict_x: bool = True, pre
 
 
 def trainer_step(params, x, t_int, eps, cfg: OracleConfig, operand_round: Optional[str] = None, loss_scale: float = 1.0,
-                 objective: Optional[dict] = None):
+                 objective: Optional[dict] = None, keras_strict: bool = False):
     """Trainer.call (default branch predict_x=True; `objective` = keyword arguments of objective_terms selects the other
     branches of train.py:238-252): returns (loss, pred, grads, noised).
     loss = mean((x - pred)^2) in the working dtype (train.py:262-272);
@@ -394,10 +414,11 @@ def trainer_step(params, x, t_int, eps, cfg: OracleConfig, operand_round: Option
     train.py:263 casts to fp32 for the loss, and the gradient that enters it is fp16 as well - which is why the
     LossScaleOptimizer (train.py:82-83) multiplies the loss by `loss_scale` first; the returned gradients are the SCALED ones.
     (Known deviation kept out of this model and of the HIP path, DESIGN.md section 4: Keras also rounds every variable gradient
-    and the conv output before the bias add to fp16.)"""
+    and the conv output before the bias add to fp16.  keras_strict=True ADDS those two rounding points - unet_forward /
+    unet_backward - so that the size of the deviation can be measured: profiles/r06_parity.json.)"""
     f16 = operand_round == "f16"
     noised = noise_image_f16(x, t_int, eps, cfg.steps).astype(x.dtype) if f16 else noise_image(x, t_int, eps, cfg.steps)
-    pred, cache = unet_forward(params, noised, cfg, operand_round)
+    pred, cache = unet_forward(params, noised, cfg, operand_round, keras_strict)
     if f16:
         pred = round_f16(pred)
     target, w = objective_terms(x, t_int, eps, cfg.steps, **(objective or {}))
@@ -407,7 +428,7 @@ def trainer_step(params, x, t_int, eps, cfg: OracleConfig, operand_round: Option
     dpred = (2.0 * loss_scale / nel) * diff * w
     if f16:
         dpred = round_f16(dpred)
-    grads = unet_backward(params, cache, dpred, cfg, operand_round)
+    grads = unet_backward(params, cache, dpred, cfg, operand_round, keras_strict)
     return loss, pred, grads, noised
 
 

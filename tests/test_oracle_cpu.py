@@ -256,3 +256,30 @@ def test_objective_terms_and_fp16_noise_model():
     assert np.allclose(tg[:, 0, 0, 0], np.sqrt(a0) + 2 * np.sqrt(1 - a0)) and np.all(w == 1)
     n16 = O.noise_image_f16(x, t, e)
     assert n16.dtype == np.float16 and np.abs(n16.astype(np.float64) - O.noise_image(x, t, e)).max() < 4e-3
+
+
+def test_keras_strict_mode_adds_the_two_mixed_float16_rounding_points():
+    """r06: trainer_step(keras_strict=True) = the rounding model + the two points of Keras' mixed_float16 policy that the HIP path
+    leaves out (fp16 conv output before an fp16 bias add; fp16 variable gradients, inf on overflow).  Without a rounding type it is
+    the plain step; with one every gradient it returns is representable in that type, it differs from the default model by the
+    fp16 noise level (not more), and a gradient beyond 65504 overflows to inf as the reference's would."""
+    cfg = O.OracleConfig(size=16, batch_size=2, octaves=2, pixel_size=8, max_size=16)
+    rng = np.random.default_rng(5)
+    params = {k: v.astype(np.float64) for k, v in O.init_params(cfg, seed=1).items()}
+    for k in params:
+        if k.endswith(".b"):
+            params[k] = params[k] + 0.05 * rng.standard_normal(params[k].shape)
+    x, t, e = O.synthetic_batch(cfg, seed=0)
+    x, e = x.astype(np.float64), e.astype(np.float64)
+    plain, strict_plain = O.trainer_step(params, x, t, e, cfg), O.trainer_step(params, x, t, e, cfg, keras_strict=True)
+    assert plain[0] == strict_plain[0] and all(np.array_equal(plain[2][k], strict_plain[2][k]) for k in plain[2])
+    a = O.trainer_step(params, x, t, e, cfg, operand_round="f16", loss_scale=2.0 ** 10)
+    b = O.trainer_step(params, x, t, e, cfg, operand_round="f16", loss_scale=2.0 ** 10, keras_strict=True)
+    assert abs(a[0] - b[0]) <= 1e-3 * a[0] and 0 < np.abs(a[1] - b[1]).max() <= 5e-3 * np.abs(a[1]).max()
+    for k, g in b[2].items():
+        assert np.array_equal(g, g.astype(np.float16).astype(np.float64)), k           # an fp16 tensor
+        d = np.linalg.norm(a[2][k] - g) / np.linalg.norm(a[2][k])
+        assert 0 < d <= 5e-2, (k, d)
+    with np.errstate(over="ignore"):
+        c = O.trainer_step(params, x, t, e, cfg, operand_round="f16", loss_scale=2.0 ** 40, keras_strict=True)
+    assert any(not np.isfinite(g).all() for g in c[2].values())

@@ -138,7 +138,10 @@ def test_config2_bf16_vs_fp32_cpu_oracle(gpu, parity_log):
     assert abs(float(loss[0]) - loss_r) <= 1e-3 * loss_r and rel_l2(pred, pred_r) <= 3e-3
     for k, e in gerr.items():
         level = int(k[1]) if k[0] in "DU" else 0
-        assert e <= (1e-2, 2e-2, 3e-2, 4.5e-2, 8e-2, 1.4e-1)[level], (k, e)
+        # 1.5 x the measured worst tensor of each level (profiles/r05_parity.json: 1.1e-3 / 6.5e-3 / 1.5e-2 / 2.7e-2 / 4.1e-2 / 6.6e-2;
+        # the step is bitwise reproducible, so these only move when a kernel or the dispatch changes): a regression that doubles
+        # an error fails (r05 accepted 4.5e-2 / 8e-2 / 1.4e-1 at levels 3-5)
+        assert e <= (2e-3, 1e-2, 2.3e-2, 4.2e-2, 6.2e-2, 1.0e-1)[level], (k, e)
 
 
 def test_denoiser_eager_layers_match_planned_engine(gpu):
@@ -504,31 +507,31 @@ def test_failed_recording_leaves_the_engine_as_it_was(gpu):
     cfg = O.OracleConfig(size=64, pixel_size=128, max_size=512, octaves=4, batch_size=4)
     params = O.init_params(cfg, seed=3)
     xs = [torch.tensor(O.synthetic_batch(cfg, seed=k)[0], dtype=torch.float32, device=gpu) for k in range(3)]
+    import gan_class_transfer2_amd as g
     out = []
     for fail in (False, True):
         eng = make_engine(cfg, 1, gpu, rng_seed=5)
         eng.set_params(params)
-        losses = []
-        for k in range(6):
-            if fail and k == eng.plan_after - 1:              # the step that records: its reverse pass raises half-way
-                orig = eng._ready
-                seen = []
+        losses, raised = [], []
+        if fail:
+            orig = eng._ready
 
-                def boom(layer, stream=None):
-                    seen.append(layer)
-                    if layer == "U2":
-                        raise RuntimeError("hook failed while recording")
-                    return orig(layer, stream)
-                eng._ready = boom
-                state = (eng.rng_offset_t, eng.rng_offset_eps, eng.iterations, list(eng._pending), set(eng._pending_names))
-                with pytest.raises(RuntimeError, match="while recording"):
-                    eng.train_step(xs[k % 3])
-                eng._ready = orig
-                assert "U2" in seen and not eng._plans
+            def boom(layer, stream=None):                     # the first step that RECORDS: its reverse pass raises half-way
+                if layer == "U2" and g._lib._recording is not None and not raised:
+                    raised.append(layer)
+                    raise RuntimeError("hook failed while recording")
+                return orig(layer, stream)
+            eng._ready = boom
+        for k in range(6):
+            state = (eng.rng_offset_t, eng.rng_offset_eps, eng.iterations, list(eng._pending), set(eng._pending_names))
+            try:
+                losses.append(eng.train_step(xs[k % 3]).clone())
+            except RuntimeError as e:
+                assert fail and "while recording" in str(e) and raised == ["U2"]
+                assert not eng._plans and g._lib._recording is None
                 assert state == (eng.rng_offset_t, eng.rng_offset_eps, eng.iterations, list(eng._pending), set(eng._pending_names))
-                import gan_class_transfer2_amd as g
-                assert g._lib._recording is None
-            losses.append(eng.train_step(xs[k % 3]).clone())
+                losses.append(eng.train_step(xs[k % 3]).clone())          # the same step again: recorded this time
+        assert bool(raised) == fail
         torch.cuda.synchronize()
         assert len(eng._plans) >= 1
         out.append((torch.cat(losses), {n: getattr(eng.arena, n).clone() for n in ("p", "m", "v", "shadow")},
@@ -900,6 +903,19 @@ def test_config5_fp16_loss_scaling_at_size(gpu, parity_log):
                slice_worst_grad_rel_l2=max(gerr.values()), slice_worst_grad=max(gerr, key=gerr.get))
     rec.update({"slice_grad_rel_l2/" + k: v for k, v in gerr.items()})
     parity_log("config5_fp16_256x256", **rec)
+    # the documented deviation from Keras' mixed_float16 policy, MEASURED (logged, not asserted: the HIP path keeps more precision on
+    # purpose): the same slice against the oracle with the two extra rounding points - fp16 conv output before an
+    # fp16 bias add, fp16 variable gradients (inf beyond 65504) - and that stricter model against the default one
+    loss_k, pred_k, grads_k, _ = O.trainer_step(params, xs, ts, es, cfg2, operand_round="f16", loss_scale=2.0 ** 15, keras_strict=True)
+    finite = {k: bool(np.isfinite(v).all()) for k, v in grads_k.items()}
+    kerr = {k: (rel_l2(grads[k], grads_k[k]) if finite[k] else float("inf")) for k in grads}
+    merr = {k: (rel_l2(grads_ref[k], grads_k[k]) if finite[k] else float("inf")) for k in grads}
+    strict = dict(loss_rel_hip_vs_strict=abs(float(loss2[0]) - loss_k) / loss_k, pred_rel_l2_hip_vs_strict=rel_l2(b.pred.cpu().numpy(), pred_k),
+                  strict_model_overflows=sorted(k for k, f in finite.items() if not f),
+                  worst_grad_hip_vs_strict=max(kerr.values()), worst_grad_hip_vs_strict_name=max(kerr, key=kerr.get),
+                  worst_grad_default_model_vs_strict=max(merr.values()))
+    strict.update({"grad_hip_vs_strict/" + k: v for k, v in kerr.items()})
+    parity_log("config5_fp16_256x256_vs_keras_strict_model", **strict)
     assert rec["slice_loss_rel"] <= 1e-3 and rec["slice_pred_rel_l2"] <= 3e-3
     # gradient norms fall ~10x per level: even at scale 2^15 the activation gradients of the 8x8 / 4x4 levels sit in fp16's
     # subnormal range (< 6.1e-5, 10 -> 1..9 significant bits), where one summation-order flip is a per-cent change - the same
@@ -964,7 +980,9 @@ def test_config3_bf16_slice_vs_rounded_oracle(gpu, parity_log):
         # level to the kernel tolerance on the HIP path's own stored tensors; this end-to-end bound is the secondary check.)
         for k in grads:
             level = int(k[1]) if k[0] in "DU" else 0
-            assert gerr[k] <= (1e-2, 2e-2, 3e-2, 4.5e-2, 8e-2, 1.4e-1)[level], (name, k, gerr[k])
+            # bounds = 1.5 x the worst tensor of the level over the runs of this test (profiles/r05_parity.json: default dispatch
+            # 2.4e-3 / 8.9e-3 / 1.8e-2 / 2.8e-2 / 5.0e-2 / 8.9e-2, forced batch-64 dispatch 2.7e-3 / 9.4e-3 / 1.8e-2 / 3.1e-2 / 5.3e-2 / 6.1e-2)
+            assert gerr[k] <= (4.1e-3, 1.4e-2, 2.8e-2, 4.7e-2, 8e-2, 1.35e-1)[level], (name, k, gerr[k])
     # which kernels ran: the default run takes none of the batch-64 kernels of the big levels (that is the point), the forced run all of them
     ran = logs["b64_dispatch"]
     for token in B64_KERNELS:
