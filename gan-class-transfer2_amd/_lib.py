@@ -44,6 +44,7 @@ SIGNATURES = {
     "gct2_abi_version": [],
     "gct2_build_flags": [],
     "gct2_device_check": [],
+    "gct2_stream_occupy": [_vp, _i, _d],
     "gct2_ctx_create": [C.POINTER(C.c_void_p)],
     "gct2_ctx_destroy": [_vp],
     "gct2_ctx_set_workspace": [_vp, _vp, _sz],
@@ -166,7 +167,7 @@ def call(name: str, *args) -> None:
 
 # the entry points a plan can hold (csrc/plan.hip ENTRIES): everything that enqueues work on a stream + the one-shot ReLU plane
 PLANNABLE = frozenset(n for n, sig in SIGNATURES.items() if n == "gct2_ctx_set_relu_bits" or (
-    not n.startswith(("gct2_ctx_", "gct2_plan_", "gct2_loss_scale_init")) and n not in ("gct2_abi_version", "gct2_build_flags", "gct2_device_check")))
+    not n.startswith(("gct2_ctx_", "gct2_plan_", "gct2_loss_scale_init")) and n not in ("gct2_abi_version", "gct2_build_flags", "gct2_device_check", "gct2_stream_occupy")))
 _recording = None      # the Plan that is recording calls right now (one host thread drives an engine: _lib.call is not re-entrant)
 _FLOAT_STRUCT = struct.Struct("<f")
 _DOUBLE_STRUCT = struct.Struct("<d")

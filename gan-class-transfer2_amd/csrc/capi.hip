@@ -297,6 +297,12 @@ int gct2_device_check(void) {
   return GCT2_OK;
 }
 
+int gct2_stream_occupy(void* stream, int workgroups, double microseconds) {
+  if (workgroups < 1 || workgroups > 1024 || !(microseconds >= 0.0) || microseconds > 20000.0)
+    return gct2_fail(GCT2_EINVAL, "stream_occupy: 1..1024 work-groups for 0..20000 us (got %d, %g)", workgroups, microseconds);
+  return pw_occupy(workgroups, (unsigned long long)(microseconds * 100.0), S(stream));
+}
+
 int gct2_conv4s2_fwd(gct2_ctx* ctx, int dtype, const void* x, int ldx, const void* w, const float* bias, void* y, int ldy, int B, int H, int W,
                      int Cin, int Cout, int relu, void* stream) {
   gct2_ctx& c = C(ctx);

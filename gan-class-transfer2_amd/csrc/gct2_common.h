@@ -334,6 +334,7 @@ __device__ __forceinline__ bool xcd_tile(int id, int m_tiles, int inner, int chu
 
 // the atomic fall-backs of the fused bias gradients add into their targets: overwritten targets start from zero
 // bias queue of a call context (tapgemm_mfma.hip): record the partial rows a launch left in the queue buffer / reduce everything recorded
+int pw_occupy(int workgroups, unsigned long long ticks, hipStream_t s);      // pointwise.hip: gct2_stream_occupy
 int tapgemm_dbq_push(gct2_ctx& c, const float* part, int rows, const TapGemmParams& p, hipStream_t s);
 int tapgemm_dbq_flush(gct2_ctx& c, hipStream_t s);
 int tapgemm_dbq_flush_for(gct2_ctx& c, const float* db, int n0, const float* db2, int n1, hipStream_t s);   // in front of an immediate writer

@@ -1208,3 +1208,16 @@ int pw_relu_bits(int dtype, const void* y, int ldy, size_t pixels, int channels,
   else hipLaunchKernelGGL(relu_bits_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)y, ldy, pixels, groups, bits, ldbits);
   return gct2_check_launch("relu_bits");
 }
+
+// gct2_stream_occupy: hold `workgroups` work-group slots for `ticks` of the constant 100-MHz counter.  Every wave watches its own
+// clock, so every wave reaches the exit whatever the others do.
+namespace {
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+}  // namespace
+int pw_occupy(int workgroups, unsigned long long ticks, hipStream_t s) {
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), 0, s, ticks);
+  return gct2_check_launch("stream_occupy");
+}

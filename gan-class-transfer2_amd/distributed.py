@@ -52,6 +52,24 @@ class _Plumbing:
             fn()
 
 
+def _comm_stream(engine, device):
+    """the communication stream of a wrapper: the engine's registered "comm" stream - one that shares a hardware queue neither with
+    the caller's stream nor with the weight-gradient side stream, and the same one for every wrapper of this caller (engine.py
+    distinct_stream) - or a plain new stream for a stand-alone reducer"""
+    f = getattr(engine, "stream_for", None)
+    return f("comm") if f is not None else torch.cuda.Stream(device=device)
+
+
+def _warm_up_collective(group, stream, device) -> None:
+    """ONE tiny collective on the communication stream at construction: the collective library creates its communicator and takes its
+    internal streams at a DEFINED point of the process (its first call), not in the middle of the first timed step"""
+    if not dist.is_initialized():
+        return
+    with torch.cuda.stream(stream):
+        dist.all_reduce(torch.zeros(64, dtype=torch.float32, device=device), op=dist.ReduceOp.SUM, group=group)
+    stream.synchronize()
+
+
 class BucketedAllReducer:
     """sums `flat[lo:hi]` across ranks, one collective per bucket of consecutive layers.
 
@@ -77,7 +95,9 @@ class BucketedAllReducer:
                 self.buckets.append((lo, h))
                 lo = None
         self.on_cuda = flat.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=flat.device) if self.on_cuda else None
+        self.comm_stream = _comm_stream(engine, flat.device) if self.on_cuda else None
+        if self.on_cuda and self.exchange:
+            _warm_up_collective(group, self.comm_stream, flat.device)
         self.works: List[Optional[object]] = [None] * len(self.buckets)
         self.launched = 0
 
@@ -267,7 +287,9 @@ class ShardedDataParallelStep:
         # last_layer[k]: index of the layer that holds the last element of bucket k (the bucket is complete when it is ready)
         self.last_layer = [next(i for i, e in enumerate(ends) if e >= hi) for _, hi in self.buckets]
         self.on_cuda = A.g.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=A.g.device) if self.on_cuda else None
+        self.comm_stream = _comm_stream(engine, A.g.device) if self.on_cuda else None
+        if self.on_cuda and self.exchange:
+            _warm_up_collective(group, self.comm_stream, A.g.device)
         self.pl = _Plumbing(engine)
         engine.grad_ready_hook = self._grad_ready
         engine.hook_plan_aware = True          # the hook does its plumbing through the engine: recorded with the step

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
@@ -214,6 +215,61 @@ class _StepPlan:
         self.x_ref = None
 
 
+# ---- stream placement -------------------------------------------------------------------------------------------------------------
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues in the order the streams are first
+# used, and two streams on one queue block each other for the whole run.  Which queue a new stream lands on depends on how many
+# streams the process used before - the collective library's included - so "the next stream of the pool" made the same engine run
+# 2.49 or 2.78 ms per step depending on its position in the process (scripts/probe_stream_queues.py, profiles/r06_stream_queues.txt:
+# pool streams 0 and 4 share the caller's queue, 1 and 5 each other's, ...).  The streams an engine and its data-parallel wrapper
+# use are therefore (a) PROBED: a candidate is taken only if a marker on it does not wait for a 300-us occupy on any stream it has
+# to run beside (gct2_stream_occupy), and (b) REGISTERED per (device, caller stream, role): the third engine of a process runs on
+# the same streams as the first.
+_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+_STREAM_LOG: list = []              # (role, candidate index, microseconds the marker waited per avoided stream) - scripts print it
+
+
+def _marker_delay_us(busy: "torch.cuda.Stream", cand: "torch.cuda.Stream", device: torch.device, occupy_us: float = 300.0) -> float:
+    """microseconds between the start of an occupy on `busy` and the end of a trivial launch enqueued on `cand` right behind it:
+    a few us when the two streams sit on different hardware queues, >= occupy_us when they share one"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    e0.record(busy)
+    call("gct2_stream_occupy", busy.cuda_stream, 1, float(occupy_us))
+    call("gct2_stream_occupy", cand.cuda_stream, 1, 1.0)
+    e1.record(cand)
+    cand.synchronize()
+    busy.synchronize()
+    return e0.elapsed_time(e1) * 1e3
+
+
+def distinct_stream(device: torch.device, role: str, caller: "torch.cuda.Stream", priority: int = 0, tries: int = 8) -> "torch.cuda.Stream":
+    """the stream of `role` ("side", "chain", "comm") for work launched beside `caller` on `device`: registered once per (device,
+    caller, role); a new one is the first of up to `tries` pool streams that shares a hardware queue neither with the caller nor
+    with the streams already registered for this caller (GCT2_STREAM_PROBE=0: the first candidate, unprobed)."""
+    key = (device.index, caller.cuda_stream, role)
+    st = _STREAMS.get(key)
+    if st is not None:
+        return st
+    avoid = [caller] + [v for (d, c, _), v in _STREAMS.items() if d == device.index and c == caller.cuda_stream]
+    probe = os.environ.get("GCT2_STREAM_PROBE", "1") != "0"
+    best, best_wait = None, None
+    for k in range(tries if probe else 1):
+        cand = torch.cuda.Stream(device=device, priority=priority)
+        if any(cand.cuda_stream == a.cuda_stream for a in avoid):
+            continue
+        waits = [_marker_delay_us(a, cand, device) for a in avoid] if probe else []
+        _STREAM_LOG.append((role, k, [round(w, 1) for w in waits]))
+        worst = max(waits) if waits else 0.0
+        if best is None or worst < best_wait:
+            best, best_wait = cand, worst
+        if worst < 150.0:                                  # (half of the occupy: a shared queue shows >= 300)
+            break
+    if best is None:
+        best = torch.cuda.Stream(device=device, priority=priority)
+    _STREAMS[key] = best
+    return best
+
+
 _ADAM_INPUT_FIELDS = ("p", "m", "v", "shadow", "shadow_dtype", "n", "beta1", "beta2", "eps", "grad_mul", "defer")
 
 
@@ -261,7 +317,9 @@ class UNetEngine:
         # beside the dgrad chain instead of between its links (backward())
         self.overlap = True
         self.fuse_adam = True          # per-layer Adam fused behind the weight-gradient calls (single replica, no loss scaling)
-        self._side = torch.cuda.Stream(device=self.device)
+        # (a stream that shares no hardware queue with the caller's; the same one for every engine of this caller: distinct_stream)
+        self._caller0 = torch.cuda.current_stream(self.device)
+        self._side = distinct_stream(self.device, "side", self._caller0)
         # chain_priority: run the dgrad chain (the only true dependency chain of the reverse pass, with its short split-K finalize /
         # row-sum launches) on a HIGH-priority stream of its own, so that its work-groups are dispatched ahead of the side stream's
         # queued weight-gradient work-groups.  Worth -2 % when it was introduced (r02.c); since the image layer's weight gradient
@@ -359,6 +417,10 @@ class UNetEngine:
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def stream_for(self, role: str) -> "torch.cuda.Stream":
+        """the registered stream of `role` beside this engine's caller stream (the data-parallel wrappers ask for "comm")"""
+        return distinct_stream(self.device, role, self._caller0)
 
     # ---- stream plumbing: torch events when the step runs eagerly, plan records while a step plan is being recorded ---------------
     def _mark(self, stream: "torch.cuda.Stream", system_scope: bool = False):
@@ -739,7 +801,7 @@ class UNetEngine:
             self._bias_queue_on = want_queue
         caller = torch.cuda.current_stream(self.device)
         if self.overlap and self.chain_priority and self._chain_stream is None:
-            self._chain_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            self._chain_stream = distinct_stream(self.device, "chain", self._caller0, priority=-1)
         main = self._chain_stream if (self.overlap and self.chain_priority) else caller
         if main is not caller:
             self._wait_stream(main, caller)

@@ -44,6 +44,12 @@ enum { GCT2_BUILD_STAMP = 1 };
 int gct2_build_flags(void);
 const char* gct2_last_error(void);          /* host string describing the last non-OK return */
 int gct2_device_check(void);                /* GCT2_OK iff the current device is gfx950 */
+/* ABI v17, host plumbing: `workgroups` 256-thread work-groups that do nothing but hold their slots on `stream` for `microseconds`
+ * (every wave spins on the constant 100-MHz s_memrealtime counter and leaves by itself; at most 20 ms).  Two users: the host mirror
+ * finds out which of its streams the runtime put on ONE hardware queue (a short occupy on stream A, a marker behind a trivial one on
+ * stream B: B finishing only after A means they share a queue and would block each other for the whole run - engine.py
+ * `distinct_stream`), and scripts/bench_dp_overhead.py stands a collective's wire time in for a collective on a one-GPU box. */
+int gct2_stream_occupy(void* stream, int workgroups, double microseconds);
 /* ---- call context: caller-owned scratch + tuning, one per engine / host thread ------------------------------------------
  * The library keeps NO process-wide mutable state (ABI v11).  A gct2_ctx is a small host object created by the caller; it
  * carries (a) the caller's device scratch for split reductions / partial rows and (b) the tile-selection knobs.  A ctx is used by
