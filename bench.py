@@ -534,7 +534,10 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "loss": loss_val,
             "library": {"abi": int(_lib.load().gct2_abi_version()), "build_flags": int(_lib.build_flags())},
-            "host": {"step_plan": bool(eng.use_plan), "enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 4)},
+            # stream_picks: (role, pool candidate, us a marker on it waited behind an occupy on each stream it runs beside) - a candidate
+            # that shares a hardware queue with one of them (>= 300 us) is passed over (engine.distinct_stream)
+            "host": {"step_plan": bool(eng.use_plan), "enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 4),
+                     "stream_picks": [list(p_) for p_ in engine_mod._STREAM_LOG]},
             "comm": comm,
             "flops_per_image": f_img,
             "step_roofline_frac": round(imgs / world * f_img / MFMA_PEAK, 5),

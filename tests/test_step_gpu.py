@@ -248,6 +248,43 @@ def test_data_parallel_exchange_streams_single_rank(gpu):
         dist.destroy_process_group()
 
 
+def test_stream_placement_is_probed_and_independent_of_creation_order(gpu):
+    """the HIP runtime puts a process's streams on 4 hardware queues in the order of their first use, and two
+    streams on one queue block each other - "the next stream of the pool" made the same engine 10 % slower as the first engine of a
+    process that had initialised the collective library than as a later one (profiles/r06_stream_queues.txt).  The engine's side
+    stream and a wrapper's communication stream are therefore PROBED (a marker on the candidate must not wait for an occupy on any
+    stream it runs beside) and REGISTERED per caller: the third engine + wrapper of a process run on the very streams of the first -
+    what a step costs cannot depend on the position any more - and the probe itself recognises a shared queue."""
+    import socket
+    import torch.distributed as dist
+    from gan_class_transfer2_amd import engine as E
+    from gan_class_transfer2_amd.distributed import DataParallelStep, ShardedDataParallelStep
+    cfg = O.OracleConfig(size=32, pixel_size=64, max_size=128, octaves=3, batch_size=4)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=gpu)
+    try:
+        caller = torch.cuda.current_stream(gpu)
+        picked = []
+        for k in range(3):
+            for _ in range(k):
+                torch.cuda.Stream(device=gpu)                  # other users of the stream pool in between
+            eng = make_engine(cfg, 1, gpu)
+            st = (ShardedDataParallelStep if k % 2 else DataParallelStep)(eng, force_exchange=True)
+            comm = st.comm_stream if k % 2 else st.reducer.comm_stream
+            picked.append((eng._side.cuda_stream, comm.cuda_stream))
+            side = eng._side
+        assert picked[0] == picked[1] == picked[2] and len({caller.cuda_stream, *picked[0]}) == 3
+        # the three streams of a data-parallel step sit on three hardware queues ...
+        for a, b in ((caller, side), (caller, comm), (side, comm)):
+            assert E._marker_delay_us(a, b, gpu) < 150.0, (a, b)
+        # ... and the probe would have seen a shared one: a stream always waits for itself
+        assert E._marker_delay_us(side, side, gpu) >= 290.0
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("scheme", ["allreduce", "sharded", "sharded_loss_scaled"])
 def test_data_parallel_step_recorded_in_a_plan_equals_the_eager_one(gpu, scheme):
     """the data-parallel wrappers' hooks are recorded WITH the step (stream waits and per-bucket Adam as plan records, every collective
