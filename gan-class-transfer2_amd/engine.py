@@ -350,6 +350,11 @@ class UNetEngine:
         # r05: the eleven small launches that sum the partial rows of the fused bias gradients leave the input-gradient chain - the calls
         # queue their rows (gct2_ctx_set_bias_queue) and ONE flush (two launches) behind the last input gradient sums them: same bits
         self.defer_rowsums = True
+        # EXPERIMENT (r06; off): the outer `split_forward_levels` levels of the forward pass of a train step run as
+        # TWO half-batch chains on two streams (convolutions are image-local, train.py:148-166), so that the tail of one chain's launch
+        # overlaps the head of the other's - prices the launch ramp / drain of those levels with the kernels that exist
+        self.split_forward_levels = 0
+        self._split_ctxs: Dict[int, "_lib.Context"] = {}
         self._bias_queue = None
         self._bias_queue_on = False
         self._pending: list = []
@@ -636,6 +641,24 @@ class UNetEngine:
         def plane(level: int, ch: int) -> None:                 # one-shot: applies to the layer call that follows
             if planes and b.bits[level] is not None:
                 self.ctx.set_relu_bits(b.bits[level].data_ptr() + ch // 8, b.ld[level] // 8)
+        # two half-batch chains for the outer levels (experiment, see __init__): chain 0 on the current stream, chain 1 on the side stream
+        L = min(int(self.split_forward_levels), n - 1) if (in_step and self.overlap and b.B % 2 == 0 and dt != F32) else 0
+        es, Bh = self._esize(), b.B // 2
+        side = self._side
+
+        def split_ctx(tuning: int) -> "_lib.Context":
+            # the tile the FULL batch would take, forced (a half batch falls below the automatic thresholds), never split-K: no scratch,
+            # so both chains may share the context; one context per tuning word because setters are not part of a step plan
+            c = self._split_ctxs.get(tuning)
+            if c is None:
+                c = self._split_ctxs[tuning] = _lib.Context()
+                c.set_tuning(tuning)
+            return c
+
+        def halves():
+            return ((0, cur), (1, side))
+        if L:
+            self._wait_stream(side, cur)                       # the noised image is there
         for i in range(n):                                      # DownShuffle_i  (train.py:184)
             H, W = b.hw[i]
             if i < n - 1:
@@ -643,6 +666,17 @@ class UNetEngine:
             else:
                 y, ldy = b.Dlast.data_ptr(), t.fd(i)
             x, ldx = (b.img.data_ptr(), 4) if i == 0 else (self._slice_ptr(b.R[i], t.fu(i)), b.ld[i])
+            if i < L:
+                tiles256 = ((b.B * (H // 2) * (W // 2) + 255) // 256) * ((t.fd(i) + 127) // 128)
+                c = split_ctx((5 if tiles256 >= 512 else 2) | (1 << 8))
+                for h, st in halves():
+                    if planes and b.bits[i + 1] is not None:
+                        c.set_relu_bits(b.bits[i + 1].data_ptr() + t.fu(i + 1) // 8 + h * Bh * (H // 2) * (W // 2) * (b.ld[i + 1] // 8), b.ld[i + 1] // 8)
+                    call("gct2_conv4s2_fwd", c.handle, dt, x + h * Bh * H * W * ldx * es, ldx, A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"),
+                         y + h * Bh * (H // 2) * (W // 2) * ldy * es, ldy, Bh, H, W, t.cx(i), t.fd(i), 1, st.cuda_stream)
+                if i == L - 1:
+                    self._wait_stream(cur, side)
+                continue
             if i < n - 1:
                 plane(i + 1, t.fu(i + 1))
             call("gct2_conv4s2_fwd", cx, dt, x, ldx, A.wptr(f"D{i}.w"), A.pptr(f"D{i}.b"), y, ldy, b.B, H, W, t.cx(i), t.fd(i), 1, s)
@@ -658,8 +692,20 @@ class UNetEngine:
                 x, ldx = b.Dlast.data_ptr(), t.fd(i)
             if f"U{i}" in self._pending_names or i == 0:
                 join_pending()
+            if i == 0 and L > 1:
+                self._wait_stream(cur, side)                   # both chains of the levels above are done
             if i == 0 and stop_before_u0:
                 return b.pred
+            if 1 <= i < L:
+                if i == L - 1:
+                    self._wait_stream(side, cur)               # UpShuffle_L's output (and the deferred updates joined above)
+                c = split_ctx(2 << 24)                         # the halo kernel wherever it is allowed, as at the full batch
+                for h, st in halves():
+                    if planes and b.bits[i] is not None:
+                        c.set_relu_bits(b.bits[i].data_ptr() + h * Bh * 4 * Hi * Wi * (b.ld[i] // 8), b.ld[i] // 8)
+                    call("gct2_convT4s2_fwd", c.handle, dt, x + h * Bh * Hi * Wi * ldx * es, ldx, A.wptr(f"U{i}.w"), A.pptr(f"U{i}.b"),
+                         b.R[i].data_ptr() + h * Bh * 4 * Hi * Wi * b.ld[i] * es, b.ld[i], Bh, Hi, Wi, t.up_in(i), t.fu(i), 1, st.cuda_stream)
+                continue
             if i >= 1:
                 plane(i, 0)
             call("gct2_convT4s2_fwd", cx, dt, x, ldx, A.wptr(f"U{i}.w"), A.pptr(f"U{i}.b"), b.R[i].data_ptr(), b.ld[i],
@@ -1061,7 +1107,8 @@ class UNetEngine:
                 # baked into recorded arguments (gct2_adam_keras_multi, gct2_loss_scale_begin) or restored into the per-layer
                 # gct2_adam_args by every replay: Trainer.compile() may legally rewrite them between steps
                 self.dtype, float(self.beta_1), float(self.beta_2), float(self.epsilon), float(self.base_lr), int(self.warm_up),
-                id(self.post_replay))
+                id(self.post_replay), int(self.split_forward_levels), self._side.cuda_stream,
+                self._chain_stream.cuda_stream if self._chain_stream is not None else 0)
 
     def _planned_step(self, b: _Buffers, x: torch.Tensor, apply: bool, inline: bool, cur: "torch.cuda.Stream") -> torch.Tensor:
         key = self._plan_key(b, apply, inline, cur)

@@ -82,7 +82,9 @@ stamps = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
 OFF = 1 << 19
 print(f"# in-kernel clock of the K loops, config 3 (3x128x128, batch 64, bf16), >= {args.seconds} s of back-to-back launches before the stamped one")
 print("# phases of a work-group's life from s_memrealtime: setup = entry -> K loop, loop, epilogue = K loop end -> stores drained; span = first entry -> last exit")
-print("# layer       kernel                                      clock GHz (median p10 p90)   setup / K loop / epilogue us (median per wave)   waves   PFLOP/s in loop   span us   launch us")
+print("# idle CU-us (r06) = span x 256 CUs - (sum of every wave's life, entry -> drained stores) / (waves resident per CU): the CU-time of the launch in which a wave slot")
+print("#   was empty - start skew, drain, rounds that do not fill the chip; 'idle %' = that / (span x 256).  The K-loop / setup / epilogue split of the busy part is in the phase columns.")
+print("# layer       kernel                                      clock GHz (median p10 p90)   setup / K loop / epilogue us (median per wave)   waves   PFLOP/s in loop   span us   launch us   idle CU-us  idle %")
 for lab in [s for s in args.layers.split(",") if s]:
     if lab not in calls:
         print(f"{lab:12s} (no such call)")
@@ -112,11 +114,14 @@ for lab in [s for s in args.layers.split(",") if s]:
     for _ in range(8):                             # no gap in front of the stamped launch either: the last of these is read
         launch()
     torch.cuda.synchronize()
-    kern = [k for k in eng.ctx.read_launch_log() if not k.startswith("relu_bits")][-1]
+    kern = [k for k in eng.ctx.read_launch_log() if not k.startswith(("relu_bits", "bias_queue"))][-1]
     eng.ctx.log_launches(False)
     eng.ctx.set_stamp_buffer(None)
     c = stamps[OFF:].cpu().numpy().reshape(-1, 8)
     c = c[(c[:, 1] != 0) & (c[:, 3] > c[:, 1]) & (c[:, 5] != 0)]
+    if not len(c):
+        print(f"{lab:12s} {kern:42s}  (this kernel carries no stamps)   launch {us_launch:7.1f} us")
+        continue
     clk = (c[:, 2] - c[:, 0]) / (c[:, 3] - c[:, 1]) * 0.1          # cycles per 10 ns -> GHz
     setup_us, loop_us, epi_us = (c[:, 1] - c[:, 4]) / 100.0, (c[:, 3] - c[:, 1]) / 100.0, (c[:, 5] - c[:, 3]) / 100.0
     span = (c[:, 5].max() - c[:, 4].min()) / 100.0
@@ -126,6 +131,8 @@ for lab in [s for s in args.layers.split(",") if s]:
     per_wave = fl / nwaves
     resident = min(nwaves, 256 * 16 if "256x128" in kern else 256 * 8)     # waves resident at once: two 8-wave groups per CU, else 8 waves per CU
     rate = per_wave / (np.median(loop_us) * 1e-6) * resident / 1e15
+    life_us = float(((c[:, 5] - c[:, 4]) / 100.0).sum())
+    idle_cu_us = span * 256.0 - life_us / (resident / 256.0 if resident >= 256 else 1.0)
     ph = stamps[1 << 18:(1 << 18) + 8 * (1 << 15)].cpu().numpy().reshape(-1, 8)
     grp = (np.arange(len(ph)) % 8) // 4            # wave group of the entry (8 waves per work-group: waves 0-3 / 4-7 share SIMDs pairwise)
     for gsel in (0, 1):                            # --phases (make phases): cycles per steady-state stage of wgrad256q_kernel, by phase (mean over the waves of a group;
@@ -137,4 +144,4 @@ for lab in [s for s in args.layers.split(",") if s]:
             print(f"{lab:12s} waves {4 * gsel}-{4 * gsel + 3}: issue (front) {m[0]:5.0f} | reads {m[1]:5.0f} | 32 MFMA {m[2]:5.0f} | issue (behind) {m[3]:5.0f} | "
                   f"vmcnt wait {m[4]:4.0f} | barrier {m[5]:5.0f} | sum {m.sum():6.0f} cycles per stage ({int(q[:, 7].mean())} stages per wave)")
     print(f"{lab:12s} {kern:42s}  {np.median(clk):5.3f} {np.percentile(clk, 10):5.3f} {np.percentile(clk, 90):5.3f}      "
-          f"{np.median(setup_us):6.2f} / {np.median(loop_us):7.2f} / {np.median(epi_us):6.2f}   {nwaves:6d}   {rate:6.3f}   {span:7.1f}   {us_launch:7.1f}")
+          f"{np.median(setup_us):6.2f} / {np.median(loop_us):7.2f} / {np.median(epi_us):6.2f}   {nwaves:6d}   {rate:6.3f}   {span:7.1f}   {us_launch:7.1f}   {idle_cu_us:9.0f}   {100.0 * idle_cu_us / (span * 256.0):5.1f}")

@@ -510,6 +510,25 @@ def test_planned_step_equals_eager_step_bit_for_bit(gpu, mode):
         assert torch.equal(out[0][1][n], out[1][1][n]), n
 
 
+def test_split_forward_chains_equal_the_whole_batch_bit_for_bit(gpu):
+    """r06 experiment (engine.split_forward_levels, off by default): the outer levels of the forward pass as two half-batch chains on
+    two streams.  Convolutions are image-local (train.py:148-166) and each half runs the tile the full batch takes, so at BASELINE
+    config 3 every arena after three steps must EQUAL the whole-batch step's."""
+    import gan_class_transfer2_amd as g
+    x = (torch.randint(0, 256, (64, 128, 128, 3), generator=torch.Generator().manual_seed(3)).float() / 128 - 1).to(gpu)
+    out = []
+    for levels in (0, 3):
+        eng = g.UNetEngine(g.Topology(128, 512, 6), g.BF16, gpu, seed=7, rng_seed=9)
+        eng.split_forward_levels = levels
+        losses = [eng.train_step(x).clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        out.append((torch.cat(losses), {n: getattr(eng.arena, n).clone() for n in ("p", "m", "v", "shadow")}))
+        del eng
+    assert torch.equal(out[0][0], out[1][0]), (out[0][0], out[1][0])
+    for n in ("p", "m", "v", "shadow"):
+        assert torch.equal(out[0][1][n], out[1][1][n]), n
+
+
 @pytest.mark.parametrize("mode", ["fused", "loss_scaled"])
 def test_recompiled_hyperparameters_reach_replayed_steps(gpu, mode):
     """Trainer.compile() may rewrite beta_1 / beta_2 / epsilon / base_lr / warm_up between steps (model.py); they are baked
