@@ -488,16 +488,21 @@ def main():
             eng.overlap, eng.use_plan = overlap0, plan0
         return list(timer.names), samples
 
-    situ = iso = None
+    situ = iso = leg_error = None
     if not args.no_kernel_events:
-        # in-situ leg: the step as timed (two streams): what a call takes while it shares the chip with the other stream's kernels (a
-        # weight-gradient call includes its fused optimizer launch)
-        if eng.overlap:
-            situ = event_leg(True, False, 4)
-        # roofline leg: the same step on ONE stream, so that every launch has the chip to itself and its event-pair duration is the
-        # kernel's own (+ the helper launches of calls that have any: split-K finalize); the fused optimizer launch of every
-        # weight-gradient call is issued behind the call's end record (KernelTimer.split_adam)
-        iso = event_leg(False, True, args.event_steps)
+        # (the headline number is already measured: a failure in a per-kernel leg is reported in the line, it never costs the line)
+        try:
+            # in-situ leg: the step as timed (two streams): what a call takes while it shares the chip with the other stream's kernels
+            # (a weight-gradient call includes its fused optimizer launch)
+            if eng.overlap:
+                situ = event_leg(True, False, 4)
+            # roofline leg: the same step on ONE stream, so that every launch has the chip to itself and its event-pair duration is
+            # the kernel's own (+ the helper launches of calls that have any: split-K finalize); the fused optimizer launch of every
+            # weight-gradient call is issued behind the call's end record (KernelTimer.split_adam)
+            iso = event_leg(False, True, max(1, args.event_steps))
+        except Exception as e:           # noqa: BLE001 - reported, see above
+            leg_error = f"{type(e).__name__}: {e}"
+            iso = None
     comm = None
     if world > 1:
         # evidence of what RCCL ran (rank 0): ranks it saw, the buckets of one extra step and the HIP-event time of every collective
@@ -543,6 +548,8 @@ def main():
             "step_roofline_frac": round(imgs / world * f_img / MFMA_PEAK, 5),
         }
         out["roofline"] = {"bound": "mfma", "step_frac": out["step_roofline_frac"], "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s"}
+        if leg_error is not None:
+            out["roofline"]["leg_error"] = leg_error
         if iso is not None:
             names, samples = iso
             _, fams = symbol_table(names, samples, 0)

@@ -8,8 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 K=5
 EL="python3 $R/scripts/engine_layers.py --pmc $K"
 if [ "$1" != "pmc-only" ]; then
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_serial -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events --serial-streams > $O/p_serial.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_default -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/p_default.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --mangled-kernels --output-format csv -d $O/p_serial -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events --serial-streams > $O/p_serial.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --mangled-kernels --output-format csv -d $O/p_default -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/p_default.log 2>&1
 fi
 cd $R
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_fetch -- $EL > $O/p_fetch.log 2>&1
