@@ -22,7 +22,7 @@ if [ "$1" != "pmc-only" ]; then
 cp $(ls $O/p_serial/*/*kernel_stats.csv | head -1) $O/kernel_stats_serial.csv
 cp $(ls $O/p_default/*/*kernel_stats.csv | head -1) $O/kernel_stats_default.csv
 cp $(ls $O/p_default/*/*kernel_trace.csv | head -1) $O/kernel_trace_default.csv
-python scripts/trace_step.py $O/kernel_trace_default.csv > $O/step_trace.txt 2>&1 || true
+python scripts/trace_step.py $O/kernel_trace_default.csv 15 > $O/step_trace.txt      # (step 15 = the middle of the timed region of --warmup 5 --steps 20; later steps carry the event legs' records) 2>&1 || true
 tail -1 $O/p_serial.log | cut -c1-200
 tail -1 $O/p_default.log | cut -c1-200
 fi
