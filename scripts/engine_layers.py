@@ -24,6 +24,8 @@ ap.add_argument("--pmc", type=int, default=0)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--no-planes", action="store_true")
+ap.add_argument("--cu-mask", default="", help="replay on a stream created with hipExtStreamCreateWithCUMask: 'N' = the first N mask bits, "
+                "'N/8' = N bits spread over every group of 8 (bit i set iff i %% 8 < N/32) - what a launch costs on a share of the chip")
 ap.add_argument("--zeros", action="store_true", help="replay on all-zero activations, gradients and weights (the DVFS test of MI355X_MICROARCH.md: same instruction stream, no operand toggling)")
 args = ap.parse_args()
 
@@ -120,9 +122,28 @@ if args.zeros:
     torch.cuda.synchronize()
 
 
+masked = None
+if args.cu_mask:
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = int(args.cu_mask.split("/")[0])
+    spread = "/" in args.cu_mask
+    words = (ctypes.c_uint32 * 8)()
+    for i in range(256):
+        if (i % 8 < n // 32) if spread else (i < n):
+            words[i // 32] |= 1 << (i % 32)
+    h = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+    assert rc == 0, f"hipExtStreamCreateWithCUMask failed ({rc})"
+    masked = torch.cuda.ExternalStream(h.value, device=dev)
+    print(f"# replayed on a CU-masked stream: {sum(bin(w).count('1') for w in words)} of 256 mask bits set ({'spread over every group of 8' if spread else 'the first bits'})")
+
+
 def replay(name, a, plane):
     if plane is not None:
         orig_call("gct2_ctx_set_relu_bits", *plane)
+    if masked is not None:
+        a = tuple(a[:-1]) + (masked.cuda_stream,)
     orig_call(name, *a)
 
 
@@ -143,10 +164,11 @@ for name, a, plane in calls:
     for _ in range(3):
         replay(name, a, plane)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    torch.cuda.synchronize()
+    e0.record(masked) if masked is not None else e0.record()
     for _ in range(args.iters):
         replay(name, a, plane)
-    e1.record()
+    e1.record(masked) if masked is not None else e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / args.iters
     tot_us += us
