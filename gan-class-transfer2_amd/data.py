@@ -101,7 +101,11 @@ class ImageDataset:
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         q: "queue.Queue" = queue.Queue(maxsize=max(1, self.prefetch))
         stop = threading.Event()
-        side = torch.cuda.Stream(device=self.device)
+        # the loader's own stream, picked like the engine's (engine.distinct_stream: one that shares a hardware queue neither with the
+        # consumer's stream nor with the streams a train step of this consumer already runs on)
+        from .engine import distinct_stream
+        dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        side = distinct_stream(dev, "data", torch.cuda.current_stream(dev))
 
         def worker():
             try:

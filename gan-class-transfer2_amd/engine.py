@@ -285,6 +285,8 @@ class UNetEngine:
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         if self.device.type != "cuda":
             raise _lib.Gct2Error("UNetEngine needs a HIP device (torch device 'cuda'); there is no CPU path")
+        if self.device.index is None:                       # ("cuda" without an index: the current device - the stream registry keys on it)
+            self.device = torch.device("cuda", torch.cuda.current_device())
         call("gct2_device_check")
         self.topo, self.dtype, self.steps = topo, dtype, steps
         self.base_lr, self.warm_up = base_lr, warm_up
