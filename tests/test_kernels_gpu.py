@@ -866,6 +866,38 @@ def test_noise_with_inkernel_rng_is_bit_identical(gpu):
     assert torch.equal(packed[:, :3], bb[:, 4:7]) and float(packed[:, 3].float().abs().max()) == 0
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_noise_rng_four_pixel_path_is_bit_identical(gpu, dt):
+    """r06: the train step's call of gct2_noise_image_rng (3 channels into the packed 4-slot image, nothing else, stream position a
+    multiple of 12, whole groups of four pixels) runs a kernel whose threads own three Philox counters = four whole pixels (16-byte
+    loads and stores).  Same counters, normals and mix as the general kernel - forced here by asking for eps as well - hence the same
+    bits; slot 3 of the packed image is written as zero."""
+    B, HW, C, steps = 5, 4 * 37, 3, 200
+    n = B * HW * C
+    x = ((torch.randint(0, 256, (B, HW, C)).float() / 128) - 1).to(gpu)
+    t = torch.tensor([1, 77, 200, 13, 150], dtype=torch.int32, device=gpu)
+    for off in (0, 12 * 1000 + 0, 3 * n):
+        general = torch.zeros(B * HW, 4, dtype=TDT[dt], device=gpu)
+        eps = torch.zeros(n, device=gpu)
+        lib().call("gct2_noise_image_rng", dt, x.data_ptr(), t.data_ptr(), 99, 2, off, eps.data_ptr(), general.data_ptr(), 4, None, 0,
+                   B, HW, C, steps, stream())
+        fast = torch.full((B * HW, 4), 3.0, dtype=TDT[dt], device=gpu)
+        lib().call("gct2_noise_image_rng", dt, x.data_ptr(), t.data_ptr(), 99, 2, off, None, fast.data_ptr(), 4, None, 0, B, HW, C, steps, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(general, fast), off
+        assert float(fast[:, 3].float().abs().max()) == 0 and float(fast[:, :3].float().abs().max()) > 0
+    # a stream position that is not a multiple of 12 takes the general kernel (slot 3 untouched) and still agrees with rng_normal
+    off = 12 * 50 + 5
+    fast = torch.full((B * HW, 4), 3.0, dtype=TDT[dt], device=gpu)
+    lib().call("gct2_noise_image_rng", dt, x.data_ptr(), t.data_ptr(), 99, 2, off, None, fast.data_ptr(), 4, None, 0, B, HW, C, steps, stream())
+    eps = torch.zeros(n, device=gpu)
+    lib().call("gct2_rng_normal", 99, 2, off, eps.data_ptr(), n, stream())
+    ref = torch.zeros(B * HW, 4, dtype=TDT[dt], device=gpu)
+    lib().call("gct2_noise_image", dt, x.data_ptr(), t.data_ptr(), eps.data_ptr(), ref.data_ptr(), 4, None, 0, B, HW, C, steps, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(fast[:, :3], ref[:, :3]) and float((fast[:, 3].float() - 3).abs().max()) == 0
+
+
 def test_rng_streams(gpu):
     """distributional checks (TF's Philox stream cannot be reproduced, SURVEY.md §8c 'RNG')."""
     n = 1 << 20
