@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import threading
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
@@ -225,6 +226,7 @@ class _StepPlan:
 # to run beside (gct2_stream_occupy), and (b) REGISTERED per (device, caller stream, role): the third engine of a process runs on
 # the same streams as the first.
 _STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+_STREAMS_LOCK = threading.Lock()    # (engines may be built from several host threads: one probe at a time, one registry)
 _STREAM_LOG: list = []              # (role, candidate index, microseconds the marker waited per avoided stream) - scripts print it
 
 
@@ -248,6 +250,14 @@ def distinct_stream(device: torch.device, role: str, caller: "torch.cuda.Stream"
     with the streams already registered for this caller (GCT2_STREAM_PROBE=0: the first candidate, unprobed)."""
     key = (device.index, caller.cuda_stream, role)
     st = _STREAMS.get(key)
+    if st is not None:
+        return st
+    with _STREAMS_LOCK:
+        return _pick_stream(key, device, role, caller, priority, tries)
+
+
+def _pick_stream(key: tuple, device: torch.device, role: str, caller: "torch.cuda.Stream", priority: int, tries: int) -> "torch.cuda.Stream":
+    st = _STREAMS.get(key)              # (another thread may have registered it while this one waited for the lock)
     if st is not None:
         return st
     avoid = [caller] + [v for (d, c, _), v in _STREAMS.items() if d == device.index and c == caller.cuda_stream]
