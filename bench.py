@@ -365,6 +365,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--kernel-events-multi", action="store_true", help="run the per-kernel legs at N > 1 too (default: N = 1 only)")
     ap.add_argument("--event-steps", type=int, default=8, help="measured steps of the per-kernel (roofline) leg; per call the median is reported")
     ap.add_argument("--variant", type=int, default=0, help="tapgemm tile variant hook (0 auto, 2, 3): A/B timing only")
     ap.add_argument("--no-plan", action="store_true", help="run every step through the interpreter (no recorded step plan): A/B of the host side")
@@ -489,7 +490,9 @@ def main():
         return list(timer.names), samples
 
     situ = iso = leg_error = None
-    if not args.no_kernel_events:
+    # N > 1: the per-kernel legs are off unless asked for (--kernel-events-multi): a rank-local failure inside a leg would leave the other
+    # ranks waiting in a collective, and the scaling runs only need `value`; the roofline block of a multi-GPU line carries step_frac
+    if not args.no_kernel_events and (world == 1 or args.kernel_events_multi):
         # (the headline number is already measured: a failure in a per-kernel leg is reported in the line, it never costs the line)
         try:
             # in-situ leg: the step as timed (two streams): what a call takes while it shares the chip with the other stream's kernels
